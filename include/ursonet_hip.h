@@ -1,0 +1,221 @@
+/*
+ * ursonet_hip.h -- C ABI of liburso_hip.so: the MI355X (gfx950) kernels behind the
+ * UrsoNet hot path (reference: /root/reference/net.py).
+ *
+ * The reference has NO FFI layer: every numeric op is a Keras/TensorFlow call
+ * (SURVEY.md 2.2).  Each entry point below therefore cites the Keras/TF call site in
+ * net.py that it replaces.  Conventions:
+ *   - plain C, no C++/torch types; returns 0 on success, negative URSO_E* on failure
+ *     (urso_last_error() gives the message);
+ *   - every pointer named *_d is a DEVICE pointer owned by the caller; kernels never
+ *     allocate -- workspace sizes come from the *_ws_bytes() queries;
+ *   - every launch takes the hipStream_t to enqueue on (void* here so the header is
+ *     plain C); no hidden global state except the opt-in profiler;
+ *   - activations are NHWC, row-major, dtype `dt` (URSO_F32 / URSO_BF16 / URSO_F16);
+ *     accumulation is always fp32; master weights, biases, BN tensors, gradients of
+ *     parameters and losses are fp32 in the Keras layouts (conv kernel HWIO
+ *     [kh][kw][cin][cout], dense kernel [in][out]).
+ */
+#ifndef URSONET_HIP_H
+#define URSONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URSO_OK            0
+#define URSO_EINVAL       -1   /* bad argument / unsupported shape            */
+#define URSO_ELAUNCH      -2   /* HIP launch or runtime error                 */
+#define URSO_EWORKSPACE   -3   /* caller-supplied workspace too small         */
+
+enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
+
+/* epilogue flags for urso_conv_igemm */
+#define URSO_EPI_RELU      1   /* y = max(y, 0)                 Activation('relu') net.py:104,109,116 ... */
+#define URSO_EPI_OUT_F32   2   /* store fp32 regardless of dt (head outputs)                              */
+
+const char* urso_last_error(void);
+int         urso_abi_version(void);           /* bumped on any signature change */
+
+/*
+ * Geometry of one implicit-GEMM convolution pass.  The kernel computes, for every
+ * destination pixel (b, oy, ox) and channel n:
+ *     dst[b,oy,ox,n] = sum_{ky,kx,c} src[b, iy, ix, c] * wgt[n, ky, kx, c]
+ *     with  ty = oy*SH - PH + ky,  iy = ty / DH  (term dropped unless ty % DH == 0 and 0 <= iy < H)
+ * and the same along x.  Forward conv: S = stride, P = pad_before, D = 1
+ * (KL.Conv2D / ZeroPadding2D, net.py:101-153,170-171,225-235,639; TF SAME asymmetry is
+ * expressed through P).  Data gradient of a stride-s conv: S = 1, P = k-1-pad_before,
+ * D = s with the filter taps flipped (prepared by urso_conv_weight_prep).
+ * Dense layers (KL.Dense, net.py:302,316,336,345-350) are the H=W=OH=OW=KH=KW=1 case.
+ */
+typedef struct urso_conv_geom {
+    int32_t B, H, W, C;        /* source tensor [B,H,W,C]                          */
+    int32_t OH, OW, N;         /* destination tensor [B,OH,OW,N]                   */
+    int32_t KH, KW;
+    int32_t SH, SW;
+    int32_t PH, PW;
+    int32_t DH, DW;            /* 1 or 2                                           */
+} urso_conv_geom;
+
+/*
+ * Fused implicit-GEMM convolution on MFMA (forward AND data-gradient passes).
+ *   dst = epilogue( conv(src, wgt) + bias[n] + add[m,n] ) ; then dst = 0 where mask[m,n] <= 0
+ * wgt_d : [N][KH][KW][C] in dt (K-contiguous; produced by urso_conv_weight_prep)
+ * bias_d: fp32 [N] or NULL;  add_d / mask_d: dt tensors shaped like dst, or NULL.
+ * Replaces Conv2D + (folded frozen) BatchNorm + Add + Activation('relu') of
+ * identity_block/conv_block/residual_basic_block (net.py:85-158, 216-240), Dense + ReLU of
+ * build_loc_graph/build_ori_graph (net.py:288-352), and their TF-generated gradients.
+ * C*sizeof(dt) must be a multiple of 16 bytes; every tensor < 2 GiB.
+ */
+int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
+                    const void* src_d, const void* wgt_d, const float* bias_d,
+                    const void* add_d, const void* mask_d, void* dst_d, void* stream);
+
+/*
+ * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):
+ *   dw_raw[ky][kx][c][n] = sum_{b,oy,ox} x[b,iy,ix,c] * dz[b,oy,ox,n]      (fp32, HWIO)
+ *   colsum[n]            = sum_{b,oy,ox} dz[b,oy,ox,n]                     (fp32, optional)
+ * `g` is the FORWARD geometry (src = x, dst = dz, D = 1).  Deterministic split over the
+ * pixel dimension with fp32 partials in ws_d (no atomics).
+ */
+size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt);
+int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                    void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream);
+
+/*
+ * Per-step weight preparation: folds the frozen BatchNorm that follows a conv
+ * (BatchNorm(...)(x, training=False), net.py:60-76,103-154; Keras eps 1e-3) into the
+ * filter and bias, casts to dt and lays the filter out for the MFMA kernels:
+ *   s[n]      = gamma[n] / sqrt(var[n] + eps)            (1 when there is no BN)
+ *   wf[n][ky][kx][c]            = W[ky][kx][c][n] * s[n]                     (forward)
+ *   wd[c][KH-1-ky][KW-1-kx][n]  = W[ky][kx][c][n] * s[n]                     (data-gradient; optional)
+ *   biasf[n]  = s[n]*b[n] + beta[n] - mean[n]*s[n]
+ * Any of b/gamma.. may be NULL (no bias / no BN).  Tiny heads (N = 3 or 4: loc_final, ori_q,
+ * net.py:316,345) are run with N padded to `npad` (multiple of 8) zero channels so that every
+ * tensor keeps 16-byte rows: wf is [npad][KH][KW][C], wd is [C][KH][KW][npad], biasf/scale are
+ * [npad] (zero / one in the padding).  npad >= N.
+ */
+int urso_conv_weight_prep(int KH, int KW, int C, int N, int npad, int dt,
+                          const float* w_d, const float* b_d,
+                          const float* gamma_d, const float* beta_d,
+                          const float* mean_d, const float* var_d, float eps,
+                          void* wf_d, void* wd_d, float* biasf_d, float* scale_d, void* stream);
+
+/*
+ * Stem (conv1/conv0: ZeroPadding2D(3) + Conv2D 7x7 s2, net.py:170-171,254-255) runs on the
+ * image viewed as pixel pairs [B,H,W/2,8] (channels padded 3->4): a 7(h) x 4(w) tap conv
+ * with S=(2,1), P=(3,2).  These two helpers pack the folded HWIO [7][7][3][N] filter into
+ * that geometry ([N][7][4][8]) and unpack the raw weight gradient ([7][4][8][N] -> [7][7][3][N]).
+ */
+int urso_stem_weight_pack(int N, int dt, const float* w_d, const float* b_d,
+                          const float* gamma_d, const float* beta_d, const float* mean_d,
+                          const float* var_d, float eps, void* wf_d, float* biasf_d,
+                          float* scale_d, void* stream);
+int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw_raw_d, void* stream);
+
+/*
+ * Parameter-gradient finalisation for one conv/dense layer (+ its folded BN):
+ *   gW[k][n] = s[n]*dw_raw[k][n] + (2*wd/numel(W)) * W[k][n]        (L2 term: net.py:1008-1012)
+ *   gb[n]    = s[n]*colsum[n]    + (2*wd/N) * b[n]
+ *   gbeta[n] = colsum[n]
+ *   ggamma[n]= rstd[n] * ( sum_k W[k][n]*dw_raw[k][n] + (b[n]-mean[n])*colsum[n] )
+ * (exact gradients of the frozen-BN layer w.r.t. gamma/beta recovered from the weight
+ * gradient -- no extra pass over activations).  Pointers for absent tensors are NULL.
+ * `trainable` = 0 writes zeros (layer.trainable False, net.py:1057-1062).
+ */
+int urso_param_grad_finalize(int K, int N, int ldn /* row stride of dw_raw (= npad) */,
+                             const float* dw_raw_d, const float* colsum_d,
+                             const float* w_d, const float* b_d,
+                             const float* gamma_d, const float* mean_d, const float* var_d,
+                             float eps, float weight_decay, int trainable, int bn_trainable,
+                             float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                             float* ws_d, size_t ws_bytes, void* stream);
+size_t urso_param_grad_finalize_ws_bytes(int K, int N);
+
+/* Input molding (mold_image, net.py:1337-1348): dst[b,h,w,0..3] = (src[b,h,w,c] - mean[c], 0) in dt.
+ * src is uint8 (src_is_u8=1) or float32 [B,H,W,3]; mean may be NULL (already molded). */
+int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,
+                     int dt, void* dst_d, void* stream);
+
+/* MaxPooling2D((3,3), strides=(2,2), padding="same") (net.py:176,258), H,W even.
+ * fwd also stores the arg-max tap (first maximum in row-major window order, 0..8).
+ * bwd: dx[b,iy,ix,c] = sum over windows whose arg-max is (iy,ix) of dy; with relu_mask=1 windows
+ * whose maximum is <= 0 contribute nothing (the ReLU in front of the pool, net.py:173). */
+int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const void* x_d, void* y_d,
+                          uint8_t* argmax_d, void* stream);
+int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const void* y_d, const void* dy_d,
+                          const uint8_t* argmax_d, int relu_mask, void* dx_d, void* stream);
+
+/*
+ * Losses (+ their gradients w.r.t. the head pre-activations), each followed by the
+ * batch-mean of net.py:997-1000.  loss_d is one fp32 scalar; `weight` is LOSS_WEIGHTS[name].
+ * The gradient includes `weight`.
+ */
+/* softmax_loss_graph net.py:705-711 (tf.losses.softmax_cross_entropy): loss = mean_b(-sum_k p*log_softmax(z));
+ * dz = (softmax(z) - p) * weight / B, zeroed where z <= 0 when relu_mask=1 (logits are post-ReLU, net.py:318,350). */
+int urso_softmax_xent_fwd_bwd(int B, int K, const float* logits_d /* [B][K] */, const float* labels_d,
+                              float weight, int relu_mask, int dt, float* loss_d, void* dz_d,
+                              float* row_ws_d, void* stream);
+/* rel_loss_graph net.py:750-762: loss = ||gt-pred||_F / ||gt||_F over the whole [B,D] tensor.
+ * norms_d (optional, fp32[2]) receives (sum (gt-pred)^2, sum gt^2). */
+int urso_rel_l2_fwd_bwd(int B, int D, int ld /* row stride of pred and dpred (padded heads) */,
+                        const float* gt_d /* [B][D] */, const float* pred_d, float weight,
+                        int dt, float* loss_d, void* dpred_d, float* norms_d, void* stream);
+/* K.l2_normalize (net.py:346) + one_minus_dot_prod_graph (net.py:724-733).
+ * q = x * rsqrt(max(sum x^2, 1e-12)) when normalize=1 (else q = x); loss = mean_b(1 - |gt.q|).
+ * gt_d may be NULL (inference: only q is produced). */
+int urso_absdot_fwd_bwd(int B, int D, int ld /* row stride of x and dx */, int normalize,
+                        const float* gt_d /* [B][D] */, const float* x_d,
+                        float weight, int dt, float* q_d /* [B][D] */, float* loss_d, void* dx_d, void* stream);
+/* mse_loss_graph net.py:735-748 */
+int urso_mse_fwd_bwd(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight,
+                     int dt, float* loss_d, void* dpred_d, void* stream);
+
+/*
+ * Optimizer (keras.optimizers.SGD(lr, momentum, clipnorm), net.py:979-981; Keras 2.x
+ * clipnorm is the GLOBAL gradient norm).  All tensors are flat fp32 of n elements.
+ *   urso_sqnorm: out[0] = sum g^2        (deterministic two-stage reduction; ws >= urso_sqnorm_ws_bytes)
+ *   urso_sgd_momentum_clip: c = (norm >= clip && clip > 0) ? clip/norm : 1;
+ *                           v = m*v - lr*c*g ; w += v
+ * hyper_d = device fp32 {lr, momentum, clipnorm} so that a captured hipGraph can be
+ * replayed with a changing learning rate (CyclicLR, clr_callback.py:121-133).
+ */
+size_t urso_sqnorm_ws_bytes(size_t n);
+int urso_sqnorm(size_t n, const float* g_d, void* ws_d, size_t ws_bytes, float* out_d, void* stream);
+int urso_sgd_momentum_clip(size_t n, float* w_d, const float* g_d, float* v_d,
+                           const float* hyper_d, const float* normsq_d, void* stream);
+int urso_scale_f32(size_t n, float* x_d, float s, void* stream);
+
+/*
+ * Probabilistic soft-argmax decode (pose_estimator.py:406-409 = utils.stable_softmax
+ * utils.py:26-28 + se3lib.quat_weighted_avg se3lib.py:217-260), batched on the GPU:
+ *   w = softmax(logits[b,:]);  A = sum_i w_i q_i q_i^T;  q = unit eigenvector of lambda_max(A)
+ * (sign normalised so the largest-magnitude component is positive; the reference's sign is
+ * eigen-solver dependent).  hquat_d: fp32 [K][4] bin->quaternion map; q_d: fp32 [B][4];
+ * a_d: optional fp32 [B][16].
+ */
+int urso_quat_wavg_decode(int B, int K, const float* logits_d, const float* hquat_d,
+                          float* q_d, float* a_d, void* stream);
+
+/*
+ * Opt-in launch profiler: when enabled every urso_* launch is bracketed by HIP events on
+ * its stream.  urso_prof_collect() synchronises and returns per-record milliseconds.
+ */
+typedef struct urso_prof_record {
+    int32_t kernel_id;         /* URSO_K_* below */
+    float   ms;
+    double  flops;             /* algorithmic FLOPs of the launch (2*MACs), 0 if n/a */
+    double  bytes;             /* algorithmic bytes (minimal read+write traffic)     */
+} urso_prof_record;
+enum { URSO_K_IGEMM = 1, URSO_K_WGRAD = 2, URSO_K_PREP = 3, URSO_K_FINALIZE = 4, URSO_K_POOL = 5,
+       URSO_K_LOSS = 6, URSO_K_OPTIM = 7, URSO_K_DECODE = 8, URSO_K_MOLD = 9 };
+int urso_prof_enable(int on);
+int urso_prof_collect(urso_prof_record* out, int max_records);   /* returns #records, clears */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URSONET_HIP_H */

@@ -1,0 +1,438 @@
+"""Oracle (test infrastructure): torch-CPU fp32 restatement of the reference's
+NN graph, losses and optimizer step.  PARITY UNPINNED for the TF/Keras arithmetic
+(see oracle/__init__.py): the reference holds no golden vectors for this path and
+TensorFlow 1.x / Keras 2.1.6-2.2.4 (requirements.txt:9-10) are not importable here.
+Each function cites the net.py lines it follows; third-party semantics are the
+ones listed in SURVEY.md Appendix A (A1..A13).
+
+Parameters are a dict {layer_name: {weight_name: np.ndarray}} in the Keras
+layouts (Conv kernel HWIO, Dense kernel [in,out], BN gamma/beta/moving_mean/
+moving_variance [C]) -- the "layer/weight API" of SURVEY.md Appendix B.
+"""
+import math
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # Keras BatchNormalization default epsilon            [A3]
+
+
+# --------------------------------------------------------------------------
+# layer inventory (names / shapes), in graph order
+# --------------------------------------------------------------------------
+def _deep_blocks(arch):
+    n4 = {"resnet50": 5, "resnet101": 22}[arch]                         # net.py:188
+    return [(2, ["a", "b", "c"], [64, 64, 256]),
+            (3, ["a", "b", "c", "d"], [128, 128, 512]),
+            (4, ["a"] + [chr(98 + i) for i in range(n4)], [256, 256, 1024]),   # net.py:190
+            (5, ["a", "b", "c"], [512, 512, 2048])]
+
+
+def layer_specs(config):
+    """Ordered [(layer_name, kind, {weight_name: shape})] for the whole model."""
+    specs = []
+    conv = lambda n, kh, kw, ci, co, bias: specs.append(
+        (n, "conv", OrderedDict([("kernel", (kh, kw, ci, co))] + ([("bias", (co,))] if bias else []))))
+    bn = lambda n, c: specs.append((n, "bn", OrderedDict(
+        [("gamma", (c,)), ("beta", (c,)), ("moving_mean", (c,)), ("moving_variance", (c,))])))
+    dense = lambda n, i, o: specs.append((n, "dense", OrderedDict([("kernel", (i, o)), ("bias", (o,))])))
+    cin = config.NR_IMAGE_CHANNELS
+    if config.BACKBONE in ("resnet50", "resnet101"):
+        conv("conv1", 7, 7, cin, 64, True); bn("bn_conv1", 64)            # net.py:170-172
+        c_in = 64
+        for stage, blocks, (f1, f2, f3) in _deep_blocks(config.BACKBONE):
+            for b in blocks:
+                base, bnb = "res%d%s_branch" % (stage, b), "bn%d%s_branch" % (stage, b)
+                conv(base + "2a", 1, 1, c_in, f1, True); bn(bnb + "2a", f1)
+                conv(base + "2b", 3, 3, f1, f2, True); bn(bnb + "2b", f2)
+                conv(base + "2c", 1, 1, f2, f3, True); bn(bnb + "2c", f3)
+                if b == "a":
+                    conv(base + "1", 1, 1, c_in, f3, True); bn(bnb + "1", f3)
+                c_in = f3
+        c5 = 2048
+    else:
+        assert config.BACKBONE in ("resnet18", "resnet34")                 # net.py:249
+        conv("conv0", 7, 7, cin, 64, False); bn("bn_conv0", 64)           # net.py:255-256
+        reps = [2, 2, 2, 2] if config.BACKBONE == "resnet18" else [3, 4, 6, 3]
+        c_in = 64
+        for stage, rep in enumerate(reps):
+            f = 64 * 2 ** stage
+            for block in range(rep):
+                nb = "stage%d_unit%d_" % (stage + 1, block + 1)            # net.py:209
+                if block == 0:
+                    conv(nb + "sc", 1, 1, c_in, f, False)                  # net.py:225
+                conv(nb + "conv1", 3, 3, c_in, f, False); bn(nb + "bn2", f)
+                conv(nb + "conv2", 3, 3, f, f, False)
+                c_in = f
+        c5 = c_in
+    bw = config.BOTTLENECK_WIDTH
+    conv("bottleneck_layer", 3, 3, c5, bw, True)                           # net.py:639
+    h, w = int(config.IMAGE_SHAPE[0]), int(config.IMAGE_SHAPE[1])
+    nf = int(bw * h * w / (64 ** 2))                                       # net.py:640
+    for br in ("loc", "ori"):
+        x = nf
+        for i in range(config.NR_DENSE_LAYERS):
+            dense("%s_dense_%d" % (br, i), x, config.BRANCH_SIZE)
+            if config.TRAIN_BN:                                            # net.py:304 (truthy only)
+                bn("%s_bn_%d" % (br, i), config.BRANCH_SIZE)
+            x = config.BRANCH_SIZE
+        if br == "loc":
+            if config.REGRESS_KEYPOINTS:
+                for k in ("k1_final", "k2_final", "k3_final"):
+                    dense(k, x, 3)
+            elif config.REGRESS_LOC:
+                dense("loc_final", x, 3)
+            else:
+                dense("loc_final", x, config.LOC_BINS_PER_DIM ** 3)
+        else:
+            if config.REGRESS_ORI:
+                if config.ORIENTATION_PARAM == "quaternion":
+                    dense("ori_q", x, 4)
+                else:
+                    dense("ori_final", x, 3)
+            else:
+                dense("ori_final", x, config.ORI_BINS_PER_DIM ** 3)
+    return specs
+
+
+def init_params(config, seed=1234, randomize_bn=False):
+    """Keras default initialisers [A11]: glorot_uniform kernels, zero biases, BN
+    gamma=1 beta=0 mean=0 var=1; `randomize_bn` perturbs BN tensors (and biases)
+    so the folded-BN path is actually exercised."""
+    rng = np.random.default_rng(seed)
+    params = OrderedDict()
+    for name, kind, ws in layer_specs(config):
+        p = OrderedDict()
+        for wn, shape in ws.items():
+            if wn == "kernel":
+                if kind == "conv":
+                    rf = shape[0] * shape[1]
+                    fan_in, fan_out = rf * shape[2], rf * shape[3]
+                else:
+                    fan_in, fan_out = shape
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                p[wn] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif wn == "bias":
+                p[wn] = (rng.normal(0, 0.05, size=shape) if randomize_bn else np.zeros(shape)).astype(np.float32)
+            elif wn == "gamma":
+                p[wn] = (rng.uniform(0.5, 1.5, size=shape) if randomize_bn else np.ones(shape)).astype(np.float32)
+            elif wn == "beta":
+                p[wn] = (rng.normal(0, 0.1, size=shape) if randomize_bn else np.zeros(shape)).astype(np.float32)
+            elif wn == "moving_mean":
+                p[wn] = (rng.normal(0, 0.1, size=shape) if randomize_bn else np.zeros(shape)).astype(np.float32)
+            elif wn == "moving_variance":
+                p[wn] = (rng.uniform(0.5, 1.5, size=shape) if randomize_bn else np.ones(shape)).astype(np.float32)
+        params[name] = p
+    return params
+
+
+def to_torch(params, requires_grad=True, dtype=torch.float32):
+    out = OrderedDict()
+    for ln, ws in params.items():
+        out[ln] = OrderedDict()
+        for wn, a in ws.items():
+            t = torch.tensor(np.asarray(a), dtype=dtype)
+            trainable = wn not in ("moving_mean", "moving_variance")
+            t.requires_grad_(requires_grad and trainable)
+            out[ln][wn] = t
+    return out
+
+
+# --------------------------------------------------------------------------
+# ops (NCHW inside torch; Keras layouts at the boundary)
+# --------------------------------------------------------------------------
+def same_pad(n_in, k, s):
+    """TF SAME padding [A2]: (before, after)."""
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return total // 2, total - total // 2
+
+
+def conv2d(x, p, stride=1, padding="valid"):
+    """Keras Conv2D [A1]. x NCHW; p['kernel'] HWIO; explicit zero pad for SAME."""
+    w = p["kernel"].permute(3, 2, 0, 1)
+    kh, kw = w.shape[2], w.shape[3]
+    if padding == "same":
+        pt, pb = same_pad(x.shape[2], kh, stride)
+        pl, pr = same_pad(x.shape[3], kw, stride)
+        x = F.pad(x, (pl, pr, pt, pb))
+    elif isinstance(padding, int) and padding > 0:                         # ZeroPadding2D
+        x = F.pad(x, (padding,) * 4)
+    return F.conv2d(x, w, p.get("bias"), stride=stride)
+
+
+def batchnorm(x, p, training):
+    """net.py:60-76 + [A3]. training False -> moving statistics (frozen; gamma/beta still
+    receive gradient); None -> batch statistics (biased variance), no sync."""
+    shape = (1, -1, 1, 1) if x.dim() == 4 else (1, -1)
+    if training is None or training is True:
+        dims = (0, 2, 3) if x.dim() == 4 else (0,)
+        mean = x.mean(dim=dims)
+        var = x.var(dim=dims, unbiased=False)
+    else:
+        mean, var = p["moving_mean"], p["moving_variance"]
+    inv = torch.rsqrt(var + BN_EPS)
+    return (x - mean.view(shape)) * (inv * p["gamma"]).view(shape) + p["beta"].view(shape)
+
+
+def maxpool_3x3_s2_same(x):
+    """MaxPooling2D((3,3), strides 2, 'same') [A2]: pad with -inf so padding never wins."""
+    pt, pb = same_pad(x.shape[2], 3, 2)
+    pl, pr = same_pad(x.shape[3], 3, 2)
+    x = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
+    return F.max_pool2d(x, 3, 2)
+
+
+def dense(x, p):
+    return x @ p["kernel"] + p["bias"]                                     # [A4]
+
+
+# --------------------------------------------------------------------------
+# graph builders
+# --------------------------------------------------------------------------
+def identity_block(x, P, stage, block, train_bn):
+    """net.py:85-117."""
+    cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
+    y = F.relu(batchnorm(conv2d(x, P[cb + "2a"]), P[bb + "2a"], train_bn))
+    y = F.relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn))
+    y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
+    return F.relu(y + x)
+
+
+def conv_block(x, P, stage, block, stride, train_bn):
+    """net.py:120-158 -- stride sits on 2a and on the shortcut branch1."""
+    cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
+    y = F.relu(batchnorm(conv2d(x, P[cb + "2a"], stride=stride), P[bb + "2a"], train_bn))
+    y = F.relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn))
+    y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
+    sc = batchnorm(conv2d(x, P[cb + "1"], stride=stride), P[bb + "1"], train_bn)
+    return F.relu(y + sc)
+
+
+def resnet_graph(x, P, arch, train_bn):
+    """net.py:161-199 (stage5=True)."""
+    x = conv2d(x, P["conv1"], stride=2, padding=3)
+    x = F.relu(batchnorm(x, P["bn_conv1"], train_bn))
+    x = maxpool_3x3_s2_same(x)
+    for stage, blocks, _ in _deep_blocks(arch):
+        for b in blocks:
+            if b == "a":
+                x = conv_block(x, P, stage, b, 1 if stage == 2 else 2, train_bn)
+            else:
+                x = identity_block(x, P, stage, b, train_bn)
+    return x
+
+
+def residual_basic_block(x, P, stage, block, stride, cut, train_bn):
+    """net.py:216-240 -- ONE BatchNorm per block (after conv1)."""
+    nb = "stage%d_unit%d_" % (stage + 1, block + 1)
+    sc = x if cut == "pre" else conv2d(x, P[nb + "sc"], stride=stride)
+    y = conv2d(x, P[nb + "conv1"], stride=stride, padding=1)
+    y = F.relu(batchnorm(y, P[nb + "bn2"], train_bn))
+    y = conv2d(y, P[nb + "conv2"], padding=1)
+    return F.relu(y + sc)
+
+
+def resnet_shallow_graph(x, P, arch, train_bn):
+    """net.py:242-282."""
+    x = conv2d(x, P["conv0"], stride=2, padding=3)
+    x = F.relu(batchnorm(x, P["bn_conv0"], train_bn))
+    x = maxpool_3x3_s2_same(x)
+    reps = [2, 2, 2, 2] if arch == "resnet18" else [3, 4, 6, 3]
+    for stage, rep in enumerate(reps):
+        for block in range(rep):
+            if block == 0 and stage == 0:
+                x = residual_basic_block(x, P, stage, block, 1, "post", train_bn)
+            elif block == 0:
+                x = residual_basic_block(x, P, stage, block, 2, "post", train_bn)
+            else:
+                x = residual_basic_block(x, P, stage, block, 1, "pre", train_bn)
+    return x
+
+
+def _branch_trunk(feat, P, config, br):
+    x = feat
+    for i in range(config.NR_DENSE_LAYERS):
+        x = dense(x, P["%s_dense_%d" % (br, i)])
+        if config.TRAIN_BN:
+            x = batchnorm(x, P["%s_bn_%d" % (br, i)], None)               # net.py:306: no training arg
+        x = F.relu(x)
+    return x
+
+
+def build_loc_graph(feat, P, config):
+    """net.py:288-320."""
+    x = _branch_trunk(feat, P, config, "loc")
+    if config.REGRESS_KEYPOINTS:
+        return [dense(x, P[k]) for k in ("k1_final", "k2_final", "k3_final")]
+    if config.REGRESS_LOC:
+        return dense(x, P["loc_final"])
+    return F.relu(dense(x, P["loc_final"]))
+
+
+def build_ori_graph(feat, P, config):
+    """net.py:322-352."""
+    x = _branch_trunk(feat, P, config, "ori")
+    if config.REGRESS_ORI:
+        if config.ORIENTATION_PARAM == "quaternion":
+            q = dense(x, P["ori_q"])
+            return q * torch.rsqrt(torch.clamp((q * q).sum(-1, keepdim=True), min=1e-12))   # [A5]
+        return dense(x, P["ori_final"])
+    return F.relu(dense(x, P["ori_final"]))
+
+
+def forward(P, images_nhwc, config):
+    """net.py:629-643.  images_nhwc: molded float tensor [B,H,W,C].  Returns (loc, ori)."""
+    h, w = images_nhwc.shape[1:3]
+    if h / 2 ** 6 != int(h / 2 ** 6) or w / 2 ** 6 != int(w / 2 ** 6):   # net.py:596-600
+        raise Exception("Image size must be dividable by 2 at least 6 times "
+                        "to avoid fractions when downscaling and upscaling."
+                        "For example, use 256, 320, 384, 448, 512, ... etc. ")
+    x = images_nhwc.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    if config.BACKBONE in ("resnet50", "resnet101"):
+        c5 = resnet_graph(x, P, config.BACKBONE, config.TRAIN_BN)
+    else:
+        c5 = resnet_shallow_graph(x, P, config.BACKBONE, config.TRAIN_BN)
+    c6 = conv2d(c5, P["bottleneck_layer"], stride=2, padding="same")
+    feat = c6.permute(0, 2, 3, 1).reshape(c6.shape[0], -1)                # (h,w,c) flatten [A4]
+    return build_loc_graph(feat, P, config), build_ori_graph(feat, P, config)
+
+
+# --------------------------------------------------------------------------
+# losses (net.py:705-762) and compile() (net.py:973-1028)
+# --------------------------------------------------------------------------
+def softmax_loss(y_gt, y_pred):
+    """net.py:710 + [A6]: sum_b(-sum_k p log_softmax(z)) / B."""
+    return -(y_gt * F.log_softmax(y_pred, dim=-1)).sum(-1).mean()
+
+
+def one_minus_dot_prod(y_true, y_pred):
+    """net.py:728-731."""
+    return (1 - (y_true * y_pred).sum(-1, keepdim=True).abs()).mean()
+
+
+def mse_loss(y_gt, y_pred):
+    """net.py:741-746."""
+    return ((y_gt - y_pred) ** 2).mean()
+
+
+def rel_loss(y_gt, y_pred):
+    """net.py:757 + [A7]: Frobenius norms over the WHOLE batch tensor."""
+    return torch.linalg.vector_norm((y_gt - y_pred) / torch.linalg.vector_norm(y_gt))
+
+
+def losses(P, images, gt_loc, gt_ori, config):
+    """net.py:656-669.  Returns (loc_pred, ori_pred, loc_loss, ori_loss)."""
+    loc, ori = forward(P, images, config)
+    assert not config.REGRESS_KEYPOINTS, "keypoint mode: use losses_keypoints"
+    loc_loss = rel_loss(gt_loc, loc) if config.REGRESS_LOC else softmax_loss(gt_loc, loc)
+    ori_loss = one_minus_dot_prod(gt_ori, ori) if config.REGRESS_ORI else softmax_loss(gt_ori, ori)
+    return loc, ori, loc_loss, ori_loss
+
+
+def is_trainable(layer_name, layer_regex=".*"):
+    """net.py:1057 -- fullmatch on the layer name."""
+    return bool(re.fullmatch(layer_regex, layer_name))
+
+
+def regularizer(P, config, layer_regex=".*"):
+    """net.py:1008-1012 + [A9]: sum_w WD*sum(w^2)/numel(w) over trainable non-gamma/beta weights."""
+    reg = 0.0
+    for ln, ws in P.items():
+        if not is_trainable(ln, layer_regex):
+            continue
+        for wn, w in ws.items():
+            if wn in ("gamma", "beta", "moving_mean", "moving_variance"):
+                continue
+            reg = reg + config.WEIGHT_DECAY * (w * w).sum() / w.numel()
+    return reg
+
+
+def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*"):
+    """net.py:993-1012: sum_name LOSS_WEIGHTS[name]*mean(loss) + regulariser."""
+    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config)
+    tot = config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("ori_loss", 1.) * ol
+    return tot + regularizer(P, config, layer_regex), (loc, ori, ll, ol)
+
+
+def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*"):
+    """Returns (grads {layer:{weight: tensor}}, (loc, ori, loc_loss, ori_loss), total)."""
+    leaves = [(ln, wn, w) for ln, ws in P.items() for wn, w in ws.items()
+              if w.requires_grad and is_trainable(ln, layer_regex)]
+    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex)
+    gs = torch.autograd.grad(tot, [w for _, _, w in leaves], allow_unused=True)
+    grads = OrderedDict()
+    for (ln, wn, w), g in zip(leaves, gs):
+        grads.setdefault(ln, OrderedDict())[wn] = g if g is not None else torch.zeros_like(w)
+    return grads, tuple(o.detach() if torch.is_tensor(o) else o for o in outs), tot.detach()
+
+
+def global_norm(grads):
+    s = 0.0
+    for ws in grads.values():
+        for g in ws.values():
+            s = s + (g.double() ** 2).sum()
+    return float(torch.sqrt(s))
+
+
+def sgd_step(P, grads, velocity, lr, momentum, clipnorm):
+    """keras.optimizers.SGD(lr, momentum, clipnorm) [A10]: GLOBAL norm clip
+    (g <- g*clipnorm/norm if norm >= clipnorm), v <- m*v - lr*g, w <- w + v.  In place.
+    Returns the pre-clip global norm."""
+    norm = global_norm(grads)
+    scale = clipnorm / norm if (clipnorm and clipnorm > 0 and norm >= clipnorm) else 1.0
+    with torch.no_grad():
+        for ln, ws in grads.items():
+            for wn, g in ws.items():
+                v = velocity.setdefault(ln, {}).setdefault(wn, torch.zeros_like(g))
+                v.mul_(momentum).add_(g * scale, alpha=-lr)
+                P[ln][wn].add_(v)
+    return norm
+
+
+def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*"):
+    """One fit_generator step [A13]: fwd, loss, bwd, clip, update.  Returns dict of scalars/outputs."""
+    grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex)
+    norm = sgd_step(P, grads, velocity, lr, config.LEARNING_MOMENTUM, config.GRADIENT_CLIP_NORM)
+    return {"loc": loc, "ori": ori, "loc_loss": float(ll), "ori_loss": float(ol), "total": float(tot),
+            "grad_norm": norm, "grads": grads}
+
+
+def mold_image(image, config):
+    """net.py:1337-1348."""
+    dt = np.float16 if config.F16 else np.float32
+    if image.shape[-1] == 3:
+        return image.astype(dt) - config.MEAN_PIXEL
+    return image.astype(dt) - np.mean(config.MEAN_PIXEL)
+
+
+def algorithmic_flops(config, batch):
+    """2*MACs over conv+dense; bwd = dgrad + wgrad = 2x fwd, minus the
+    stem's dgrad.  Returns (fwd_flops, fwd_bwd_flops) for `batch` images."""
+    h, w = int(config.IMAGE_SHAPE[0]), int(config.IMAGE_SHAPE[1])
+    total = 0
+    stem = 0
+    cur = None
+    for name, kind, ws in layer_specs(config):
+        if kind == "conv":
+            kh, kw, ci, co = ws["kernel"]
+            if name in ("conv1", "conv0"):
+                m = (h // 2) * (w // 2) * kh * kw * ci * co
+                stem = m
+                cur = (h // 4, w // 4)                         # after the 3x3/s2 max-pool
+            elif name == "bottleneck_layer":
+                m = (cur[0] // 2) * (cur[1] // 2) * kh * kw * ci * co
+            else:
+                # the first strided conv of a block (in spec order) halves the running size
+                if re.fullmatch(r"res[345]a_branch2a", name) or re.fullmatch(r"stage[234]_unit1_sc", name):
+                    cur = (cur[0] // 2, cur[1] // 2)
+                m = cur[0] * cur[1] * kh * kw * ci * co
+            total += m
+        elif kind == "dense":
+            i_, o_ = ws["kernel"]
+            total += i_ * o_
+    fwd = 2 * total * batch
+    return fwd, 3 * fwd - 2 * stem * batch

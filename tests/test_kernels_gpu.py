@@ -1,0 +1,374 @@
+"""GPU parity tests of every HIP kernel, called THROUGH THE C ABI (ursonet_amd.hip ctypes
+bindings) and checked against the CPU oracle (oracle/graph_ref.py, oracle/pose_math.py; torch
+autograd on CPU for gradients).  Tolerances: fp32 kernels 2e-5 of max|ref| (exact-fp32 MFMA,
+different summation order); bf16 kernels 1.5e-2 of max|ref| with inputs pre-rounded to bf16 so
+that only accumulation order and the output rounding differ."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-5, 1: 1.5e-2, 2: 2e-3}
+
+
+def _hip():
+    import ursonet_amd.hip as hip
+    return hip
+
+
+def rnd(t, dt):
+    hip = _hip()
+    return t.to(hip.TORCH_DT[dt]).to(torch.float32)
+
+
+def dev(t, dt=None):
+    hip = _hip()
+    t = t.contiguous()
+    if dt is not None:
+        t = t.to(hip.TORCH_DT[dt])
+    return t.cuda()
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), "non-finite values in kernel output"
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def prep_weights(w_hwio, dt, bias=None, bn=None, npad=None, want_wd=True):
+    """Runs urso_conv_weight_prep; returns (wf, wd, biasf, scale) device tensors."""
+    hip = _hip()
+    KH, KW, Ci, N = w_hwio.shape
+    npad = npad or N
+    tdt = hip.TORCH_DT[dt]
+    wf = torch.empty(npad * KH * KW * Ci, dtype=tdt, device="cuda")
+    wd = torch.empty(Ci * KH * KW * npad, dtype=tdt, device="cuda") if want_wd else None
+    biasf = torch.empty(npad, dtype=torch.float32, device="cuda")
+    scale = torch.empty(npad, dtype=torch.float32, device="cuda")
+    g = [dev(t) if t is not None else None for t in (bn or (None, None, None, None))]
+    hip.conv_weight_prep(KH, KW, Ci, N, npad, dt, dev(w_hwio), dev(bias) if bias is not None else None,
+                         g[0], g[1], g[2], g[3], 1e-3, wf, wd, biasf, scale)
+    return wf, wd, biasf, scale
+
+
+CONV_CASES = [
+    # B, H,  W,  C,  N, k, s, (pt, pl), name
+    (2, 16, 20, 64, 64, 1, 1, (0, 0), "1x1"),
+    (2, 16, 20, 64, 256, 1, 1, (0, 0), "1x1_wideN"),
+    (2, 16, 24, 128, 64, 1, 2, (0, 0), "1x1_s2"),
+    (2, 12, 20, 64, 64, 3, 1, (1, 1), "3x3_same"),
+    (3, 9, 11, 32, 160, 3, 1, (1, 1), "3x3_ragged"),
+    (2, 16, 20, 64, 32, 3, 2, (0, 0), "3x3_s2_tfsame"),      # bottleneck_layer: pad (0,1)
+    (2, 16, 16, 64, 128, 3, 2, (1, 1), "3x3_s2_pad1"),       # shallow trunk conv1
+    (4, 1, 1, 256, 1024, 1, 1, (0, 0), "dense"),
+    (2, 8, 8, 8, 24, 3, 1, (1, 1), "tinyC"),
+]
+
+
+def _out_hw(H, W, k, s, pad, case):
+    if case in ("3x3_s2_tfsame",):
+        return -(-H // s), -(-W // s)
+    return (H + 2 * pad[0] - k) // s + 1, (W + 2 * pad[1] - k) // s + 1
+
+
+def _ref_conv(x_nhwc, w_hwio, s, pad, OH, OW):
+    """fp32 CPU reference with explicit zero padding (bottom/right as needed to reach OH x OW)."""
+    k = w_hwio.shape[0]
+    H, W = x_nhwc.shape[1:3]
+    pb = max((OH - 1) * s + k - H - pad[0], 0)
+    pr = max((OW - 1) * s + k - W - pad[1], 0)
+    x = F.pad(x_nhwc.permute(0, 3, 1, 2), (pad[1], pr, pad[0], pb))
+    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
+def test_conv_forward_and_gradients(case, dt):
+    hip = _hip()
+    B, H, W, Ci, N, k, s, pad, name = case
+    torch.manual_seed(sum(map(ord, name)))
+    OH, OW = _out_hw(H, W, k, s, pad, name)
+    x = rnd(torch.randn(B, H, W, Ci), dt)
+    w = torch.randn(k, k, Ci, N) / np.sqrt(k * k * Ci)
+    bias = torch.randn(N) * 0.1
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N) * 0.1
+    mean, var = torch.randn(N) * 0.1, torch.rand(N) + 0.5
+    res = rnd(torch.randn(B, OH, OW, N), dt)
+    wf, wd, biasf, scale = prep_weights(w, dt, bias, (gamma, beta, mean, var))
+    # reference uses the SAME folded+rounded weights so that only the kernel arithmetic is compared
+    sc = gamma / torch.sqrt(var + 1e-3)
+    w_fold = rnd(w * sc, dt)
+    b_fold = sc * bias + beta - mean * sc
+    x_r = x.clone().requires_grad_(True)
+    w_r = w_fold.clone().requires_grad_(True)
+    z = _ref_conv(x_r, w_r, s, pad, OH, OW) + b_fold + res
+    y_ref = F.relu(z)
+    # ---- forward: conv + bias + residual + relu
+    g = hip.geom(B, H, W, Ci, OH, OW, N, k, k, s, s, pad[0], pad[1])
+    y = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.conv_igemm(g, dt, hip.EPI_RELU, dev(x, dt), wf, biasf, dev(res, dt), None, y)
+    torch.cuda.synchronize()
+    e = relerr(y, y_ref)
+    assert e < TOL[dt], "forward %s dt=%d rel err %.3e" % (name, dt, e)
+    # ---- backward reference
+    dy = rnd(torch.randn(B, OH, OW, N), dt)
+    dz_ref = (dy * (y_ref > 0)).detach()
+    dz_ref = rnd(dz_ref, dt)
+    (z * dz_ref).sum().backward()
+    # ---- data gradient: gather-form implicit GEMM with flipped taps, + add tensor, + relu mask of x
+    addt = rnd(torch.randn(B, H, W, Ci), dt)
+    gd = hip.geom(B, OH, OW, N, H, W, Ci, k, k, 1, 1, k - 1 - pad[0], k - 1 - pad[1], s, s)
+    dx = torch.empty(B, H, W, Ci, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.conv_igemm(gd, dt, 0, dev(dz_ref, dt), wd, None, dev(addt, dt), dev(x, dt), dx)
+    torch.cuda.synchronize()
+    dx_ref = (x_r.grad + addt) * (x > 0)
+    e = relerr(dx, dx_ref)
+    assert e < TOL[dt], "dgrad %s dt=%d rel err %.3e" % (name, dt, e)
+    # ---- weight gradient (raw, w.r.t. the folded filter) + column sums
+    ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
+    dw = torch.empty(k, k, Ci, N, dtype=torch.float32, device="cuda")
+    cs = torch.empty(N, dtype=torch.float32, device="cuda")
+    hip.conv_wgrad(g, dt, dev(x, dt), dev(dz_ref, dt), ws, dw, cs)
+    torch.cuda.synchronize()
+    e = relerr(dw, w_r.grad)
+    assert e < TOL[dt] * (1 if dt == 0 else 0.5), "wgrad %s dt=%d rel err %.3e" % (name, dt, e)
+    e = relerr(cs, dz_ref.sum(dim=(0, 1, 2)))
+    assert e < 1e-4, "colsum %s dt=%d rel err %.3e" % (name, dt, e)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_igemm_out_f32_and_padded_head(dt):
+    """loc_final-style head: N=3 padded to 8, fp32 output, no activation (net.py:316)."""
+    hip = _hip()
+    B, K, N, NP = 4, 1024, 3, 8
+    torch.manual_seed(5)
+    x = rnd(torch.randn(B, 1, 1, K), dt)
+    w = torch.randn(1, 1, K, N) / 32
+    bias = torch.randn(N)
+    wf, wd, biasf, scale = prep_weights(w, dt, bias, None, npad=NP)
+    g = hip.geom(B, 1, 1, K, 1, 1, NP, 1, 1)
+    y = torch.full((B, NP), 7.0, dtype=torch.float32, device="cuda")
+    hip.conv_igemm(g, dt, hip.EPI_OUT_F32, dev(x, dt), wf, biasf, None, None, y)
+    torch.cuda.synchronize()
+    ref = x.reshape(B, K) @ rnd(w.reshape(K, N), dt) + bias
+    assert relerr(y[:, :N], ref) < TOL[dt]
+    assert float(y[:, N:].abs().max()) == 0.0
+    # dgrad through the padded head
+    dz = torch.zeros(B, NP); dz[:, :N] = torch.randn(B, N); dz = rnd(dz, dt)
+    gd = hip.geom(B, 1, 1, NP, 1, 1, K, 1, 1)
+    dx = torch.empty(B, K, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.conv_igemm(gd, dt, 0, dev(dz, dt), wd, None, None, None, dx)
+    torch.cuda.synchronize()
+    assert relerr(dx, dz[:, :N] @ rnd(w.reshape(K, N), dt).T) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_stem_pixel_pair_conv(dt):
+    """conv1: ZeroPadding2D(3)+Conv2D 7x7 s2 (net.py:170-171) as a 7x4-tap conv on pixel pairs,
+    forward + weight gradient (no data gradient: the image needs none)."""
+    hip = _hip()
+    B, H, W, N = 2, 32, 48, 64
+    torch.manual_seed(7)
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
+    meanp = torch.tensor([123.7, 116.8, 103.9])
+    molded = torch.empty(B, H, W, 4, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.mold_images(B, H, W, img.cuda(), meanp.cuda(), dt, molded)
+    torch.cuda.synchronize()
+    x = rnd(img.float() - meanp, dt)
+    assert relerr(molded[..., :3], x) < 1e-6 and float(molded[..., 3].float().abs().max()) == 0.0
+    w = torch.randn(7, 7, 3, N) / 12
+    bias = torch.randn(N) * 0.1
+    bn = (torch.rand(N) + 0.5, torch.randn(N) * 0.1, torch.randn(N) * 0.1, torch.rand(N) + 0.5)
+    wf = torch.empty(N * 7 * 4 * 8, dtype=hip.TORCH_DT[dt], device="cuda")
+    biasf = torch.empty(N, dtype=torch.float32, device="cuda"); scale = torch.empty_like(biasf)
+    hip.stem_weight_pack(N, dt, dev(w), dev(bias), dev(bn[0]), dev(bn[1]), dev(bn[2]), dev(bn[3]), 1e-3, wf, biasf, scale)
+    OH, OW = H // 2, W // 2
+    g = hip.geom(B, H, W // 2, 8, OH, OW, N, 7, 4, 2, 1, 3, 2)
+    y = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.conv_igemm(g, dt, hip.EPI_RELU, molded, wf, biasf, None, None, y)
+    torch.cuda.synchronize()
+    sc = bn[0] / torch.sqrt(bn[3] + 1e-3)
+    w_fold = rnd(w * sc, dt).requires_grad_(True)
+    z = _ref_conv(x, w_fold, 2, (3, 3), OH, OW) + (sc * bias + bn[1] - bn[2] * sc)
+    assert relerr(y, F.relu(z)) < TOL[dt]
+    dz = rnd(torch.randn(B, OH, OW, N), dt)
+    (z * dz).sum().backward()
+    ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
+    dwp = torch.empty(7 * 4 * 8 * N, dtype=torch.float32, device="cuda")
+    cs = torch.empty(N, dtype=torch.float32, device="cuda")
+    hip.conv_wgrad(g, dt, molded, dev(dz, dt), ws, dwp, cs)
+    dw = torch.empty(7, 7, 3, N, dtype=torch.float32, device="cuda")
+    hip.stem_wgrad_unpack(N, dwp, dw)
+    torch.cuda.synchronize()
+    assert relerr(dw, w_fold.grad) < TOL[dt]
+
+
+def test_weight_prep_layouts():
+    hip = _hip()
+    torch.manual_seed(3)
+    KH, KW, Ci, N, NP = 3, 3, 40, 50, 56
+    w = torch.randn(KH, KW, Ci, N)
+    b = torch.randn(N)
+    bn = (torch.rand(N) + 0.5, torch.randn(N), torch.randn(N), torch.rand(N) + 0.5)
+    wf, wd, biasf, scale = prep_weights(w, 0, b, bn, npad=NP)
+    torch.cuda.synchronize()
+    s = bn[0] / torch.sqrt(bn[3] + 1e-3)
+    wfr = torch.zeros(NP, KH, KW, Ci); wfr[:N] = (w * s).permute(3, 0, 1, 2)
+    wdr = torch.zeros(Ci, KH, KW, NP); wdr[..., :N] = (w * s).flip(0, 1).permute(2, 0, 1, 3)
+    assert relerr(wf.view(NP, KH, KW, Ci), wfr) < 1e-6
+    assert relerr(wd.view(Ci, KH, KW, NP), wdr) < 1e-6
+    assert relerr(biasf[:N], s * b + bn[1] - bn[2] * s) < 1e-6 and relerr(scale[:N], s) < 1e-6
+    assert float(biasf[N:].abs().max()) == 0 and float((scale[N:] - 1).abs().max()) == 0
+
+
+def test_param_grad_finalize_matches_autograd_through_frozen_bn():
+    """gamma/beta/bias/kernel gradients recovered from (dw_raw, colsum) == autograd through
+    conv -> BatchNorm(training=False) (net.py:60-76) + the L2 term of net.py:1008-1012."""
+    from oracle import graph_ref as G
+    hip = _hip()
+    torch.manual_seed(11)
+    B, H, W, Ci, N = 2, 6, 5, 16, 24
+    x = torch.randn(B, Ci, H, W)
+    P = {"kernel": torch.randn(3, 3, Ci, N).requires_grad_(True), "bias": torch.randn(N).requires_grad_(True)}
+    Q = {"gamma": (torch.rand(N) + 0.5).requires_grad_(True), "beta": torch.randn(N).requires_grad_(True),
+         "moving_mean": torch.randn(N), "moving_variance": torch.rand(N) + 0.5}
+    z = G.batchnorm(G.conv2d(x, P, 1, "same"), Q, False)
+    dz = torch.randn_like(z)
+    wd_ = 1e-2
+    reg = wd_ * (P["kernel"] ** 2).sum() / P["kernel"].numel() + wd_ * (P["bias"] ** 2).sum() / N
+    ((z * dz).sum() + reg).backward()
+    # raw gradient w.r.t. the FOLDED filter is what urso_conv_wgrad produces: dw_raw = x^T dz
+    xp = F.pad(x, (1, 1, 1, 1))
+    dw_raw = torch.zeros(3, 3, Ci, N)
+    for ky in range(3):
+        for kx in range(3):
+            dw_raw[ky, kx] = torch.einsum("bchw,bnhw->cn", xp[:, :, ky:ky + H, kx:kx + W], dz)
+    colsum = dz.sum(dim=(0, 2, 3))
+    K = 9 * Ci
+    gw = torch.empty(K, N, device="cuda"); gb = torch.empty(N, device="cuda")
+    gg = torch.empty(N, device="cuda"); gbe = torch.empty(N, device="cuda")
+    ws = torch.empty(hip.param_grad_finalize_ws_bytes(K, N) // 4 + 4, device="cuda")
+    hip.param_grad_finalize(K, N, N, dev(dw_raw.reshape(K, N)), dev(colsum), dev(P["kernel"].detach().reshape(K, N)),
+                            dev(P["bias"].detach()), dev(Q["gamma"].detach()), dev(Q["moving_mean"]),
+                            dev(Q["moving_variance"]), 1e-3, wd_, 1, 1, gw, gb, gg, gbe, ws)
+    torch.cuda.synchronize()
+    assert relerr(gw, P["kernel"].grad.reshape(K, N)) < 2e-5
+    assert relerr(gb, P["bias"].grad) < 2e-5
+    assert relerr(gg, Q["gamma"].grad) < 2e-5
+    assert relerr(gbe, Q["beta"].grad) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_maxpool_same_fwd_bwd(dt):
+    from oracle import graph_ref as G
+    hip = _hip()
+    torch.manual_seed(2)
+    B, H, W, Cc = 2, 12, 16, 16
+    x = F.relu(rnd(torch.randn(B, H, W, Cc), dt))          # post-ReLU input with many zero ties
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = G.maxpool_3x3_s2_same(xr)
+    y = torch.empty(B, H // 2, W // 2, Cc, dtype=hip.TORCH_DT[dt], device="cuda")
+    am = torch.empty(B, H // 2, W // 2, Cc, dtype=torch.uint8, device="cuda")
+    hip.maxpool_fwd(B, H, W, Cc, dt, dev(x, dt), y, am)
+    torch.cuda.synchronize()
+    assert relerr(y, yr.permute(0, 2, 3, 1)) == 0.0
+    dy = rnd(torch.randn(B, H // 2, W // 2, Cc), dt)
+    (yr * dy.permute(0, 3, 1, 2)).sum().backward()
+    dx = torch.empty(B, H, W, Cc, dtype=hip.TORCH_DT[dt], device="cuda")
+    hip.maxpool_bwd(B, H, W, Cc, dt, y, dev(dy, dt), am, 1, dx)
+    torch.cuda.synchronize()
+    # fused ReLU mask: gradient w.r.t. the pre-ReLU tensor = dx * (x > 0)
+    ref = xr.grad.permute(0, 2, 3, 1) * (x > 0)
+    assert relerr(dx, ref) < (1e-6 if dt == 0 else 1e-2)
+
+
+@pytest.mark.parametrize("K", [4096, 13824, 64])
+def test_softmax_xent_soft_labels(K):
+    from oracle import graph_ref as G
+    hip = _hip()
+    torch.manual_seed(K)
+    B = 6
+    z = F.relu(torch.randn(B, K) * 2).requires_grad_(True)          # logits are post-ReLU (net.py:350)
+    p = torch.softmax(torch.randn(B, K) * 3, -1)
+    loss = G.softmax_loss(p, z) * 0.7
+    loss.backward()
+    lo = torch.empty(1, device="cuda"); dz = torch.empty(B, K, device="cuda"); rw = torch.empty(B, device="cuda")
+    hip.softmax_xent(B, K, dev(z.detach()), dev(p), 0.7, 1, 0, lo, dz, rw)
+    torch.cuda.synchronize()
+    assert abs(float(lo) - float(loss)) < 1e-5 * abs(float(loss))
+    assert relerr(dz, z.grad * (z.detach() > 0)) < 1e-4
+
+
+def test_regression_losses():
+    from oracle import graph_ref as G
+    hip = _hip()
+    torch.manual_seed(9)
+    B, LD = 5, 8
+    gt = torch.randn(B, 3) * 5
+    pred = torch.zeros(B, LD); pred[:, :3] = torch.randn(B, 3) * 5
+    pr = pred[:, :3].clone().requires_grad_(True)
+    l = G.rel_loss(gt, pr) * 1.3; l.backward()
+    lo = torch.empty(1, device="cuda"); dp = torch.empty(B, LD, device="cuda"); nr = torch.empty(2, device="cuda")
+    hip.rel_l2(B, 3, LD, dev(gt), dev(pred), 1.3, 0, lo, dp, nr)
+    torch.cuda.synchronize()
+    assert abs(float(lo) - float(l)) < 1e-5 * float(l)
+    assert relerr(dp[:, :3], pr.grad) < 1e-5 and float(dp[:, 3:].abs().max()) == 0
+    # quaternion head: l2-normalize + 1-|dot| (net.py:345-346, 724-733)
+    q_gt = F.normalize(torch.randn(B, 4), dim=-1)
+    x = torch.zeros(B, LD); x[:, :4] = torch.randn(B, 4)
+    xr = x[:, :4].clone().requires_grad_(True)
+    qn = xr * torch.rsqrt(torch.clamp((xr * xr).sum(-1, keepdim=True), min=1e-12))
+    l2 = G.one_minus_dot_prod(q_gt, qn) * 0.9; l2.backward()
+    qo = torch.empty(B, 4, device="cuda"); dx = torch.empty(B, LD, device="cuda")
+    hip.absdot(B, 4, LD, 1, dev(q_gt), dev(x), 0.9, 0, qo, lo, dx)
+    torch.cuda.synchronize()
+    assert relerr(qo, qn) < 1e-6 and abs(float(lo) - float(l2)) < 1e-5
+    assert relerr(dx[:, :4], xr.grad) < 1e-5
+    # MSE (keypoint mode, net.py:735-748)
+    pm = pred[:, :3].clone().requires_grad_(True)
+    l3 = G.mse_loss(gt, pm); l3.backward()
+    hip.mse(B, 3, LD, dev(gt), dev(pred), 1.0, 0, lo, dp)
+    torch.cuda.synchronize()
+    assert abs(float(lo) - float(l3)) < 1e-5 * float(l3) and relerr(dp[:, :3], pm.grad) < 1e-5
+
+
+@pytest.mark.parametrize("gscale", [0.01, 30.0])
+def test_sgd_momentum_global_clipnorm(gscale):
+    """keras SGD(momentum, clipnorm) with the GLOBAL norm [A10] vs oracle.sgd_step."""
+    from oracle import graph_ref as G
+    hip = _hip()
+    torch.manual_seed(1)
+    n = 1_000_003
+    w = torch.randn(n); g = torch.randn(n) * gscale / np.sqrt(n); v = torch.randn(n) * 0.01
+    P = {"l": {"w": w.clone()}}; vel = {"l": {"w": v.clone()}}
+    norm = G.sgd_step(P, {"l": {"w": g}}, vel, 0.05, 0.9, 5.0)
+    wd_, gd, vd = dev(w), dev(g), dev(v)
+    ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, device="cuda"); nsq = torch.empty(1, device="cuda")
+    hyper = torch.tensor([0.05, 0.9, 5.0], device="cuda")
+    hip.sqnorm(n, gd, ws, nsq)
+    hip.sgd_momentum_clip(n, wd_, gd, vd, hyper, nsq)
+    torch.cuda.synchronize()
+    assert abs(float(nsq) ** 0.5 - norm) < 1e-4 * norm
+    assert (norm >= 5.0) == (gscale > 1)
+    assert relerr(wd_, P["l"]["w"]) < 1e-6 and relerr(vd, vel["l"]["w"]) < 1e-5
+
+
+def test_quat_weighted_average_decode_against_golden():
+    """GPU soft-argmax decode vs the reference's se3lib.quat_weighted_avg outputs (golden)."""
+    import os
+    hip = _hip()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ori_codec.npz"))
+    for n in (8, 16):
+        Hq = gold["Hquat_%d" % n]; logits = gold["logits_%d" % n]; qref = gold["wavg_q_%d" % n][4:]
+        Aref = gold["wavg_A_%d" % n][4:]
+        B, K = logits.shape
+        q = torch.empty(B, 4, device="cuda"); A = torch.empty(B, 16, device="cuda")
+        hip.quat_wavg_decode(B, K, torch.tensor(logits).cuda(), torch.tensor(Hq).cuda(), q, A)
+        torch.cuda.synchronize()
+        dots = np.abs((q.cpu().numpy() * qref).sum(-1))
+        assert dots.min() > 1 - 1e-5, dots
+        assert np.abs(A.cpu().numpy().reshape(B, 4, 4) - Aref).max() < 2e-5

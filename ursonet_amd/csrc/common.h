@@ -1,0 +1,118 @@
+// Shared device/host helpers for liburso_hip.so (gfx950 only; no portability layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ursonet_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+
+// ---------------------------------------------------------------- error / launch plumbing
+void urso_set_error(const char* fmt, ...);
+int  urso_check_launch(const char* what);
+
+// profiler hooks (prof.cpp)
+void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);
+void urso_prof_after(hipStream_t s);
+
+struct ProfScope {
+    hipStream_t s;
+    ProfScope(hipStream_t st, int id, double flops, double bytes) : s(st) { urso_prof_before(s, id, flops, bytes); }
+    ~ProfScope() { urso_prof_after(s); }
+};
+
+static inline size_t dt_size(int dt) { return dt == URSO_F32 ? 4 : 2; }
+static __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- element traits
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VE = 4;            // elements per 16-byte vector
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<__bf16> {
+    static constexpr int VE = 8;
+    static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+    static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
+};
+template <> struct Elem<_Float16> {
+    static constexpr int VE = 8;
+    static __device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
+    static __device__ __forceinline__ _Float16 from_f(float v) { return (_Float16)v; }
+};
+
+// One MFMA "chunk-group step": every lane supplies one 16-byte chunk of its A row and one of
+// its B row (lane = 16*g + r: row r of the 16-row sub-tile, chunk g of the 4-chunk K group).
+//   D[i][j] += sum_k A[i][k] * B[j][k],  D layout: lane holds D[i = 4*(lane>>4) + reg][j = lane&15].
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<_Float16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; four
+    // instructions consume the lane's four floats (MFMA-k index g <-> element 4*g + j).
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x4_t& c) {
+        f32x4_t fa = __builtin_bit_cast(f32x4_t, a), fb = __builtin_bit_cast(f32x4_t, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, c, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------- LDS tile layout
+// Tiles are [rows][128 bytes] (8 chunks of 16 B).  Chunk swizzle: conflict-free for the
+// MFMA fragment reads (ds_read_b128: lane -> row lane&15, chunk 4*ks + lane>>4), for the
+// row-contiguous ds_write_b128 staging of conv_igemm and <=2-way for the transposing
+// ds_write_b32 staging of conv_wgrad (derivation in DESIGN.md "LDS layout").
+__device__ __forceinline__ int lds_swz(int row) {
+    int c = (row >> 3) & 7;
+    int s = (c & 4) | ((c & 1) << 1) | ((c >> 1) & 1);     // swap bits 0 and 1 of c
+    return (row & 7) ^ s;
+}
+__device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside one tile
+    return row * 128 + ((chunk ^ lds_swz(row)) << 4);
+}
+
+// ---------------------------------------------------------------- buffer loads with OOB->0
+#define URSO_OOB_SHIFT 0x80000000u          // added to the byte offset of a predicated-off lane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ i32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear block id: consecutive logical ids share an XCD (and its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int NX = 8;
+    if (nblk < NX) return bid;
+    int xcd = bid % NX, idx = bid / NX;
+    int q = nblk / NX, r = nblk % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

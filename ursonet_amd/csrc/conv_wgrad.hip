@@ -1,0 +1,267 @@
+// Weight-gradient implicit GEMM on MFMA for gfx950 (TF Conv2DBackpropFilter / MatMul-grad
+// of every Conv2D / Dense in net.py:85-158, 216-240, 288-352, 639).
+//
+//   dW[k][n] = sum_m Xp[m][k] * dZ[m][n]      k = (ky,kx,c), m = (b,oy,ox), n = out channel
+//
+// The reduction index is the PIXEL index, which is the strided dimension of both operands in
+// NHWC, while the MFMA wants the reduction index contiguous per lane.  Both operand tiles are
+// therefore transposed on the way into LDS: a thread loads 16 B (8 bf16 / 4 fp32 channels of
+// one pixel) and scatters them with 32-bit LDS writes (bf16: two neighbouring pixels are
+// interleaved in-register first), giving tiles Tx[k][m] and Tz[n][m] with 128-byte rows that
+// the MFMA fragment reads consume exactly like conv_igemm does.
+//
+// Output tile 128(k) x 128(n) per block, 4 waves (2x2), pixels consumed RM = 64 (bf16) / 32
+// (fp32) per step, double-buffered LDS.  The pixel range is split over gridDim.z blocks that
+// write fp32 partial tiles; a second kernel sums the partials in a fixed order (deterministic,
+// no atomics) and also produces colsum[n] = sum_m dZ[m][n].
+#include "common.h"
+
+struct WgradArgs {
+    const void* x; const void* dz; float* part; float* colpart;
+    uint32_t x_bytes, dz_bytes;
+    int B, H, W, C, OH, OW, N, KH, KW, SH, SW, PH, PW;
+    int M, Cc, Kc, K;          // K = Kc*VE
+    int ktiles, ntiles, splits, m_per_split;   // m_per_split multiple of RM
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int RM = 128 / (int)sizeof(T);          // pixels per reduction step (64 / 32)
+    constexpr int NCH = 128 / VE;                     // 16-B chunks across the 128 k (or n) of the tile
+    constexpr int PIX = (sizeof(T) == 2) ? 2 : 1;     // pixels handled per staged item
+    constexpr int ITEMS = (RM / PIX) * NCH / 256;     // items per thread per operand (2 / 4)
+    constexpr int PSTEP = 256 / NCH;                  // item-row stride between a thread's items (16 / 8)
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * 128];
+    auto sX = [&](int buf) -> char* { return smem + buf * 2 * 128 * 128; };
+    auto sZ = [&](int buf) -> char* { return smem + buf * 2 * 128 * 128 + 128 * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wn = wave >> 1;
+    const int kt = blockIdx.x % a.ktiles, nt = blockIdx.x / a.ktiles, sp = blockIdx.y;
+    const int k0c = kt * NCH;                     // first k-chunk of this tile
+    const int n0 = nt * 128;
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz, a.dz_bytes);
+
+    // this thread's fixed k-chunk / n-chunk and its item rows (pixel or pixel-pair index in the step)
+    const int ch = tid % NCH, prow = tid / NCH;
+    const int kc = k0c + ch;
+    const bool kvalid = kc < a.Kc;
+    int ky = 0, kx = 0, cc = 0;
+    if (kvalid) { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
+    const int ncol = n0 + ch * VE;
+    const bool nvalid = ncol < a.N;                 // N is a multiple of VE for vector loads (checked on host)
+
+    // running (b, oy, ox) of every pixel this thread stages: pixel index p = (prow + PSTEP*it)*PIX + q
+    int pb[ITEMS * PIX], poy[ITEMS * PIX], pox[ITEMS * PIX];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+        for (int q = 0; q < PIX; ++q) {
+            int m = m_begin + (prow + PSTEP * it) * PIX + q;
+            int b = m / ohw, rem = m - b * ohw;
+            pb[it * PIX + q] = b; poy[it * PIX + q] = rem / a.OW; pox[it * PIX + q] = rem - (rem / a.OW) * a.OW;
+        }
+    int mcur = m_begin;                              // first pixel of the step being fetched
+
+    i32x4_t rxv[ITEMS * PIX], rzv[ITEMS * PIX];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int q = 0; q < PIX; ++q) {
+                const int e = it * PIX + q;
+                const int m = mcur + (prow + PSTEP * it) * PIX + q;
+                const bool mvalid = m < m_end;
+                int iy = poy[e] * a.SH - a.PH + ky, ix = pox[e] * a.SW - a.PW + kx;
+                bool ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                uint32_t off = (uint32_t)(((pb[e] * a.H + iy) * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
+                rxv[e] = buf_load16(rx, ok ? off : URSO_OOB_SHIFT);
+                uint32_t zoff = ((uint32_t)m * (uint32_t)a.N + (uint32_t)ncol) * (uint32_t)sizeof(T);
+                rzv[e] = buf_load16(rz, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
+                // advance this pixel by RM for the next step
+                pox[e] += RM;
+                while (pox[e] >= a.OW) { pox[e] -= a.OW; if (++poy[e] == a.OH) { poy[e] = 0; ++pb[e]; } }
+            }
+        mcur += RM;
+    };
+    // transposing store of one item: rows (ch*VE + j), 4-byte column slot `slot` (0..31) of the 128-B row
+    auto put = [&](char* tile, int slot, int j, int word) {
+        const int row = ch * VE + j;
+        *(int*)(tile + row * 128 + ((((slot >> 2) ^ lds_swz(row)) << 4) | ((slot & 3) << 2))) = word;
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int slot = prow + PSTEP * it;
+            if constexpr (sizeof(T) == 2) {
+                const i32x4_t x0 = rxv[2 * it], x1 = rxv[2 * it + 1], z0 = rzv[2 * it], z1 = rzv[2 * it + 1];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t a0 = (uint32_t)x0[w], a1 = (uint32_t)x1[w], b0 = (uint32_t)z0[w], b1 = (uint32_t)z1[w];
+                    put(sX(buf), slot, 2 * w, (int)((a0 & 0xFFFFu) | (a1 << 16)));
+                    put(sX(buf), slot, 2 * w + 1, (int)((a0 >> 16) | (a1 & 0xFFFF0000u)));
+                    put(sZ(buf), slot, 2 * w, (int)((b0 & 0xFFFFu) | (b1 << 16)));
+                    put(sZ(buf), slot, 2 * w + 1, (int)((b0 >> 16) | (b1 & 0xFFFF0000u)));
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { put(sX(buf), slot, w, rxv[it][w]); put(sZ(buf), slot, w, rzv[it][w]); }
+            }
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;                                 // colsum partial: thread -> row n = tid>>1, half tid&1
+    const bool do_col = (kt == 0) && a.colpart;
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
+    if (nsteps > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) fetch();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i32x4_t fz[4], fx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fz[j] = *(const i32x4_t*)(sZ(cur) + lds_off(wn * 64 + j * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fx[i] = *(const i32x4_t*)(sX(cur) + lds_off(wk * 64 + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], fx[i], acc[i][j]);   // D rows -> n, cols -> k
+        }
+        if (do_col) {
+            const int row = tid >> 1, half = tid & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                i32x4_t v = *(const i32x4_t*)(sZ(cur) + lds_off(row, half * 4 + c));
+                T e[VE]; __builtin_memcpy(e, &v, 16);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) csum += Elem<T>::to_f(e[q]);
+            }
+        }
+        if (s + 1 < nsteps) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- store the fp32 partial tile: part[sp][k][n], lane holds n..n+3 for one k
+    float* out = a.part + (size_t)sp * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kt * 128 + wk * 64 + i * 16 + fr;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb >= a.N) continue;
+            float* o = out + (size_t)k * a.N + nb;
+            if ((a.N & 3) == 0) *(f32x4_t*)o = acc[i][j];
+            else { float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                for (int q = 0; q < 4 && nb + q < a.N; ++q) o[q] = v[q]; }
+        }
+    }
+    if (do_col) {
+        csum += __shfl_xor(csum, 1, 64);
+        const int n = n0 + (tid >> 1);
+        if ((tid & 1) == 0 && n < a.N) a.colpart[(size_t)sp * a.N + n] = csum;
+    }
+}
+
+// sums `splits` partial tensors of `count` floats in a fixed order
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i * 4 < count; i += stride) {
+        if (i * 4 + 3 < count) {
+            f32x4_t s = *(const f32x4_t*)(part + i * 4);
+            for (int p = 1; p < splits; ++p) { f32x4_t v = *(const f32x4_t*)(part + (size_t)p * count + i * 4); s += v; }
+            *(f32x4_t*)(out + i * 4) = s;
+        } else {
+            for (size_t e = i * 4; e < count; ++e) { float s = 0.f; for (int p = 0; p < splits; ++p) s += part[(size_t)p * count + e]; out[e] = s; }
+        }
+    }
+}
+
+struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split; size_t part_elems, col_elems; };
+
+static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
+    const int es = (int)dt_size(dt);
+    p.VE = 16 / es; p.RM = 128 / es;
+    if (g->C % p.VE || g->N % p.VE) return URSO_EINVAL;
+    p.Cc = g->C / p.VE; p.Kc = g->KH * g->KW * p.Cc; p.K = p.Kc * p.VE;
+    p.M = g->B * g->OH * g->OW;
+    p.ktiles = ceil_div(p.K, 128); p.ntiles = ceil_div(g->N, 128);
+    const int tiles = p.ktiles * p.ntiles;
+    const int steps = ceil_div(p.M, p.RM);
+    // aim for ~1024 blocks (4 per CU) but keep >= 8 reduction steps per block
+    int splits = ceil_div(1024, tiles);
+    splits = splits < 1 ? 1 : splits;
+    int max_splits = steps / 8; if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    int steps_per = ceil_div(steps, splits);
+    splits = ceil_div(steps, steps_per);
+    p.splits = splits; p.m_per_split = steps_per * p.RM;
+    p.part_elems = (size_t)splits * p.K * g->N;
+    p.col_elems = (size_t)splits * g->N;
+    return URSO_OK;
+}
+
+extern "C" size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt) {
+    WgradPlan p;
+    if (!g || plan_wgrad(g, dt, p) != URSO_OK) return 0;
+    return (p.part_elems + p.col_elems) * sizeof(float) + 256;
+}
+
+extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                               void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream) {
+    if (!g || !x_d || !dz_d || !ws_d || !dw_raw_d) { urso_set_error("urso_conv_wgrad: null argument"); return URSO_EINVAL; }
+    if (dt != URSO_F32 && dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_conv_wgrad: bad dtype"); return URSO_EINVAL; }
+    if (g->DH != 1 || g->DW != 1) { urso_set_error("urso_conv_wgrad: expects the forward geometry (D=1)"); return URSO_EINVAL; }
+    WgradPlan p;
+    if (plan_wgrad(g, dt, p) != URSO_OK) { urso_set_error("urso_conv_wgrad: C=%d and N=%d must be multiples of %d", g->C, g->N, 16 / (int)dt_size(dt)); return URSO_EINVAL; }
+    const size_t need = urso_conv_wgrad_ws_bytes(g, dt);
+    if (ws_bytes < need) { urso_set_error("urso_conv_wgrad: workspace %zu < %zu", ws_bytes, need); return URSO_EWORKSPACE; }
+    const size_t es = dt_size(dt);
+    const size_t x_bytes = (size_t)g->B * g->H * g->W * g->C * es, dz_bytes = (size_t)p.M * g->N * es;
+    if (x_bytes >= 0x7FFFFF00ull || dz_bytes >= 0x7FFFFF00ull) { urso_set_error("urso_conv_wgrad: tensor exceeds 2 GiB"); return URSO_EINVAL; }
+    WgradArgs a;
+    a.x = x_d; a.dz = dz_d; a.x_bytes = (uint32_t)x_bytes; a.dz_bytes = (uint32_t)dz_bytes;
+    float* part = (float*)ws_d; float* colpart = part + p.part_elems;
+    const bool direct = (p.splits == 1);
+    a.part = direct ? dw_raw_d : part;
+    a.colpart = colsum_d ? (direct ? colsum_d : colpart) : nullptr;
+    a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.OH = g->OH; a.OW = g->OW; a.N = g->N;
+    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    a.M = p.M; a.Cc = p.Cc; a.Kc = p.Kc; a.K = p.K; a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    double flops = 2.0 * p.M * (double)g->N * g->KH * g->KW * g->C;
+    double bytes = (double)x_bytes + (double)dz_bytes + (double)p.K * g->N * 4;
+    ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
+    dim3 grid(p.ktiles * p.ntiles, p.splits);
+    if (dt == URSO_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, st, a);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<_Float16>), grid, dim3(256), 0, st, a);
+    int rc = urso_check_launch("urso_conv_wgrad");
+    if (rc != URSO_OK) return rc;
+    if (!direct) {
+        size_t cnt = (size_t)p.K * g->N;
+        int blocks = (int)((cnt / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits);
+        rc = urso_check_launch("urso_conv_wgrad(reduce)");
+    }
+    return rc;
+}

@@ -1,0 +1,399 @@
+// Max-pool, loss (+gradient), optimizer and soft-argmax decode kernels.  All HBM/latency-bound;
+// reductions use 64-lane wavefront shuffles.  Math and net.py citations: include/ursonet_hip.h.
+#include "common.h"
+#include <math.h>
+
+// =============================================================== max-pool 3x3 / s2 / TF-SAME
+template <typename T>
+__global__ void maxpool_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ am) {
+    constexpr int VE = Elem<T>::VE;
+    const int OH = H / 2, OW = W / 2, Cv = C / VE;
+    const size_t total = (size_t)B * OH * OW * Cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % Cv); size_t p = i / Cv;
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int b = (int)(p / OH);
+        float best[VE]; int arg[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) { best[q] = -INFINITY; arg[q] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky; if (iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx; if (ix >= W) continue;
+                i32x4_t raw = *(const i32x4_t*)(x + (((size_t)b * H + iy) * W + ix) * C + cv * VE);
+                T e[VE]; __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) { float v = Elem<T>::to_f(e[q]); if (v > best[q]) { best[q] = v; arg[q] = ky * 3 + kx; } }
+            }
+        }
+        T o[VE]; uint8_t ab[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) { o[q] = Elem<T>::from_f(best[q]); ab[q] = (uint8_t)arg[q]; }
+        i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+        const size_t ob = (((size_t)b * OH + oy) * OW + ox) * C + cv * VE;
+        *(i32x4_t*)(y + ob) = ov;
+        if (am) __builtin_memcpy(am + ob, ab, VE);
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(int B, int H, int W, int C, const T* __restrict__ y, const T* __restrict__ dy,
+                                   const uint8_t* __restrict__ am, int relu_mask, T* __restrict__ dx) {
+    constexpr int VE = Elem<T>::VE;
+    const int OH = H / 2, OW = W / 2, Cv = C / VE;
+    const size_t total = (size_t)B * H * W * Cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % Cv); size_t p = i / Cv;
+        const int ix = (int)(p % W); p /= W; const int iy = (int)(p % H); const int b = (int)(p / H);
+        float g[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) g[q] = 0.f;
+        // windows containing (iy, ix): oy = iy/2 with ky = iy&1, and (iy even) oy = iy/2 - 1 with ky = 2
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            int oy, ky;
+            if (wy == 0) { oy = iy >> 1; ky = iy & 1; } else { if (iy & 1) continue; oy = (iy >> 1) - 1; ky = 2; }
+            if (oy < 0 || oy >= OH) continue;
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                int ox, kx;
+                if (wx == 0) { ox = ix >> 1; kx = ix & 1; } else { if (ix & 1) continue; ox = (ix >> 1) - 1; kx = 2; }
+                if (ox < 0 || ox >= OW) continue;
+                const size_t ob = (((size_t)b * OH + oy) * OW + ox) * C + cv * VE;
+                uint8_t ab[VE]; __builtin_memcpy(ab, am + ob, VE);
+                i32x4_t rd = *(const i32x4_t*)(dy + ob); T ed[VE]; __builtin_memcpy(ed, &rd, 16);
+                T ey[VE];
+                if (relu_mask) { i32x4_t ry = *(const i32x4_t*)(y + ob); __builtin_memcpy(ey, &ry, 16); }
+                const int tap = ky * 3 + kx;
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    bool hit = (ab[q] == tap);
+                    if (relu_mask) hit = hit && (Elem<T>::to_f(ey[q]) > 0.f);
+                    if (hit) g[q] += Elem<T>::to_f(ed[q]);
+                }
+            }
+        }
+        T o[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) o[q] = Elem<T>::from_f(g[q]);
+        i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+        *(i32x4_t*)(dx + (((size_t)b * H + iy) * W + ix) * C + cv * VE) = ov;
+    }
+}
+
+static int pool_blocks(size_t total) { size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+extern "C" int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const void* x_d, void* y_d, uint8_t* argmax_d, void* stream) {
+    const int VE = 16 / (int)dt_size(dt);
+    if (!x_d || !y_d || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_fwd: bad argument (H,W even; C multiple of %d)", VE); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
+    ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.25 + (double)B * H * W * C / 4);
+    if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)x_d, (float*)y_d, argmax_d);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)x_d, (__bf16*)y_d, argmax_d);
+    else hipLaunchKernelGGL((maxpool_fwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)x_d, (_Float16*)y_d, argmax_d);
+    return urso_check_launch("urso_maxpool3x3s2_fwd");
+}
+
+extern "C" int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const void* y_d, const void* dy_d,
+                                     const uint8_t* argmax_d, int relu_mask, void* dx_d, void* stream) {
+    const int VE = 16 / (int)dt_size(dt);
+    if (!dy_d || !argmax_d || !dx_d || (relu_mask && !y_d) || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_bwd: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)B * H * W * (C / VE);
+    ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.5 + (double)B * H * W * C / 4);
+    if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)y_d, (const float*)dy_d, argmax_d, relu_mask, (float*)dx_d);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)y_d, (const __bf16*)dy_d, argmax_d, relu_mask, (__bf16*)dx_d);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)y_d, (const _Float16*)dy_d, argmax_d, relu_mask, (_Float16*)dx_d);
+    return urso_check_launch("urso_maxpool3x3s2_bwd");
+}
+
+// =============================================================== block reductions (256 threads)
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+template <typename T> __device__ __forceinline__ void put_dt(void* p, size_t i, float v) { ((T*)p)[i] = Elem<T>::from_f(v); }
+__device__ __forceinline__ void put_any(int dt, void* p, size_t i, float v) {
+    if (dt == URSO_F32) put_dt<float>(p, i, v); else if (dt == URSO_BF16) put_dt<__bf16>(p, i, v); else put_dt<_Float16>(p, i, v);
+}
+
+// =============================================================== softmax cross-entropy with soft labels
+__global__ void softmax_xent_kernel(int K, const float* __restrict__ z, const float* __restrict__ p, float gscale,
+                                    int relu_mask, int dt, float* __restrict__ row_loss, void* __restrict__ dz) {
+    __shared__ float sh[8];
+    const int b = blockIdx.x;
+    const float* zr = z + (size_t)b * K; const float* pr = p + (size_t)b * K;
+    float mx = -INFINITY;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, zr[k]);
+    mx = block_max(mx, sh);
+    float se = 0.f, spz = 0.f, sp = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { const float zz = zr[k], pp = pr[k]; se += __expf(zz - mx); spz += pp * zz; sp += pp; }
+    se = block_sum(se, sh); spz = block_sum(spz, sh); sp = block_sum(sp, sh);
+    const float lse = mx + logf(se);
+    if (threadIdx.x == 0) row_loss[b] = lse * sp - spz;              // -sum p*(z - lse)
+    const float inv = 1.f / se;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float zz = zr[k];
+        float g = (__expf(zz - mx) * inv - pr[k]) * gscale;           // TF backprop: softmax - labels
+        if (relu_mask && !(zz > 0.f)) g = 0.f;
+        put_any(dt, dz, (size_t)b * K + k, g);
+    }
+}
+__global__ void mean_scale_kernel(int n, const float* __restrict__ v, float scale, float* __restrict__ out) {
+    __shared__ float sh[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+extern "C" int urso_softmax_xent_fwd_bwd(int B, int K, const float* logits_d, const float* labels_d, float weight,
+                                         int relu_mask, int dt, float* loss_d, void* dz_d, float* row_ws_d, void* stream) {
+    if (!logits_d || !labels_d || !loss_d || !dz_d || !row_ws_d || B <= 0 || K <= 0) { urso_set_error("urso_softmax_xent_fwd_bwd: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, (double)B * K * (8 + dt_size(dt)));
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B), dim3(256), 0, st, K, logits_d, labels_d, weight / (float)B, relu_mask, dt, row_ws_d, dz_d);
+    hipLaunchKernelGGL(mean_scale_kernel, dim3(1), dim3(256), 0, st, B, (const float*)row_ws_d, weight / (float)B, loss_d);
+    return urso_check_launch("urso_softmax_xent_fwd_bwd");
+}
+
+// =============================================================== relative L2 (batch-Frobenius)
+__global__ void rel_l2_kernel(int B, int D, int ld, const float* __restrict__ gt, const float* __restrict__ pred, float weight,
+                              int dt, float* __restrict__ loss, void* __restrict__ dpred, float* __restrict__ norms) {
+    __shared__ float sh[8];
+    float sd = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < B * D; i += blockDim.x) {
+        const int b = i / D, d = i - b * D;
+        const float g = gt[i], e = g - pred[(size_t)b * ld + d];
+        sd += e * e; sg += g * g;
+    }
+    sd = block_sum(sd, sh); sg = block_sum(sg, sh);
+    const float nd = sqrtf(sd), ng = sqrtf(sg);
+    if (threadIdx.x == 0) { loss[0] = weight * nd / ng; if (norms) { norms[0] = sd; norms[1] = sg; } }
+    const float c = -weight / (nd * ng);                               // d/dpred ||gt-pred||/||gt||  (NaN if pred==gt, as in TF)
+    for (int i = threadIdx.x; i < B * ld; i += blockDim.x) {
+        const int b = i / ld, d = i - b * ld;
+        put_any(dt, dpred, i, d < D ? c * (gt[b * D + d] - pred[i]) : 0.f);
+    }
+}
+extern "C" int urso_rel_l2_fwd_bwd(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight,
+                                   int dt, float* loss_d, void* dpred_d, float* norms_d, void* stream) {
+    if (!gt_d || !pred_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_fwd_bwd: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, 0);
+    hipLaunchKernelGGL(rel_l2_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d, norms_d);
+    return urso_check_launch("urso_rel_l2_fwd_bwd");
+}
+
+// =============================================================== l2-normalise + 1-|dot|
+__global__ void absdot_kernel(int B, int D, int ld, int normalize, const float* __restrict__ gt, const float* __restrict__ x,
+                              float weight, int dt, float* __restrict__ q, float* __restrict__ loss, void* __restrict__ dx) {
+    __shared__ float sh[8];
+    float lsum = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float ss = 0.f;
+        for (int d = 0; d < D; ++d) { const float v = x[(size_t)b * ld + d]; ss += v * v; }
+        const bool clamped = !(ss > 1e-12f);
+        const float rinv = normalize ? rsqrtf(fmaxf(ss, 1e-12f)) : 1.f;
+        float dot = 0.f;
+        for (int d = 0; d < D; ++d) { const float qq = x[(size_t)b * ld + d] * rinv; if (q) q[(size_t)b * D + d] = qq; if (gt) dot += gt[(size_t)b * D + d] * qq; }
+        if (gt) {
+            lsum += 1.f - fabsf(dot);
+            // dL/dq = -sign(dot) * gt * weight / B ; through q = x*rinv:  dx = rinv*(dq - q*(q.dq))  (dq*rinv when clamped)
+            const float sg = (dot > 0.f) ? 1.f : ((dot < 0.f) ? -1.f : 0.f);
+            const float c = -sg * weight / (float)B;
+            float qdq = 0.f;
+            if (normalize && !clamped) for (int d = 0; d < D; ++d) qdq += (x[(size_t)b * ld + d] * rinv) * (c * gt[(size_t)b * D + d]);
+            for (int d = 0; d < ld; ++d) {
+                float g = 0.f;
+                if (d < D) { const float dq = c * gt[(size_t)b * D + d]; g = normalize ? rinv * (dq - (clamped ? 0.f : x[(size_t)b * ld + d] * rinv * qdq)) : dq; }
+                if (dx) put_any(dt, dx, (size_t)b * ld + d, g);
+            }
+        }
+    }
+    if (gt && loss) { lsum = block_sum(lsum, sh); if (threadIdx.x == 0) loss[0] = weight * lsum / (float)B; }
+}
+extern "C" int urso_absdot_fwd_bwd(int B, int D, int ld, int normalize, const float* gt_d, const float* x_d, float weight,
+                                   int dt, float* q_d, float* loss_d, void* dx_d, void* stream) {
+    if (!x_d || B <= 0 || D <= 0 || ld < D || (gt_d && (!loss_d || !dx_d))) { urso_set_error("urso_absdot_fwd_bwd: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, 0);
+    hipLaunchKernelGGL(absdot_kernel, dim3(1), dim3(256), 0, st, B, D, ld, normalize, gt_d, x_d, weight, dt, q_d, loss_d, dx_d);
+    return urso_check_launch("urso_absdot_fwd_bwd");
+}
+
+// =============================================================== MSE
+__global__ void mse_kernel(int B, int D, int ld, const float* __restrict__ gt, const float* __restrict__ pred, float weight,
+                           int dt, float* __restrict__ loss, void* __restrict__ dpred) {
+    __shared__ float sh[8];
+    float s = 0.f;
+    const float c = 2.f * weight / (float)(B * D);
+    for (int i = threadIdx.x; i < B * ld; i += blockDim.x) {
+        const int b = i / ld, d = i - b * ld;
+        float g = 0.f;
+        if (d < D) { const float e = pred[i] - gt[b * D + d]; s += e * e; g = c * e; }
+        put_any(dt, dpred, i, g);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) loss[0] = weight * s / (float)(B * D);
+}
+extern "C" int urso_mse_fwd_bwd(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight,
+                                int dt, float* loss_d, void* dpred_d, void* stream) {
+    if (!gt_d || !pred_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_mse_fwd_bwd: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, 0);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d);
+    return urso_check_launch("urso_mse_fwd_bwd");
+}
+
+// =============================================================== optimizer
+#define SQN_BLOCKS 1024
+__global__ void sqnorm_part_kernel(size_t n, const float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float sh[8];
+    float s = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4_t v = ((const f32x4_t*)g)[i]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sqnorm_final_kernel(int nb, const float* __restrict__ part, float* __restrict__ out) {
+    __shared__ float sh[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" size_t urso_sqnorm_ws_bytes(size_t n) { (void)n; return SQN_BLOCKS * sizeof(float); }
+extern "C" int urso_sqnorm(size_t n, const float* g_d, void* ws_d, size_t ws_bytes, float* out_d, void* stream) {
+    if (!g_d || !ws_d || !out_d || ws_bytes < urso_sqnorm_ws_bytes(n)) { urso_set_error("urso_sqnorm: bad argument"); return URSO_EINVAL; }
+    if (((uintptr_t)g_d) & 15) { urso_set_error("urso_sqnorm: gradient buffer must be 16-byte aligned"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 4);
+    hipLaunchKernelGGL(sqnorm_part_kernel, dim3(SQN_BLOCKS), dim3(256), 0, st, n, g_d, (float*)ws_d);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, SQN_BLOCKS, (const float*)ws_d, out_d);
+    return urso_check_launch("urso_sqnorm");
+}
+
+__global__ void sgd_kernel(size_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
+                           const float* __restrict__ hyper, const float* __restrict__ normsq) {
+    const float lr = hyper[0], mom = hyper[1], clip = hyper[2];
+    const float norm = sqrtf(normsq[0]);
+    const float c = (clip > 0.f && norm >= clip) ? clip / norm : 1.f;
+    const float step = lr * c;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4_t gv = ((const f32x4_t*)g)[i], vv = ((f32x4_t*)v)[i], wv = ((f32x4_t*)w)[i];
+        vv = vv * mom - gv * step; wv += vv;
+        ((f32x4_t*)v)[i] = vv; ((f32x4_t*)w)[i] = wv;
+    }
+    if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) { float nv = mom * v[i] - step * g[i]; v[i] = nv; w[i] += nv; }
+}
+extern "C" int urso_sgd_momentum_clip(size_t n, float* w_d, const float* g_d, float* v_d, const float* hyper_d,
+                                      const float* normsq_d, void* stream) {
+    if (!w_d || !g_d || !v_d || !hyper_d || !normsq_d) { urso_set_error("urso_sgd_momentum_clip: null argument"); return URSO_EINVAL; }
+    if ((((uintptr_t)w_d) | ((uintptr_t)g_d) | ((uintptr_t)v_d)) & 15) { urso_set_error("urso_sgd_momentum_clip: buffers must be 16-byte aligned"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 20);
+    size_t blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, v_d, hyper_d, normsq_d);
+    return urso_check_launch("urso_sgd_momentum_clip");
+}
+
+__global__ void scale_kernel(size_t n, float* __restrict__ x, float s) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+extern "C" int urso_scale_f32(size_t n, float* x_d, float s, void* stream) {
+    if (!x_d) { urso_set_error("urso_scale_f32: null argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 8);
+    hipLaunchKernelGGL(scale_kernel, dim3((int)blocks), dim3(256), 0, st, n, x_d, s);
+    return urso_check_launch("urso_scale_f32");
+}
+
+// =============================================================== soft-argmax decode
+// One block per sample: softmax over K bins, A = sum_i w_i q_i q_i^T (10 unique entries),
+// cyclic Jacobi on the 4x4 symmetric matrix (double), eigenvector of the largest eigenvalue.
+__global__ void quat_wavg_kernel(int K, const float* __restrict__ logits, const float* __restrict__ hq,
+                                 float* __restrict__ qout, float* __restrict__ aout) {
+    __shared__ float sh[8];
+    __shared__ float A10[10];
+    const int b = blockIdx.x;
+    const float* z = logits + (size_t)b * K;
+    float mx = -INFINITY;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, z[k]);
+    mx = block_max(mx, sh);
+    float se = 0.f, acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float w = expf(z[k] - mx); se += w;
+        const f32x4_t q = ((const f32x4_t*)hq)[k];
+        const float v[4] = {q.x, q.y, q.z, q.w};
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) acc[t++] += w * v[i] * v[j];
+    }
+    se = block_sum(se, sh);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { float s = block_sum(acc[i], sh); if (threadIdx.x == 0) A10[i] = s / se; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double A[4][4], V[4][4];
+        int t = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i; j < 4; ++j) { A[i][j] = A[j][i] = (double)A10[t++]; }
+        if (aout) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) aout[(size_t)b * 16 + i * 4 + j] = (float)A[i][j];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0.0;
+            for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+            if (off < 1e-30) break;
+            for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 4; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 4; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            }
+        }
+        int best = 0;
+        for (int i = 1; i < 4; ++i) if (A[i][i] > A[best][best]) best = i;
+        double q[4], nrm = 0.0; int im = 0;
+        for (int i = 0; i < 4; ++i) { q[i] = V[i][best]; nrm += q[i] * q[i]; if (fabs(q[i]) > fabs(q[im])) im = i; }
+        nrm = 1.0 / sqrt(nrm);
+        if (q[im] < 0) nrm = -nrm;
+        for (int i = 0; i < 4; ++i) qout[(size_t)b * 4 + i] = (float)(q[i] * nrm);
+    }
+}
+extern "C" int urso_quat_wavg_decode(int B, int K, const float* logits_d, const float* hquat_d, float* q_d, float* a_d, void* stream) {
+    if (!logits_d || !hquat_d || !q_d || B <= 0 || K <= 0) { urso_set_error("urso_quat_wavg_decode: bad argument"); return URSO_EINVAL; }
+    if (((uintptr_t)hquat_d) & 15) { urso_set_error("urso_quat_wavg_decode: hquat must be 16-byte aligned"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 16);
+    hipLaunchKernelGGL(quat_wavg_kernel, dim3(B), dim3(256), 0, st, K, logits_d, hquat_d, q_d, a_d);
+    return urso_check_launch("urso_quat_wavg_decode");
+}

@@ -1,0 +1,219 @@
+// Weight preparation (BN folding + MFMA layouts), parameter-gradient finalisation and input
+// molding.  HBM-bound helper kernels on weight-sized tensors; see include/ursonet_hip.h for the
+// math and the net.py lines each one replaces.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ void store_elem(void* p, size_t i, float v) { ((T*)p)[i] = Elem<T>::from_f(v); }
+
+__device__ __forceinline__ float bn_scale(const float* gamma, const float* var, float eps, int n) {
+    return gamma ? gamma[n] * rsqrtf(var[n] + eps) : 1.0f;
+}
+
+// One block = one (tap, 32-channel, 32-filter) tile: reads W[tap][c][n] coalesced along n, writes
+// wd[c][ftap][n] coalesced along n and wf[n][tap][c] coalesced along c through an LDS transpose.
+template <typename T>
+__global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
+                                   const float* __restrict__ w, const float* __restrict__ b,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                   void* wf, void* wd, float* biasf, float* scale) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads: 32 x 8
+    const int taps = KH * KW;
+    const int ftap = taps - 1 - tap;                               // (KH-1-ky)*KW + (KW-1-kx)
+    const int n = n0 + tx;
+    const float s = (n < N) ? bn_scale(gamma, var, eps, n) : 1.0f;
+    for (int cy = ty; cy < 32; cy += 8) {
+        const int c = c0 + cy;
+        float v = 0.f;
+        if (c < C && n < N) v = w[((size_t)tap * C + c) * N + n] * s;
+        tile[cy][tx] = v;
+        if (wd && c < C && n < npad) store_elem<T>(wd, ((size_t)c * taps + ftap) * npad + n, v);
+    }
+    __syncthreads();
+    for (int ny = ty; ny < 32; ny += 8) {
+        const int nn = n0 + ny, c = c0 + tx;
+        if (nn < npad && c < C) store_elem<T>(wf, ((size_t)nn * taps + tap) * C + c, tile[tx][ny]);
+    }
+    if (tap == 0 && blockIdx.x == 0 && ty == 0 && n < npad) {
+        float bf = 0.f, sc = 1.f;
+        if (n < N) {
+            sc = s;
+            bf = (b ? b[n] * s : 0.f);
+            if (gamma) bf += beta[n] - mean[n] * s;
+        }
+        biasf[n] = bf; scale[n] = sc;
+    }
+}
+
+extern "C" int urso_conv_weight_prep(int KH, int KW, int C, int N, int npad, int dt,
+                                     const float* w_d, const float* b_d, const float* gamma_d, const float* beta_d,
+                                     const float* mean_d, const float* var_d, float eps,
+                                     void* wf_d, void* wd_d, float* biasf_d, float* scale_d, void* stream) {
+    if (!w_d || !wf_d || !biasf_d || !scale_d || KH <= 0 || KW <= 0 || C <= 0 || N <= 0 || npad < N) {
+        urso_set_error("urso_conv_weight_prep: bad argument"); return URSO_EINVAL; }
+    if (gamma_d && (!beta_d || !mean_d || !var_d)) { urso_set_error("urso_conv_weight_prep: incomplete BN tensors"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(ceil_div(C, 32), ceil_div(npad, 32), KH * KW);
+    ProfScope ps(st, URSO_K_PREP, 0, (double)KH * KW * C * N * (4 + 2 * dt_size(dt)));
+    if (dt == URSO_F32) hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((weight_prep_kernel<__bf16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    else if (dt == URSO_F16) hipLaunchKernelGGL((weight_prep_kernel<_Float16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    else { urso_set_error("urso_conv_weight_prep: bad dtype"); return URSO_EINVAL; }
+    return urso_check_launch("urso_conv_weight_prep");
+}
+
+// ------------------------------------------------------------------ stem packing
+// wf[n][ky][kp][cp], kp = 0..3 pixel pair, cp = 0..7: pixel-in-window q = 2*kp + (cp>>2), kx = q-1, c = cp&3.
+template <typename T>
+__global__ void stem_pack_kernel(int N, const float* __restrict__ w, const float* __restrict__ b,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                 void* wf, float* biasf, float* scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = N * 7 * 4 * 8;
+    if (i < total) {
+        const int cp = i & 7, kp = (i >> 3) & 3, ky = (i >> 5) % 7, n = i / 224;
+        const int q = 2 * kp + (cp >> 2), kx = q - 1, c = cp & 3;
+        float v = 0.f;
+        if (kx >= 0 && c < 3) v = w[(((size_t)ky * 7 + kx) * 3 + c) * N + n] * bn_scale(gamma, var, eps, n);
+        store_elem<T>(wf, i, v);
+    }
+    if (i < N) {
+        const float s = bn_scale(gamma, var, eps, i);
+        float bf = b ? b[i] * s : 0.f;
+        if (gamma) bf += beta[i] - mean[i] * s;
+        biasf[i] = bf; scale[i] = s;
+    }
+}
+
+extern "C" int urso_stem_weight_pack(int N, int dt, const float* w_d, const float* b_d, const float* gamma_d,
+                                     const float* beta_d, const float* mean_d, const float* var_d, float eps,
+                                     void* wf_d, float* biasf_d, float* scale_d, void* stream) {
+    if (!w_d || !wf_d || !biasf_d || !scale_d || N <= 0) { urso_set_error("urso_stem_weight_pack: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int total = N * 224, blocks = ceil_div(total, 256);
+    ProfScope ps(st, URSO_K_PREP, 0, 0);
+    if (dt == URSO_F32) hipLaunchKernelGGL((stem_pack_kernel<float>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((stem_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    else if (dt == URSO_F16) hipLaunchKernelGGL((stem_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    else { urso_set_error("urso_stem_weight_pack: bad dtype"); return URSO_EINVAL; }
+    return urso_check_launch("urso_stem_weight_pack");
+}
+
+__global__ void stem_unpack_kernel(int N, const float* __restrict__ dwp, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 7 * 7 * 3 * N) return;
+    const int n = i % N, c = (i / N) % 3, kx = (i / (3 * N)) % 7, ky = i / (21 * N);
+    const int q = kx + 1, kp = q >> 1, cp = (q & 1) * 4 + c;
+    dw[i] = dwp[(((size_t)ky * 4 + kp) * 8 + cp) * N + n];
+}
+
+extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw_raw_d, void* stream) {
+    if (!dw_packed_d || !dw_raw_d || N <= 0) { urso_set_error("urso_stem_wgrad_unpack: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
+    hipLaunchKernelGGL(stem_unpack_kernel, dim3(ceil_div(147 * N, 256)), dim3(256), 0, st, N, dw_packed_d, dw_raw_d);
+    return urso_check_launch("urso_stem_wgrad_unpack");
+}
+
+// ------------------------------------------------------------------ parameter-gradient finalisation
+// pass 1: grid (ceil(N/64), KS): gW = s*dw_raw + c*W, partial column dots of W*dw_raw
+__global__ void finalize_mat_kernel(int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
+                                    const float* __restrict__ gamma, const float* __restrict__ var, float eps,
+                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
+    __shared__ float red[4][64];
+    const int tn = threadIdx.x & 63, tk = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tn;
+    const int kbeg = blockIdx.y * kb, kend = min(K, kbeg + kb);
+    float dot = 0.f;
+    if (n < N) {
+        const float s = bn_scale(gamma, var, eps, n);
+        for (int k = kbeg + tk; k < kend; k += 4) {
+            const float d = dwr[(size_t)k * ldn + n], ww = w[(size_t)k * N + n];
+            dot += ww * d;
+            gw[(size_t)k * N + n] = trainable ? (s * d + regc * ww) : 0.f;
+        }
+    }
+    red[tk][tn] = dot;
+    __syncthreads();
+    if (tk == 0 && n < N) dotpart[(size_t)blockIdx.y * N + n] = red[0][tn] + red[1][tn] + red[2][tn] + red[3][tn];
+}
+
+// pass 2: one thread per channel
+__global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dotpart, const float* __restrict__ colsum,
+                                    const float* __restrict__ b, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                    float regb, int trainable, int bn_trainable,
+                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float cs = colsum ? colsum[n] : 0.f;
+    const float s = bn_scale(gamma, var, eps, n);
+    if (gb) gb[n] = trainable ? (s * cs + regb * (b ? b[n] : 0.f)) : 0.f;
+    if (ggamma) {
+        float dot = 0.f;
+        for (int i = 0; i < ks; ++i) dot += dotpart[(size_t)i * N + n];
+        const float rstd = rsqrtf(var[n] + eps);
+        ggamma[n] = bn_trainable ? rstd * (dot + ((b ? b[n] : 0.f) - mean[n]) * cs) : 0.f;
+        gbeta[n] = bn_trainable ? cs : 0.f;
+    }
+}
+
+static int finalize_ks(int K, int N) {
+    int ntiles = ceil_div(N, 64);
+    int ks = ceil_div(512, ntiles);
+    int maxks = K / 16; if (maxks < 1) maxks = 1;
+    if (ks > maxks) ks = maxks;
+    return ks;
+}
+extern "C" size_t urso_param_grad_finalize_ws_bytes(int K, int N) { return (size_t)finalize_ks(K, N) * N * sizeof(float) + 256; }
+
+extern "C" int urso_param_grad_finalize(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
+                                        const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
+                                        const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
+                                        float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                                        float* ws_d, size_t ws_bytes, void* stream) {
+    if (!dw_raw_d || !w_d || !gw_d || !ws_d || K <= 0 || N <= 0 || ldn < N) { urso_set_error("urso_param_grad_finalize: bad argument"); return URSO_EINVAL; }
+    if ((gb_d || ggamma_d) && !colsum_d) { urso_set_error("urso_param_grad_finalize: colsum required for bias/BN gradients"); return URSO_EINVAL; }
+    if (ggamma_d && (!gamma_d || !mean_d || !var_d || !gbeta_d)) { urso_set_error("urso_param_grad_finalize: incomplete BN tensors"); return URSO_EINVAL; }
+    if (ws_bytes < urso_param_grad_finalize_ws_bytes(K, N)) { urso_set_error("urso_param_grad_finalize: workspace too small"); return URSO_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = finalize_ks(K, N), kb = ceil_div(K, ks);
+    const float regc = 2.0f * weight_decay / ((float)K * (float)N), regb = 2.0f * weight_decay / (float)N;
+    ProfScope ps(st, URSO_K_FINALIZE, 0, (double)K * N * 12);
+    hipLaunchKernelGGL(finalize_mat_kernel, dim3(ceil_div(N, 64), ks), dim3(256), 0, st, K, N, ldn, kb, dw_raw_d, w_d, gamma_d, var_d, eps, regc, trainable, gw_d, ws_d);
+    if (gb_d || ggamma_d)
+        hipLaunchKernelGGL(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d);
+    return urso_check_launch("urso_param_grad_finalize");
+}
+
+// ------------------------------------------------------------------ input molding
+template <typename T>
+__global__ void mold_kernel(size_t npix, int is_u8, const void* __restrict__ src, const float* __restrict__ mean, void* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    for (; i < npix; i += stride) {
+        float a, b, c;
+        if (is_u8) { const uint8_t* p = (const uint8_t*)src + i * 3; a = p[0]; b = p[1]; c = p[2]; }
+        else { const float* p = (const float*)src + i * 3; a = p[0]; b = p[1]; c = p[2]; }
+        T* o = (T*)dst + i * 4;
+        o[0] = Elem<T>::from_f(a - m0); o[1] = Elem<T>::from_f(b - m1); o[2] = Elem<T>::from_f(c - m2); o[3] = Elem<T>::from_f(0.f);
+    }
+}
+
+extern "C" int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,
+                                int dt, void* dst_d, void* stream) {
+    if (!src_d || !dst_d || B <= 0 || H <= 0 || W <= 0) { urso_set_error("urso_mold_images: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    int blocks = (int)((npix + 255) / 256); if (blocks > 4096) blocks = 4096;
+    ProfScope ps(st, URSO_K_MOLD, 0, (double)npix * ((src_is_u8 ? 3 : 12) + 4 * dt_size(dt)));
+    if (dt == URSO_F32) hipLaunchKernelGGL((mold_kernel<float>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    else if (dt == URSO_BF16) hipLaunchKernelGGL((mold_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    else if (dt == URSO_F16) hipLaunchKernelGGL((mold_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    else { urso_set_error("urso_mold_images: bad dtype"); return URSO_EINVAL; }
+    return urso_check_launch("urso_mold_images");
+}

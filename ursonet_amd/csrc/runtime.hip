@@ -1,0 +1,67 @@
+// Host-side runtime glue of liburso_hip.so: error reporting and the opt-in launch profiler.
+#include "common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void urso_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int urso_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { urso_set_error("%s: %s", what, hipGetErrorString(e)); return URSO_ELAUNCH; }
+    return URSO_OK;
+}
+
+extern "C" const char* urso_last_error(void) { return g_err; }
+extern "C" int urso_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- profiler
+struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; };
+static std::mutex g_pmu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pmu);
+    ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event();
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+void urso_prof_after(hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pmu);
+    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
+}
+
+extern "C" int urso_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_pmu);
+    g_prof_on = on != 0;
+    return URSO_OK;
+}
+
+extern "C" int urso_prof_collect(urso_prof_record* out, int max_records) {
+    std::lock_guard<std::mutex> lk(g_pmu);
+    int n = 0;
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (out && n < max_records) { out[n].kernel_id = r.id; out[n].ms = ms; out[n].flops = r.flops; out[n].bytes = r.bytes; ++n; }
+        g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+    return n;
+}

@@ -1,0 +1,214 @@
+"""ctypes binding of liburso_hip.so (C ABI declared in include/ursonet_hip.h).
+
+The library is the only compute path of this package: if it is missing or fails to
+load, importing this module raises -- there is no CPU / PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liburso_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+EPI_RELU, EPI_OUT_F32 = 1, 2
+K_IGEMM, K_WGRAD, K_PREP, K_FINALIZE, K_POOL, K_LOSS, K_OPTIM, K_DECODE, K_MOLD = range(1, 10)
+KERNEL_NAMES = {K_IGEMM: "conv_igemm", K_WGRAD: "conv_wgrad", K_PREP: "weight_prep", K_FINALIZE: "param_grad_finalize",
+                K_POOL: "maxpool", K_LOSS: "loss", K_OPTIM: "optimizer", K_DECODE: "quat_decode", K_MOLD: "mold"}
+
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+DT_OF_TORCH = {v: k for k, v in TORCH_DT.items()}
+DT_NAME = {F32: "f32", BF16: "bf16", F16: "f16"}
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "H", "W", "C", "OH", "OW", "N", "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW")]
+
+    def __repr__(self):
+        return "ConvGeom(" + ", ".join("%s=%d" % (n, getattr(self, n)) for n, _ in self._fields_) + ")"
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class UrsoHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("liburso_hip.so not found at %s -- build it with `python -m ursonet_amd.build` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+_vp, _fp, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_gp = C.POINTER(ConvGeom)
+_SIGS = {
+    "urso_last_error": (C.c_char_p, []),
+    "urso_abi_version": (_i, []),
+    "urso_conv_igemm": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp]),
+    "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
+    "urso_conv_wgrad": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
+    "urso_conv_weight_prep": (_i, [_i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _vp, _fp, _fp, _vp]),
+    "urso_stem_weight_pack": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _fp, _fp, _vp]),
+    "urso_stem_wgrad_unpack": (_i, [_i, _fp, _fp, _vp]),
+    "urso_param_grad_finalize": (_i, [_i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i,
+                                      _fp, _fp, _fp, _fp, _fp, _sz, _vp]),
+    "urso_param_grad_finalize_ws_bytes": (_sz, [_i, _i]),
+    "urso_mold_images": (_i, [_i, _i, _i, _i, _vp, _fp, _i, _vp, _vp]),
+    "urso_maxpool3x3s2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "urso_maxpool3x3s2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "urso_softmax_xent_fwd_bwd": (_i, [_i, _i, _fp, _fp, _f, _i, _i, _fp, _vp, _fp, _vp]),
+    "urso_rel_l2_fwd_bwd": (_i, [_i, _i, _i, _fp, _fp, _f, _i, _fp, _vp, _fp, _vp]),
+    "urso_absdot_fwd_bwd": (_i, [_i, _i, _i, _i, _fp, _fp, _f, _i, _fp, _fp, _vp, _vp]),
+    "urso_mse_fwd_bwd": (_i, [_i, _i, _i, _fp, _fp, _f, _i, _fp, _vp, _vp]),
+    "urso_sqnorm_ws_bytes": (_sz, [_sz]),
+    "urso_sqnorm": (_i, [_sz, _fp, _vp, _sz, _fp, _vp]),
+    "urso_sgd_momentum_clip": (_i, [_sz, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "urso_scale_f32": (_i, [_sz, _fp, _f, _vp]),
+    "urso_quat_wavg_decode": (_i, [_i, _i, _fp, _fp, _fp, _fp, _vp]),
+    "urso_prof_enable": (_i, [_i]),
+    "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_lib, _name)          # AttributeError here == symbol missing from the .so
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return (_lib.urso_last_error() or b"").decode()
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+    return t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream
+
+
+def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1):
+    return ConvGeom(B, H, W, Cin, OH, OW, N, KH, KW, SH, SW, PH, PW, DH, DW)
+
+
+# ---------------------------------------------------------------- thin typed wrappers
+def conv_igemm(g, dt, flags, src, wgt, bias, add, mask, dst, stream=None):
+    _chk(_lib.urso_conv_igemm(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
+                              stream_ptr(stream)), "urso_conv_igemm")
+
+
+def conv_wgrad_ws_bytes(g, dt):
+    return int(_lib.urso_conv_wgrad_ws_bytes(C.byref(g), dt))
+
+
+def conv_wgrad(g, dt, x, dz, ws, dw_raw, colsum, stream=None):
+    _chk(_lib.urso_conv_wgrad(C.byref(g), dt, ptr(x), ptr(dz), ptr(ws), ws.numel() * ws.element_size(), ptr(dw_raw),
+                              ptr(colsum), stream_ptr(stream)), "urso_conv_wgrad")
+
+
+def conv_weight_prep(KH, KW, Cin, N, npad, dt, w, b, gamma, beta, mean, var, eps, wf, wd, biasf, scale, stream=None):
+    _chk(_lib.urso_conv_weight_prep(KH, KW, Cin, N, npad, dt, ptr(w), ptr(b), ptr(gamma), ptr(beta), ptr(mean), ptr(var),
+                                    eps, ptr(wf), ptr(wd), ptr(biasf), ptr(scale), stream_ptr(stream)),
+         "urso_conv_weight_prep")
+
+
+def stem_weight_pack(N, dt, w, b, gamma, beta, mean, var, eps, wf, biasf, scale, stream=None):
+    _chk(_lib.urso_stem_weight_pack(N, dt, ptr(w), ptr(b), ptr(gamma), ptr(beta), ptr(mean), ptr(var), eps, ptr(wf),
+                                    ptr(biasf), ptr(scale), stream_ptr(stream)), "urso_stem_weight_pack")
+
+
+def stem_wgrad_unpack(N, dw_packed, dw_raw, stream=None):
+    _chk(_lib.urso_stem_wgrad_unpack(N, ptr(dw_packed), ptr(dw_raw), stream_ptr(stream)), "urso_stem_wgrad_unpack")
+
+
+def param_grad_finalize_ws_bytes(K, N):
+    return int(_lib.urso_param_grad_finalize_ws_bytes(K, N))
+
+
+def param_grad_finalize(K, N, ldn, dw_raw, colsum, w, b, gamma, mean, var, eps, wd, trainable, bn_trainable,
+                        gw, gb, ggamma, gbeta, ws, stream=None):
+    _chk(_lib.urso_param_grad_finalize(K, N, ldn, ptr(dw_raw), ptr(colsum), ptr(w), ptr(b), ptr(gamma), ptr(mean),
+                                       ptr(var), eps, wd, int(trainable), int(bn_trainable), ptr(gw), ptr(gb),
+                                       ptr(ggamma), ptr(gbeta), ptr(ws), ws.numel() * ws.element_size(),
+                                       stream_ptr(stream)), "urso_param_grad_finalize")
+
+
+def mold_images(B, H, W, src, mean3, dt, dst, stream=None):
+    is_u8 = 1 if src.dtype == torch.uint8 else 0
+    assert is_u8 or src.dtype == torch.float32
+    _chk(_lib.urso_mold_images(B, H, W, is_u8, ptr(src), ptr(mean3), dt, ptr(dst), stream_ptr(stream)), "urso_mold_images")
+
+
+def maxpool_fwd(B, H, W, Cc, dt, x, y, argmax, stream=None):
+    _chk(_lib.urso_maxpool3x3s2_fwd(B, H, W, Cc, dt, ptr(x), ptr(y), ptr(argmax), stream_ptr(stream)), "urso_maxpool3x3s2_fwd")
+
+
+def maxpool_bwd(B, H, W, Cc, dt, y, dy, argmax, relu_mask, dx, stream=None):
+    _chk(_lib.urso_maxpool3x3s2_bwd(B, H, W, Cc, dt, ptr(y), ptr(dy), ptr(argmax), int(relu_mask), ptr(dx),
+                                    stream_ptr(stream)), "urso_maxpool3x3s2_bwd")
+
+
+def softmax_xent(B, K, logits, labels, weight, relu_mask, dt, loss, dz, row_ws, stream=None):
+    _chk(_lib.urso_softmax_xent_fwd_bwd(B, K, ptr(logits), ptr(labels), weight, int(relu_mask), dt, ptr(loss), ptr(dz),
+                                        ptr(row_ws), stream_ptr(stream)), "urso_softmax_xent_fwd_bwd")
+
+
+def rel_l2(B, D, ld, gt, pred, weight, dt, loss, dpred, norms=None, stream=None):
+    _chk(_lib.urso_rel_l2_fwd_bwd(B, D, ld, ptr(gt), ptr(pred), weight, dt, ptr(loss), ptr(dpred), ptr(norms),
+                                  stream_ptr(stream)), "urso_rel_l2_fwd_bwd")
+
+
+def absdot(B, D, ld, normalize, gt, x, weight, dt, q, loss, dx, stream=None):
+    _chk(_lib.urso_absdot_fwd_bwd(B, D, ld, int(normalize), ptr(gt), ptr(x), weight, dt, ptr(q), ptr(loss), ptr(dx),
+                                  stream_ptr(stream)), "urso_absdot_fwd_bwd")
+
+
+def mse(B, D, ld, gt, pred, weight, dt, loss, dpred, stream=None):
+    _chk(_lib.urso_mse_fwd_bwd(B, D, ld, ptr(gt), ptr(pred), weight, dt, ptr(loss), ptr(dpred), stream_ptr(stream)),
+         "urso_mse_fwd_bwd")
+
+
+def sqnorm_ws_bytes(n):
+    return int(_lib.urso_sqnorm_ws_bytes(n))
+
+
+def sqnorm(n, g, ws, out, stream=None):
+    _chk(_lib.urso_sqnorm(n, ptr(g), ptr(ws), ws.numel() * ws.element_size(), ptr(out), stream_ptr(stream)), "urso_sqnorm")
+
+
+def sgd_momentum_clip(n, w, g, v, hyper, normsq, stream=None):
+    _chk(_lib.urso_sgd_momentum_clip(n, ptr(w), ptr(g), ptr(v), ptr(hyper), ptr(normsq), stream_ptr(stream)),
+         "urso_sgd_momentum_clip")
+
+
+def scale_f32(n, x, s, stream=None):
+    _chk(_lib.urso_scale_f32(n, ptr(x), s, stream_ptr(stream)), "urso_scale_f32")
+
+
+def quat_wavg_decode(B, K, logits, hquat, q, a=None, stream=None):
+    _chk(_lib.urso_quat_wavg_decode(B, K, ptr(logits), ptr(hquat), ptr(q), ptr(a), stream_ptr(stream)),
+         "urso_quat_wavg_decode")
+
+
+def prof_enable(on):
+    _lib.urso_prof_enable(int(on))
+
+
+def prof_collect(max_records=65536):
+    buf = (ProfRecord * max_records)()
+    n = _lib.urso_prof_collect(buf, max_records)
+    return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes) for i in range(n)]
