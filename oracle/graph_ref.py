@@ -190,101 +190,112 @@ def dense(x, p):
     return x @ p["kernel"] + p["bias"]                                     # [A4]
 
 
+def relu(x, site=None, hook=None):
+    """Activation('relu').  `hook(site, pre_activation) -> bool mask or None` lets a TEST force
+    the few ReLU decisions that sit within float rounding of zero to the decision the device
+    took (tests/test_model_gpu.py); with hook=None this is plain max(x, 0)."""
+    if hook is not None:
+        m = hook(site, x)
+        if m is not None:
+            return x * m.to(x.dtype)
+    return F.relu(x)
+
+
 # --------------------------------------------------------------------------
 # graph builders
 # --------------------------------------------------------------------------
-def identity_block(x, P, stage, block, train_bn):
+def identity_block(x, P, stage, block, train_bn, hook=None):
     """net.py:85-117."""
     cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
-    y = F.relu(batchnorm(conv2d(x, P[cb + "2a"]), P[bb + "2a"], train_bn))
-    y = F.relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn))
+    y = relu(batchnorm(conv2d(x, P[cb + "2a"]), P[bb + "2a"], train_bn), cb + "2a", hook)
+    y = relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn), cb + "2b", hook)
     y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
-    return F.relu(y + x)
+    return relu(y + x, cb + "2c", hook)
 
 
-def conv_block(x, P, stage, block, stride, train_bn):
+def conv_block(x, P, stage, block, stride, train_bn, hook=None):
     """net.py:120-158 -- stride sits on 2a and on the shortcut branch1."""
     cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
-    y = F.relu(batchnorm(conv2d(x, P[cb + "2a"], stride=stride), P[bb + "2a"], train_bn))
-    y = F.relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn))
+    y = relu(batchnorm(conv2d(x, P[cb + "2a"], stride=stride), P[bb + "2a"], train_bn), cb + "2a", hook)
+    y = relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn), cb + "2b", hook)
     y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
     sc = batchnorm(conv2d(x, P[cb + "1"], stride=stride), P[bb + "1"], train_bn)
-    return F.relu(y + sc)
+    return relu(y + sc, cb + "2c", hook)
 
 
-def resnet_graph(x, P, arch, train_bn):
+def resnet_graph(x, P, arch, train_bn, hook=None):
     """net.py:161-199 (stage5=True)."""
     x = conv2d(x, P["conv1"], stride=2, padding=3)
-    x = F.relu(batchnorm(x, P["bn_conv1"], train_bn))
+    x = relu(batchnorm(x, P["bn_conv1"], train_bn), "conv1", hook)
     x = maxpool_3x3_s2_same(x)
     for stage, blocks, _ in _deep_blocks(arch):
         for b in blocks:
             if b == "a":
-                x = conv_block(x, P, stage, b, 1 if stage == 2 else 2, train_bn)
+                x = conv_block(x, P, stage, b, 1 if stage == 2 else 2, train_bn, hook)
             else:
-                x = identity_block(x, P, stage, b, train_bn)
+                x = identity_block(x, P, stage, b, train_bn, hook)
     return x
 
 
-def residual_basic_block(x, P, stage, block, stride, cut, train_bn):
+def residual_basic_block(x, P, stage, block, stride, cut, train_bn, hook=None):
     """net.py:216-240 -- ONE BatchNorm per block (after conv1)."""
     nb = "stage%d_unit%d_" % (stage + 1, block + 1)
     sc = x if cut == "pre" else conv2d(x, P[nb + "sc"], stride=stride)
     y = conv2d(x, P[nb + "conv1"], stride=stride, padding=1)
-    y = F.relu(batchnorm(y, P[nb + "bn2"], train_bn))
+    y = relu(batchnorm(y, P[nb + "bn2"], train_bn), nb + "conv1", hook)
     y = conv2d(y, P[nb + "conv2"], padding=1)
-    return F.relu(y + sc)
+    return relu(y + sc, nb + "conv2", hook)
 
 
-def resnet_shallow_graph(x, P, arch, train_bn):
+def resnet_shallow_graph(x, P, arch, train_bn, hook=None):
     """net.py:242-282."""
     x = conv2d(x, P["conv0"], stride=2, padding=3)
-    x = F.relu(batchnorm(x, P["bn_conv0"], train_bn))
+    x = relu(batchnorm(x, P["bn_conv0"], train_bn), "conv0", hook)
     x = maxpool_3x3_s2_same(x)
     reps = [2, 2, 2, 2] if arch == "resnet18" else [3, 4, 6, 3]
     for stage, rep in enumerate(reps):
         for block in range(rep):
             if block == 0 and stage == 0:
-                x = residual_basic_block(x, P, stage, block, 1, "post", train_bn)
+                x = residual_basic_block(x, P, stage, block, 1, "post", train_bn, hook)
             elif block == 0:
-                x = residual_basic_block(x, P, stage, block, 2, "post", train_bn)
+                x = residual_basic_block(x, P, stage, block, 2, "post", train_bn, hook)
             else:
-                x = residual_basic_block(x, P, stage, block, 1, "pre", train_bn)
+                x = residual_basic_block(x, P, stage, block, 1, "pre", train_bn, hook)
     return x
 
 
-def _branch_trunk(feat, P, config, br):
+def _branch_trunk(feat, P, config, br, hook=None):
     x = feat
     for i in range(config.NR_DENSE_LAYERS):
         x = dense(x, P["%s_dense_%d" % (br, i)])
         if config.TRAIN_BN:
             x = batchnorm(x, P["%s_bn_%d" % (br, i)], None)               # net.py:306: no training arg
-        x = F.relu(x)
+        x = relu(x, "%s_dense_%d" % (br, i), hook)
     return x
 
 
-def build_loc_graph(feat, P, config):
+def build_loc_graph(feat, P, config, hook=None):
     """net.py:288-320."""
-    x = _branch_trunk(feat, P, config, "loc")
+    x = _branch_trunk(feat, P, config, "loc", hook)
     if config.REGRESS_KEYPOINTS:
         return [dense(x, P[k]) for k in ("k1_final", "k2_final", "k3_final")]
     if config.REGRESS_LOC:
         return dense(x, P["loc_final"])
-    return F.relu(dense(x, P["loc_final"]))
+    return relu(dense(x, P["loc_final"]), "loc_final", hook)
 
 
-def build_ori_graph(feat, P, config):
+def build_ori_graph(feat, P, config, hook=None):
     """net.py:322-352."""
-    x = _branch_trunk(feat, P, config, "ori")
+    x = _branch_trunk(feat, P, config, "ori", hook)
     if config.REGRESS_ORI:
         if config.ORIENTATION_PARAM == "quaternion":
             q = dense(x, P["ori_q"])
             return q * torch.rsqrt(torch.clamp((q * q).sum(-1, keepdim=True), min=1e-12))   # [A5]
         return dense(x, P["ori_final"])
-    return F.relu(dense(x, P["ori_final"]))
+    return relu(dense(x, P["ori_final"]), "ori_final", hook)
 
 
-def forward(P, images_nhwc, config):
+def forward(P, images_nhwc, config, relu_hook=None):
     """net.py:629-643.  images_nhwc: molded float tensor [B,H,W,C].  Returns (loc, ori)."""
     h, w = images_nhwc.shape[1:3]
     if h / 2 ** 6 != int(h / 2 ** 6) or w / 2 ** 6 != int(w / 2 ** 6):   # net.py:596-600
@@ -293,12 +304,12 @@ def forward(P, images_nhwc, config):
                         "For example, use 256, 320, 384, 448, 512, ... etc. ")
     x = images_nhwc.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     if config.BACKBONE in ("resnet50", "resnet101"):
-        c5 = resnet_graph(x, P, config.BACKBONE, config.TRAIN_BN)
+        c5 = resnet_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook)
     else:
-        c5 = resnet_shallow_graph(x, P, config.BACKBONE, config.TRAIN_BN)
+        c5 = resnet_shallow_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook)
     c6 = conv2d(c5, P["bottleneck_layer"], stride=2, padding="same")
     feat = c6.permute(0, 2, 3, 1).reshape(c6.shape[0], -1)                # (h,w,c) flatten [A4]
-    return build_loc_graph(feat, P, config), build_ori_graph(feat, P, config)
+    return build_loc_graph(feat, P, config, relu_hook), build_ori_graph(feat, P, config, relu_hook)
 
 
 # --------------------------------------------------------------------------
@@ -324,9 +335,9 @@ def rel_loss(y_gt, y_pred):
     return torch.linalg.vector_norm((y_gt - y_pred) / torch.linalg.vector_norm(y_gt))
 
 
-def losses(P, images, gt_loc, gt_ori, config):
+def losses(P, images, gt_loc, gt_ori, config, relu_hook=None):
     """net.py:656-669.  Returns (loc_pred, ori_pred, loc_loss, ori_loss)."""
-    loc, ori = forward(P, images, config)
+    loc, ori = forward(P, images, config, relu_hook)
     assert not config.REGRESS_KEYPOINTS, "keypoint mode: use losses_keypoints"
     loc_loss = rel_loss(gt_loc, loc) if config.REGRESS_LOC else softmax_loss(gt_loc, loc)
     ori_loss = one_minus_dot_prod(gt_ori, ori) if config.REGRESS_ORI else softmax_loss(gt_ori, ori)
@@ -351,18 +362,18 @@ def regularizer(P, config, layer_regex=".*"):
     return reg
 
 
-def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*"):
+def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None):
     """net.py:993-1012: sum_name LOSS_WEIGHTS[name]*mean(loss) + regulariser."""
-    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config)
+    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config, relu_hook)
     tot = config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("ori_loss", 1.) * ol
     return tot + regularizer(P, config, layer_regex), (loc, ori, ll, ol)
 
 
-def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*"):
+def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None):
     """Returns (grads {layer:{weight: tensor}}, (loc, ori, loc_loss, ori_loss), total)."""
     leaves = [(ln, wn, w) for ln, ws in P.items() for wn, w in ws.items()
               if w.requires_grad and is_trainable(ln, layer_regex)]
-    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex)
+    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook)
     gs = torch.autograd.grad(tot, [w for _, _, w in leaves], allow_unused=True)
     grads = OrderedDict()
     for (ln, wn, w), g in zip(leaves, gs):
@@ -393,9 +404,9 @@ def sgd_step(P, grads, velocity, lr, momentum, clipnorm):
     return norm
 
 
-def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*"):
+def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*", relu_hook=None):
     """One fit_generator step [A13]: fwd, loss, bwd, clip, update.  Returns dict of scalars/outputs."""
-    grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex)
+    grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook)
     norm = sgd_step(P, grads, velocity, lr, config.LEARNING_MOMENTUM, config.GRADIENT_CLIP_NORM)
     return {"loc": loc, "ori": ori, "loc_loss": float(ll), "ori_loss": float(ol), "total": float(tot),
             "grad_norm": norm, "grads": grads}

@@ -1,0 +1,476 @@
+"""Static execution plan of the UrsoNet hot path on one MI355X.
+
+The reference runs its graph through Keras/TensorFlow sessions (net.py:1152-1163 fit_generator,
+net.py:1251 predict).  Here the graph (ursonet_amd/graph.py) is lowered ONCE into a flat list of
+C-ABI kernel launches over pre-allocated HBM buffers -- weight prep (BN folding), forward, fused
+loss+gradient, backward (dgrad/wgrad), parameter-gradient finalisation, global-norm clip + momentum
+SGD -- and the whole step is captured into a hipGraph and replayed (no per-step Python, no
+allocator, no host sync).  PyTorch is used only for device memory, streams and graph capture.
+
+Data layout in HBM: activations NHWC in the compute dtype; all trainable parameters live in ONE
+flat fp32 buffer (Keras layouts, forward layer order) with matching flat gradient / momentum
+buffers, so that the data-parallel all-reduce works on contiguous slices (ursonet_amd/dp.py)
+and the optimizer is two launches.
+"""
+import math
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hip
+from .config import compute_dtype_name
+from .graph import BN_EPS, build_graph, conv_flops
+
+_DT = {"float32": hip.F32, "bfloat16": hip.BF16, "float16": hip.F16}
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class _Act(object):
+    """An activation tensor in HBM (+ its gradient buffer, allocated on demand)."""
+
+    def __init__(self, eng, spec, numel, dtype):
+        self.spec, self.numel = spec, numel
+        self.data = torch.empty(numel, dtype=dtype, device=eng.device)
+        self.grad = None
+        self.grad_written = False
+        self.pending = None          # gradient tensor to be folded into the next dgrad into this tensor
+        self.eng = eng
+
+    def grad_buf(self):
+        if self.grad is None:
+            self.grad = torch.empty(self.numel, dtype=self.data.dtype, device=self.eng.device)
+        return self.grad
+
+
+class _Conv(object):
+    pass
+
+
+class Engine(object):
+    def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False):
+        assert mode in ("training", "inference")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ursonet_amd.Engine needs an AMD GPU (MI355X / gfx950); there is no CPU fallback")
+        self.config, self.mode = config, mode
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.dt_name = compute_dtype_name(config)
+        self.dt = _DT[self.dt_name]
+        self.tdt = hip.TORCH_DT[self.dt]
+        self.B = int(batch if batch is not None else config.BATCH_SIZE)
+        self.graph = build_graph(config)
+        self.H, self.W = int(config.IMAGE_SHAPE[0]), int(config.IMAGE_SHAPE[1])
+        self.layer_trainable = {n: True for n in self.graph.params}
+        self.world_size = 1
+        self._graphs = None
+        self._alloc_params(seed, randomize_bn)
+        self._build_plan()
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self, seed, randomize_bn):
+        g = self.graph
+        off, soff = 0, 0
+        self.slices = OrderedDict()        # (layer, weight) -> (offset, numel, shape) in the flat trainable buffer
+        self.stat_slices = OrderedDict()   # (layer, weight) -> ... in the BN statistics buffer
+        for ln, ws in g.params.items():
+            for wn, shape in ws.items():
+                n = int(np.prod(shape))
+                if wn in ("moving_mean", "moving_variance"):
+                    self.stat_slices[(ln, wn)] = (soff, n, shape); soff += _round_up(n, 4)
+                else:
+                    self.slices[(ln, wn)] = (off, n, shape); off += _round_up(n, 4)
+        self.n_flat = off
+        dev = self.device
+        self.flat_w = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        self.flat_stats = torch.zeros(max(soff, 4), dtype=torch.float32, device=dev)
+        if self.mode == "training":
+            self.flat_g = torch.zeros_like(self.flat_w)
+            self.flat_v = torch.zeros_like(self.flat_w)
+        self.set_weights(initial_weights(g, seed, randomize_bn))
+
+    def wview(self, ln, wn, buf=None):
+        if (ln, wn) in self.slices:
+            o, n, shape = self.slices[(ln, wn)]
+            base = self.flat_w if buf is None else buf
+        else:
+            o, n, shape = self.stat_slices[(ln, wn)]
+            base = self.flat_stats
+        return base[o:o + n].view(shape)
+
+    def gview(self, ln, wn):
+        return self.wview(ln, wn, self.flat_g)
+
+    def set_weights(self, params, strict=True):
+        """params: {layer: {weight: array}} in Keras layouts.  Missing layers are skipped unless strict."""
+        for ln, ws in self.graph.params.items():
+            if ln not in params:
+                if strict:
+                    raise KeyError("missing layer %r" % ln)
+                continue
+            for wn, shape in ws.items():
+                a = np.asarray(params[ln][wn], dtype=np.float32)
+                if tuple(a.shape) != tuple(shape):
+                    raise ValueError("layer %s weight %s: shape %s != expected %s" % (ln, wn, a.shape, shape))
+                self.wview(ln, wn).copy_(torch.from_numpy(np.ascontiguousarray(a)))
+
+    def get_weights(self):
+        out = OrderedDict()
+        for ln, ws in self.graph.params.items():
+            out[ln] = OrderedDict((wn, self.wview(ln, wn).detach().cpu().numpy().copy()) for wn in ws)
+        return out
+
+    def get_grads(self):
+        out = OrderedDict()
+        for (ln, wn) in self.slices:
+            out.setdefault(ln, OrderedDict())[wn] = self.gview(ln, wn).detach().cpu().numpy().copy()
+        return out
+
+    def set_trainable(self, layer_regex):
+        """net.py:1030-1066: layer.trainable = fullmatch(regex, layer.name).  Rebuilds the plan."""
+        self.layer_trainable = {n: bool(re.fullmatch(layer_regex, n)) for n in self.graph.params}
+        self._graphs = None
+        self._build_plan()
+
+    # ------------------------------------------------------------------ plan construction
+    def _ptr_or_none(self, ln, wn):
+        if ln is None or (ln, wn) not in self.slices and (ln, wn) not in self.stat_slices:
+            return None
+        return self.wview(ln, wn).reshape(-1)
+
+    def _build_plan(self):
+        cfg, g, B, dt, dev = self.config, self.graph, self.B, self.dt, self.device
+        training = self.mode == "training"
+        VE = 16 // (4 if dt == hip.F32 else 2)
+        self.acts = {}
+        self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
+        self.convs = OrderedDict()
+
+        def act(spec, numel=None):
+            if spec.id not in self.acts:
+                self.acts[spec.id] = _Act(self, spec, numel if numel is not None else B * spec.h * spec.w * spec.c, self.tdt)
+            return self.acts[spec.id]
+
+        # ---- inputs
+        self.in_images = torch.zeros(B, self.H, self.W, 3, dtype=torch.float32, device=dev)
+        img_spec = g.tensors[0]
+        x0 = act(img_spec, B * self.H * self.W * 4)               # channels padded 3 -> 4, viewed as pixel pairs
+        self.fwd_ops.append(lambda: hip.mold_images(B, self.H, self.W, self.in_images, None, dt, x0.data))
+
+        max_ws = 0
+        max_fin_ws = 0
+        for node in g.nodes:
+            if node.op == "pool":
+                src, dst = act(node.src), act(node.dst)
+                am = torch.empty(dst.numel, dtype=torch.uint8, device=dev)
+                h, w, c = node.src.h, node.src.w, node.src.c
+                self.fwd_ops.append(lambda s=src, d=dst, am=am, h=h, w=w, c=c: hip.maxpool_fwd(B, h, w, c, dt, s.data, d.data, am))
+                node._am = am
+                continue
+            c = _Conv()
+            c.node = node
+            c.name, c.bn = node.name, node.bn
+            c.N = node.cout
+            c.npad = _round_up(node.cout, 8)
+            c.src = act(node.src) if not node.stem else x0
+            out_elt = torch.float32 if node.out_f32 else self.tdt
+            if node.dst.id not in self.acts:
+                a = _Act(self, node.dst, B * node.dst.h * node.dst.w * c.npad, out_elt)
+                self.acts[node.dst.id] = a
+            c.dst = self.acts[node.dst.id]
+            c.res = act(node.residual) if node.residual is not None else None
+            if node.stem:
+                c.gf = hip.geom(B, self.H, self.W // 2, 8, node.dst.h, node.dst.w, c.npad, 7, 4, 2, 1, 3, 2)
+                c.K_raw = 7 * 4 * 8
+                c.gd = None
+            elif node.dense:
+                c.gf = hip.geom(B, 1, 1, node.cin, 1, 1, c.npad, 1, 1)
+                c.gd = hip.geom(B, 1, 1, c.npad, 1, 1, node.cin, 1, 1)
+                c.K_raw = node.cin
+            else:
+                s, (pt, pl) = node.stride, node.pad
+                c.gf = hip.geom(B, node.src.h, node.src.w, node.cin, node.dst.h, node.dst.w, c.npad, node.kh, node.kw, s, s, pt, pl)
+                c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.src.h, node.src.w, node.cin, node.kh, node.kw,
+                                1, 1, node.kh - 1 - pt, node.kw - 1 - pl, s, s)
+                c.K_raw = node.kh * node.kw * node.cin
+            if node.cin % VE and not node.stem:
+                raise ValueError("layer %s: %d input channels is not a multiple of %d" % (node.name, node.cin, VE))
+            kelems = c.npad * c.K_raw
+            c.wf = torch.empty(kelems, dtype=self.tdt, device=dev)
+            need_dgrad = training and not node.stem
+            c.wd = torch.empty(kelems, dtype=self.tdt, device=dev) if need_dgrad else None
+            c.biasf = torch.empty(c.npad, dtype=torch.float32, device=dev)
+            c.scale = torch.empty(c.npad, dtype=torch.float32, device=dev)
+            c.w = self.wview(node.name, "kernel").reshape(-1)
+            c.b = self._ptr_or_none(node.name, "bias") if node.bias else None
+            c.gamma = self._ptr_or_none(node.bn, "gamma") if node.bn else None
+            c.beta = self._ptr_or_none(node.bn, "beta") if node.bn else None
+            c.mean = self._ptr_or_none(node.bn, "moving_mean") if node.bn else None
+            c.var = self._ptr_or_none(node.bn, "moving_variance") if node.bn else None
+            self.convs[node.name] = c
+            # -- weight prep (per step in training; once in inference)
+            if node.stem:
+                self.prep_ops.append(lambda c=c: hip.stem_weight_pack(c.N, dt, c.w, c.b, c.gamma, c.beta, c.mean, c.var, BN_EPS,
+                                                                      c.wf, c.biasf, c.scale))
+            else:
+                self.prep_ops.append(lambda c=c, n=node: hip.conv_weight_prep(n.kh if not n.dense else 1, n.kw if not n.dense else 1,
+                                                                              n.cin, c.N, c.npad, dt, c.w, c.b, c.gamma, c.beta, c.mean,
+                                                                              c.var, BN_EPS, c.wf, c.wd, c.biasf, c.scale))
+            # -- forward
+            flags = (hip.EPI_RELU if node.relu else 0) | (hip.EPI_OUT_F32 if node.out_f32 else 0)
+            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm(c.gf, dt, f, c.src.data, c.wf, c.biasf,
+                                                                    c.res.data if c.res is not None else None, None, c.dst.data))
+            if training:
+                max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
+                max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(c.K_raw if not node.stem else 147, c.N))
+        self.out_loc = self.acts[g.outputs["loc"].id]
+        self.out_ori = self.acts[g.outputs["ori"].id]
+        self._build_heads_io()
+        if not training:
+            return
+        # ---------------------------------------------------------------- losses + backward
+        self.ws = torch.empty(max_ws // 4 + 64, dtype=torch.float32, device=dev)
+        self.fin_ws = torch.empty(max_fin_ws // 4 + 64, dtype=torch.float32, device=dev)
+        self._build_losses()
+        self.bucket_of_op = []
+        for node in reversed(g.nodes):
+            if node.op == "pool":
+                src, dst = self.acts[node.src.id], self.acts[node.dst.id]
+                h, w, cc = node.src.h, node.src.w, node.src.c
+                gsrc = src.grad_buf()
+                assert dst.grad_written
+                self.bwd_ops.append((None, lambda d=dst, gs=gsrc, am=node._am, h=h, w=w, cc=cc:
+                                     hip.maxpool_bwd(B, h, w, cc, dt, d.data, d.grad, am, 1, gs)))
+                src.grad_written = True
+                continue
+            c = self.convs[node.name]
+            assert c.dst.grad_written or c.dst.grad is not None, "no gradient reaches %s" % node.name
+            G = c.dst.grad
+            tr = self.layer_trainable[node.name]
+            bn_tr = self.layer_trainable[node.bn] if node.bn else False
+            # -- weight gradient + finalisation (skipped for fully frozen layers; their grads stay zero)
+            if tr or bn_tr:
+                c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
+                c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev)
+                self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad(c.gf, dt, c.src.data, G, self.ws, c.dw_raw, c.colsum)))
+                dwr = c.dw_raw
+                Kf = c.K_raw
+                if node.stem:
+                    c.dw_unp = torch.empty(147 * c.N, dtype=torch.float32, device=dev)
+                    self.bwd_ops.append((node.name, lambda c=c: hip.stem_wgrad_unpack(c.N, c.dw_raw, c.dw_unp)))
+                    dwr, Kf = c.dw_unp, 147
+                gw = self.gview(node.name, "kernel").reshape(-1)
+                gb = self.gview(node.name, "bias").reshape(-1) if node.bias else None
+                gg = self.gview(node.bn, "gamma").reshape(-1) if node.bn else None
+                gbe = self.gview(node.bn, "beta").reshape(-1) if node.bn else None
+                ldn = c.npad if not node.stem else c.N
+                self.bwd_ops.append((node.name, lambda c=c, dwr=dwr, Kf=Kf, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr, ldn=ldn:
+                                     hip.param_grad_finalize(Kf, c.N, ldn, dwr, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
+                                                             float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
+            # -- residual branch: its gradient IS G (Add); fold it into the next dgrad (post-ReLU tensors) or alias it
+            if c.res is not None:
+                R = c.res
+                if R.grad_written or R.pending is not None:
+                    raise AssertionError("unexpected second residual consumer for %s" % node.name)
+                if R.spec.relu:
+                    R.pending = G
+                else:
+                    R.grad, R.grad_written = G, True
+            # -- data gradient into the conv input
+            if not node.stem:
+                X = c.src
+                add = X.grad if X.grad_written else X.pending
+                dstg = X.grad_buf()
+                mask = X.data if X.spec.relu else None
+                self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
+                                     hip.conv_igemm(c.gd, dt, 0, G, c.wd, None, add, mask, dstg)))
+                X.grad_written, X.pending = True, None
+        # ---------------------------------------------------------------- optimizer
+        n = self.n_flat
+        self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), float(cfg.GRADIENT_CLIP_NORM or 0.0)],
+                                  dtype=torch.float32, device=dev)
+        self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sq_ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, dtype=torch.float32, device=dev)
+        self.opt_ops.append(lambda: hip.sqnorm(n, self.flat_g, self.sq_ws, self.normsq))
+        self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
+        self.flat_g.zero_()
+
+    def _build_heads_io(self):
+        cfg, B, dev = self.config, self.B, self.device
+        self.quat_head = bool(cfg.REGRESS_ORI and cfg.ORIENTATION_PARAM == "quaternion")
+        if self.quat_head:
+            self.q_out = torch.zeros(B, 4, dtype=torch.float32, device=dev)
+            if self.mode == "inference":
+                x = self.out_ori
+                self.fwd_ops.append(lambda: hip.absdot(B, 4, 8, 1, None, x.data, 1.0, self.dt, self.q_out, None, None))
+
+    def _build_losses(self):
+        cfg, g, B, dt, dev = self.config, self.graph, self.B, self.dt, self.device
+        lw = cfg.LOSS_WEIGHTS
+        self.loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)       # loc_loss, ori_loss, k2_loss, k3_loss (weighted)
+        self.rel_norms = torch.zeros(2, dtype=torch.float32, device=dev)
+        loc, ori = self.out_loc, self.out_ori
+        nloc = g.outputs["loc"].c
+        nori = g.outputs["ori"].c
+        self.row_ws = torch.empty(B, dtype=torch.float32, device=dev)
+        if cfg.REGRESS_KEYPOINTS:
+            # experimental keypoint mode (net.py:657-659): three MSE losses on k1 (=loc), k2, k3
+            self.gt_loc = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+            self.gt_ori = torch.zeros(B, 3, dtype=torch.float32, device=dev)      # input_gt_k2
+            self.gt_k3 = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+            for key, gt, wname, li in (("k1", self.gt_loc, "loc_loss", 0), ("k2", self.gt_ori, "k2_loss", 2), ("k3", self.gt_k3, "k3_loss", 3)):
+                a = self.acts[g.outputs[key].id]
+                gzt = torch.empty(a.numel, dtype=self.tdt, device=dev)
+                a.grad, a.grad_written = gzt, True
+                self.loss_ops.append(lambda a=a, gt=gt, w=float(lw.get(wname, 1.)), li=li, gzt=gzt:
+                                     hip.mse(B, 3, 8, gt, a.data, w, dt, self.loss_buf[li:li + 1], gzt))
+            return
+        if (not cfg.REGRESS_LOC and nloc % 8) or (not cfg.REGRESS_ORI and nori % 8):
+            raise ValueError("classification heads need a bin count that is a multiple of 8 (got %d / %d)" % (nloc, nori))
+        # location head
+        gz_loc = torch.empty(loc.numel, dtype=self.tdt, device=dev)
+        loc.grad, loc.grad_written = gz_loc, True
+        wl = float(lw.get("loc_loss", 1.))
+        if cfg.REGRESS_LOC:
+            self.gt_loc = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+            self.loss_ops.append(lambda: hip.rel_l2(B, 3, 8, self.gt_loc, loc.data, wl, dt, self.loss_buf[0:1], gz_loc, self.rel_norms))
+        else:
+            self.gt_loc = torch.zeros(B, nloc, dtype=torch.float32, device=dev)
+            self.loss_ops.append(lambda: hip.softmax_xent(B, nloc, loc.data, self.gt_loc, wl, 1, dt, self.loss_buf[0:1], gz_loc, self.row_ws))
+        # orientation head
+        gz_ori = torch.empty(ori.numel, dtype=self.tdt, device=dev)
+        ori.grad, ori.grad_written = gz_ori, True
+        wo = float(lw.get("ori_loss", 1.))
+        if cfg.REGRESS_ORI:
+            d = 4 if self.quat_head else 3
+            self.gt_ori = torch.zeros(B, d, dtype=torch.float32, device=dev)
+            qo = self.q_out if self.quat_head else None
+            self.loss_ops.append(lambda: hip.absdot(B, d, 8, 1 if self.quat_head else 0, self.gt_ori, ori.data, wo, dt, qo,
+                                                    self.loss_buf[1:2], gz_ori))
+        else:
+            self.gt_ori = torch.zeros(B, nori, dtype=torch.float32, device=dev)
+            self.loss_ops.append(lambda: hip.softmax_xent(B, nori, ori.data, self.gt_ori, wo, 1, dt, self.loss_buf[1:2], gz_ori, self.row_ws))
+
+    # ------------------------------------------------------------------ execution
+    def run_prep(self):
+        for op in self.prep_ops:
+            op()
+
+    def run_forward(self):
+        for op in self.fwd_ops:
+            op()
+
+    def run_backward(self):
+        for op in self.loss_ops:
+            op()
+        for _, op in self.bwd_ops:
+            op()
+
+    def run_optimizer(self):
+        for op in self.opt_ops:
+            op()
+
+    def step_eager(self):
+        """One training step, launched kernel by kernel (used for capture, profiling and debugging)."""
+        self.run_prep(); self.run_forward(); self.run_backward(); self.run_optimizer()
+
+    def capture(self):
+        """Capture the step (training) or prep+forward (inference) into a hipGraph."""
+        torch.cuda.synchronize(self.device)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):                     # warm-up launch outside capture (module load etc.)
+            if self.mode == "training":
+                saved = (self.flat_w.clone(), self.flat_v.clone())
+                self.step_eager()
+                self.flat_w.copy_(saved[0]); self.flat_v.copy_(saved[1])
+            else:
+                self.run_prep(); self.run_forward()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            if self.mode == "training":
+                self.step_eager()
+            else:
+                self.run_prep(); self.run_forward()
+        self._graphs = gr
+        return gr
+
+    def step(self):
+        """Replay the captured training step (captures on first use)."""
+        if self._graphs is None:
+            self.capture()
+        self._graphs.replay()
+
+    def forward(self):
+        if self.mode == "training":
+            self.run_prep(); self.run_forward()
+        else:
+            if self._graphs is None:
+                self.capture()
+            self._graphs.replay()
+
+    # ------------------------------------------------------------------ I/O helpers
+    def load_batch(self, images, gt_loc=None, gt_ori=None, gt_k3=None):
+        """images: float32 [B,H,W,3] already molded (mold_image, net.py:1337-1348) -- numpy or torch."""
+        self.in_images.copy_(torch.as_tensor(images, dtype=torch.float32).reshape(self.in_images.shape), non_blocking=True)
+        if gt_loc is not None:
+            self.gt_loc.copy_(torch.as_tensor(gt_loc, dtype=torch.float32).reshape(self.gt_loc.shape), non_blocking=True)
+        if gt_ori is not None:
+            self.gt_ori.copy_(torch.as_tensor(gt_ori, dtype=torch.float32).reshape(self.gt_ori.shape), non_blocking=True)
+        if gt_k3 is not None:
+            self.gt_k3.copy_(torch.as_tensor(gt_k3, dtype=torch.float32).reshape(self.gt_k3.shape), non_blocking=True)
+
+    def outputs(self):
+        """(loc [B, n_loc], ori [B, n_ori]) as fp32 device tensors (raw network outputs, net.py:1254-1258)."""
+        g = self.graph
+        nl, no = g.outputs["loc"].c, g.outputs["ori"].c
+        loc = self.out_loc.data.view(self.B, -1)[:, :nl]
+        ori = self.q_out if self.quat_head else self.out_ori.data.view(self.B, -1)[:, :no]
+        return loc, ori
+
+    def losses(self):
+        """{'loc_loss','ori_loss'} weighted by LOSS_WEIGHTS, as in the Keras metrics (net.py:1019-1028)."""
+        l = self.loss_buf.detach().cpu().numpy()
+        return {"loc_loss": float(l[0]), "ori_loss": float(l[1])}
+
+    def set_lr(self, lr):
+        self.hyper[0] = float(lr)
+
+    def reset_optimizer(self):
+        self.flat_v.zero_()
+
+    def flops(self):
+        return conv_flops(self.graph, self.B)
+
+
+def initial_weights(graph, seed=1234, randomize_bn=False):
+    """Keras default initialisers (glorot_uniform kernels, zero biases, BN gamma=1 beta=0 mean=0 var=1;
+    used by `--weights none`, pose_estimator.py:897).  `randomize_bn` perturbs BN tensors and biases."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for ln, ws in graph.params.items():
+        p = OrderedDict()
+        for wn, shape in ws.items():
+            if wn == "kernel":
+                if len(shape) == 4:
+                    rf = shape[0] * shape[1]
+                    fi, fo = rf * shape[2], rf * shape[3]
+                else:
+                    fi, fo = shape
+                lim = math.sqrt(6.0 / (fi + fo))
+                p[wn] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif wn == "bias":
+                p[wn] = (rng.normal(0, 0.05, size=shape) if randomize_bn else np.zeros(shape)).astype(np.float32)
+            elif wn == "gamma":
+                p[wn] = (rng.uniform(0.5, 1.5, size=shape) if randomize_bn else np.ones(shape)).astype(np.float32)
+            elif wn in ("beta", "moving_mean"):
+                p[wn] = (rng.normal(0, 0.1, size=shape) if randomize_bn else np.zeros(shape)).astype(np.float32)
+            else:
+                p[wn] = (rng.uniform(0.5, 1.5, size=shape) if randomize_bn else np.ones(shape)).astype(np.float32)
+        out[ln] = p
+    return out
