@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the UrsoNet hot path on MI355X: images/sec of one full training step
+(weight prep + forward + losses + backward + global-norm clip + momentum SGD [+ RCCL gradient
+all-reduce for N > 1]) of ResNet-50 / bottleneck 32 / ori_resolution 16 soft-classification
+head at batch 32 x 512 x 640 x 3 per GPU, bf16 storage with fp32 accumulation (BASELINE.json
+configs[1]; the 640x512 of the metric is W x H).  Synthetic SPEED/URSO-shaped inputs already
+resident in HBM, random-init (glorot) weights with randomised BN statistics.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) incl. `roofline` (dominant kernel:
+the MFMA implicit-GEMM conv, timed live with HIP events through the library's launch profiler)
+and `cpu_baseline` (the torch-CPU oracle restatement of the same step, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_MFMA = {"bfloat16": 2500.0, "float16": 2500.0, "float32": 157.3}      # dense TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def bench_config(dtype, batch, h, w, backbone="resnet50", ori_bins=16):
+    from util import make_config
+    return make_config(backbone=backbone, h=h, w=w, batch=batch, regress_ori=False, regress_loc=True, ori_bins=ori_bins,
+                       bottleneck=32, branch=1024, dtype=dtype)
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(cfg_kw, sample_batch, steps):
+    """The oracle's training step (fwd+loss+bwd+SGD, fp32, torch-CPU/oneDNN) on the host cores,
+    on a bounded sample: `sample_batch` images per step, `steps` timed steps after one warm-up."""
+    from oracle import graph_ref as G
+    from util import synthetic_batch
+    cores = min(physical_cores(), 128)
+    torch.set_num_threads(cores)
+    cfg = bench_config("float32", sample_batch, cfg_kw["h"], cfg_kw["w"], cfg_kw["backbone"], cfg_kw["ori_bins"])
+    P = G.to_torch(G.init_params(cfg, 1234, randomize_bn=True))
+    img, loc, ori, _ = synthetic_batch(cfg, sample_batch, seed=99)
+    img, loc, ori = torch.tensor(img), torch.tensor(loc), torch.tensor(ori)
+    vel = {}
+    G.train_step(P, vel, img, loc, ori, cfg, 1e-3)
+    t0 = time.time()
+    for _ in range(steps):
+        G.train_step(P, vel, img, loc, ori, cfg, 1e-3)
+    dt = time.time() - t0
+    return {"value": round(sample_batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/graph_ref.train_step fp32, %s %dx%d, batch %d, %d timed steps after 1 warm-up (%.1f s)"
+                      % (cfg_kw["backbone"], cfg_kw["h"], cfg_kw["w"], sample_batch, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--ori-bins", type=int, default=16)
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ursonet_amd.engine import Engine
+    from ursonet_amd import hip
+    from util import synthetic_batch
+
+    cfg = bench_config(args.dtype, args.batch, args.height, args.width, args.backbone, args.ori_bins)
+    eng = Engine(cfg, "training", seed=1234, randomize_bn=True)
+    img, loc, ori, _ = synthetic_batch(cfg, args.batch, seed=1234 + rank)
+    eng.load_batch(img, loc, ori)                  # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+    if world > 1:
+        from ursonet_amd.dp import DataParallelEngine
+        runner = DataParallelEngine(eng)
+    else:
+        runner = eng
+    for _ in range(max(args.warmup, 1)):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = eng.losses()
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    fwd_flops, step_flops = eng.flops()
+
+    # ---- per-kernel timing with HIP events (library launch profiler), eager launches on the same stream
+    hip.prof_enable(True)
+    for _ in range(args.profile_steps):
+        eng.step_eager()
+    torch.cuda.synchronize()
+    recs = hip.prof_collect()
+    hip.prof_enable(False)
+    agg = {}
+    for kid, ms, fl, by in recs:
+        a = agg.setdefault(hip.KERNEL_NAMES.get(kid, str(kid)), [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+    kernels = {k: {"launches_per_step": v[0] // args.profile_steps, "ms_per_step": round(v[1] / args.profile_steps, 4),
+                   "tflops": round(v[2] / (v[1] * 1e9), 1) if v[1] > 0 and v[2] > 0 else None,
+                   "gbytes_per_s_algorithmic": round(v[3] / (v[1] * 1e6), 1) if v[1] > 0 and v[3] > 0 else None}
+               for k, v in agg.items()}
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    dname, (dn, dms, dfl, dby) = dom
+    peak = PEAK_MFMA[args.dtype]
+    achieved = dfl / (dms * 1e9) if dms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "avg_launch_ms": round(dms / dn, 4), "launches": dn // args.profile_steps,
+                "algorithmic_flops_per_launch": dfl / dn,
+                "whole_step_frac_of_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+    out = {
+        "metric": "images/sec fwd+bwd ResNet50 640x512 bs32/GPU", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "%s bottleneck=32 ori_resolution=%d soft-class head + loc regression, batch %d/GPU x %dx%dx3, "
+                               "full training step (prep+fwd+loss+bwd+clip+SGD%s)" % (args.backbone, args.ori_bins, args.batch, args.height,
+                                                                                     args.width, "+RCCL all-reduce" if world > 1 else ""),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hipgraph": True,
+                   "step_tflop": round(step_flops / 1e12, 3), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
+        "roofline": roofline, "kernels": kernels,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline({"h": args.height, "w": args.width, "backbone": args.backbone, "ori_bins": args.ori_bins},
+                                           args.cpu_sample_batch, args.cpu_steps)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,9 +121,71 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels nb..nb+3 of pixel m for each sub-tile
+    // ---- epilogue
     const bool relu = a.flags & URSO_EPI_RELU, outf32 = a.flags & URSO_EPI_OUT_F32;
     const bool nvec = (a.N & 3) == 0;
+    if (!outf32 && (a.N % VE) == 0) {
+        // Coalesced path: the fp32 accumulators of one 64-pixel half of the tile are staged in LDS
+        // ([64][BN+4] floats, conflict-free for both the per-lane 16-B writes and the row reads), then
+        // every thread finishes 16-byte vectors of ONE pixel row: bias + residual + ReLU + mask + cast
+        // with 16-byte global loads/stores that cover whole 256-byte row segments per 16 lanes.
+        constexpr int LROW = BN + 4;
+        constexpr int VPR = BN / VE;                 // 16-byte output vectors per tile row
+        constexpr int EIT = 64 * VPR / 256;          // vectors per thread per half
+        float* stile = (float*)smem;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        *(f32x4_t*)(stile + (i * 16 + fr) * LROW + wn * WN + j * 16 + fg * 4) = acc[i][j];
+            }
+            __syncthreads();
+            i32x4_t radd[EIT], rmsk[EIT];
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int item = tid + 256 * it, row = item / VPR, v = item % VPR;
+                const int m = m0 + pass * 64 + row, n = n0 + v * VE;
+                const bool ok = m < a.M && n < a.N;
+                const size_t o = (size_t)m * a.N + n;
+                radd[it] = (ok && a.add) ? *(const i32x4_t*)((const T*)a.add + o) : i32x4_t{0, 0, 0, 0};
+                rmsk[it] = (ok && a.mask) ? *(const i32x4_t*)((const T*)a.mask + o) : i32x4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int item = tid + 256 * it, row = item / VPR, v = item % VPR;
+                const int m = m0 + pass * 64 + row, n = n0 + v * VE;
+                if (!(m < a.M && n < a.N)) continue;
+                float x[VE];
+#pragma unroll
+                for (int q = 0; q < VE / 4; ++q) {
+                    f32x4_t t = *(const f32x4_t*)(stile + row * LROW + v * VE + q * 4);
+                    x[q * 4] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
+                }
+                if (a.bias) {
+#pragma unroll
+                    for (int q = 0; q < VE / 4; ++q) { f32x4_t b = *(const f32x4_t*)(a.bias + n + q * 4); x[q * 4] += b.x; x[q * 4 + 1] += b.y; x[q * 4 + 2] += b.z; x[q * 4 + 3] += b.w; }
+                }
+                T ea[VE], em[VE], eo[VE];
+                __builtin_memcpy(ea, &radd[it], 16); __builtin_memcpy(em, &rmsk[it], 16);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    float y = x[q];
+                    if (a.add) y += Elem<T>::to_f(ea[q]);
+                    if (relu) y = fmaxf(y, 0.f);
+                    if (a.mask && !(Elem<T>::to_f(em[q]) > 0.f)) y = 0.f;
+                    eo[q] = Elem<T>::from_f(y);
+                }
+                i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                *(i32x4_t*)((T*)a.dst + (size_t)m * a.N + n) = ov;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // scalar-friendly path (fp32 head outputs, channel counts that are not a multiple of the vector)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WM + i * 16 + fr;

@@ -15,6 +15,7 @@
 // write fp32 partial tiles; a second kernel sums the partials in a fixed order (deterministic,
 // no atomics) and also produces colsum[n] = sum_m dZ[m][n].
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
     const void* x; const void* dz; float* part; float* colpart;
@@ -180,17 +181,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// sums `splits` partial tensors of `count` floats in a fixed order
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i * 4 < count; i += stride) {
-        if (i * 4 + 3 < count) {
-            f32x4_t s = *(const f32x4_t*)(part + i * 4);
-            for (int p = 1; p < splits; ++p) { f32x4_t v = *(const f32x4_t*)(part + (size_t)p * count + i * 4); s += v; }
-            *(f32x4_t*)(out + i * 4) = s;
+// Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
+// float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
+// sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
+    __shared__ f32x4_t red[16][17];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t q = (size_t)blockIdx.x * 16 + col;          // float4 index
+    const size_t nq = (count + 3) / 4;
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const bool full = (q * 4 + 3 < count);
+    if (q < nq && full) {
+        const f32x4_t* p = (const f32x4_t*)part + q;
+        const size_t stride = count / 4;                      // count % 4 == 0 whenever `full` rows are used (host guarantees)
+        int k = sl;
+        for (; k + 48 < splits; k += 64) {
+            f32x4_t a = p[(size_t)k * stride], b = p[(size_t)(k + 16) * stride], c = p[(size_t)(k + 32) * stride], d = p[(size_t)(k + 48) * stride];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; k < splits; k += 16) s0 += p[(size_t)k * stride];
+    }
+    red[sl][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && q < nq) {
+        if (full) {
+            f32x4_t t = red[0][col];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) t += red[i][col];
+            *((f32x4_t*)out + q) = t;
         } else {
-            for (size_t e = i * 4; e < count; ++e) { float s = 0.f; for (int p = 0; p < splits; ++p) s += part[(size_t)p * count + e]; out[e] = s; }
+            for (size_t e = q * 4; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * count + e]; out[e] = t; }
         }
     }
 }
@@ -206,8 +226,11 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     p.ktiles = ceil_div(p.K, 128); p.ntiles = ceil_div(g->N, 128);
     const int tiles = p.ktiles * p.ntiles;
     const int steps = ceil_div(p.M, p.RM);
-    // aim for ~1024 blocks (4 per CU) but keep >= 8 reduction steps per block
-    int splits = ceil_div(1024, tiles);
+    // aim for ~2 resident blocks per CU (64 KiB LDS each) but keep >= 8 reduction steps per block;
+    // every extra split costs a K*N fp32 partial written and re-read, so do not over-split
+    static int target = 0;
+    if (!target) { const char* e = getenv("URSO_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    int splits = ceil_div(target, tiles);
     splits = splits < 1 ? 1 : splits;
     int max_splits = steps / 8; if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
@@ -257,10 +280,10 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
     int rc = urso_check_launch("urso_conv_wgrad");
     if (rc != URSO_OK) return rc;
     if (!direct) {
-        size_t cnt = (size_t)p.K * g->N;
-        int blocks = (int)((cnt / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
+        int blocks = (int)(((cnt + 3) / 4 + 15) / 16);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + 15) / 16)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits);
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;

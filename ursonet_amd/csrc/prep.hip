@@ -153,8 +153,12 @@ __global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dot
     const float s = bn_scale(gamma, var, eps, n);
     if (gb) gb[n] = trainable ? (s * cs + regb * (b ? b[n] : 0.f)) : 0.f;
     if (ggamma) {
-        float dot = 0.f;
-        for (int i = 0; i < ks; ++i) dot += dotpart[(size_t)i * N + n];
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        int i = 0;
+        for (; i + 3 < ks; i += 4) { d0 += dotpart[(size_t)i * N + n]; d1 += dotpart[(size_t)(i + 1) * N + n];
+                                     d2 += dotpart[(size_t)(i + 2) * N + n]; d3 += dotpart[(size_t)(i + 3) * N + n]; }
+        for (; i < ks; ++i) d0 += dotpart[(size_t)i * N + n];
+        const float dot = (d0 + d1) + (d2 + d3);
         const float rstd = rsqrtf(var[n] + eps);
         ggamma[n] = bn_trainable ? rstd * (dot + ((b ? b[n] : 0.f) - mean[n]) * cs) : 0.f;
         gbeta[n] = bn_trainable ? cs : 0.f;
@@ -164,6 +168,7 @@ __global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dot
 static int finalize_ks(int K, int N) {
     int ntiles = ceil_div(N, 64);
     int ks = ceil_div(512, ntiles);
+    if (ks > 32) ks = 32;
     int maxks = K / 16; if (maxks < 1) maxks = 1;
     if (ks > maxks) ks = maxks;
     return ks;

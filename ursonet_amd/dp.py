@@ -1,0 +1,146 @@
+"""Single-node data parallelism: one process per GPU, replicated weights, minibatch sharded by
+rank, ONE exchange step per training step -- a sum-all-reduce (averaged) of the flat fp32
+gradient buffer over RCCL/xGMI, issued per bucket while the backward pass is still running.
+
+The reference has no multi-GPU code (config.py:20 GPU_COUNT = 1; a commented-out ParallelModel at
+net.py:694-697), so the semantics are the ones a tower-parallel Keras model would have: every
+rank computes the loss of ITS shard (incl. the batch-Frobenius rel_loss, net.py:750-762), the
+gradients are averaged, and every rank applies the identical global-norm-clipped SGD update.
+
+Buckets are contiguous slices of the flat gradient buffer taken from its END (heads, stage 5 ...)
+towards its start, because that is the order in which the backward pass finalises gradients.
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): buckets are large (default 32 MiB)
+so each collective is bandwidth- not latency-bound, and there are few of them.
+"""
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(layer_sizes, bucket_bytes=32 << 20):
+    """layer_sizes: [(layer_name, start, end)] in FLAT (forward) order, contiguous.
+    Returns buckets in the order they become ready (backward order):
+    [(start, end, [layer names whose gradients live in the slice])]."""
+    buckets, cur, cur_end = [], [], None
+    for name, s, e in reversed(layer_sizes):
+        if cur_end is None:
+            cur_end = e
+        cur.append(name)
+        if (cur_end - s) * 4 >= bucket_bytes:
+            buckets.append((s, cur_end, cur))
+            cur, cur_end = [], None
+    if cur:
+        buckets.append((layer_sizes[0][1], cur_end, cur))
+    return buckets
+
+
+class GradReducer(object):
+    """Averages slices of a flat gradient tensor across the process group, asynchronously."""
+
+    def __init__(self, flat_g, buckets, group=None):
+        self.flat_g, self.buckets, self.group = flat_g, buckets, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.works = []
+
+    def launch(self, k):
+        """Start the all-reduce of bucket k (call after the kernels producing it were enqueued)."""
+        if self.world == 1:
+            return
+        s, e, _ = self.buckets[k]
+        t = self.flat_g[s:e]
+        if self.backend == "nccl":          # RCCL: averaging happens inside the collective
+            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        else:                               # gloo (CPU tests): sum, then scale on wait
+            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+
+    def wait_all(self):
+        for w, t in self.works:
+            w.wait()
+            if t is not None:
+                t.div_(self.world)
+        self.works = []
+
+
+class DataParallelEngine(object):
+    """Wraps an Engine: broadcasts the initial weights, splits the captured step into
+    [prep+forward+loss+backward-part-0], [backward-part-1], ..., [optimizer] hipGraphs and
+    interleaves the bucket all-reduces between their replays."""
+
+    def __init__(self, engine, bucket_bytes=32 << 20, group=None):
+        self.eng, self.group = engine, group
+        self.world = dist.get_world_size(group)
+        eng = engine
+        dist.broadcast(eng.flat_w, src=0, group=group)
+        dist.broadcast(eng.flat_stats, src=0, group=group)
+        # layer extents in the flat buffer
+        ext = {}
+        for (ln, wn), (o, n, _) in eng.slices.items():
+            s, e = ext.get(ln, (o, o))
+            ext[ln] = (min(s, o), max(e, o + ((n + 3) // 4) * 4))
+        layers = sorted(((ln, s, e) for ln, (s, e) in ext.items()), key=lambda t: t[1])
+        self.buckets = plan_buckets(layers, bucket_bytes)
+        self.reducer = GradReducer(eng.flat_g, self.buckets, group)
+        # split the backward op list where each bucket becomes complete
+        last_op_of_layer = {}
+        for i, (tag, _) in enumerate(eng.bwd_ops):
+            if tag is not None:
+                last_op_of_layer[tag] = i
+                bn = eng.convs[tag].bn
+                if bn:
+                    last_op_of_layer[bn] = i
+        cuts = []
+        for (_, _, names) in self.buckets:
+            idx = [last_op_of_layer[n] for n in names if n in last_op_of_layer]
+            cuts.append(max(idx) + 1 if idx else 0)
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+        self.cuts = cuts
+        self._graphs = None
+
+    def _segments(self):
+        eng = self.eng
+        segs, prev = [], 0
+        for k, c in enumerate(self.cuts):
+            ops = [op for _, op in eng.bwd_ops[prev:c]]
+            if k == 0:
+                ops = eng.prep_ops + eng.fwd_ops + eng.loss_ops + ops
+            segs.append(ops)
+            prev = c
+        tail = [op for _, op in eng.bwd_ops[prev:]]
+        return segs, tail + eng.opt_ops
+
+    def capture(self):
+        eng = self.eng
+        segs, last = self._segments()
+        torch.cuda.synchronize(eng.device)
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(side):
+            saved = (eng.flat_w.clone(), eng.flat_v.clone())
+            eng.step_eager()
+            eng.flat_w.copy_(saved[0]); eng.flat_v.copy_(saved[1])
+        torch.cuda.current_stream(eng.device).wait_stream(side)
+        torch.cuda.synchronize(eng.device)
+        graphs = []
+        pool = None
+        for ops in segs + [last]:
+            if not ops:                      # e.g. a bucket made only of frozen layers
+                graphs.append(None)
+                continue
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, pool=pool):
+                for op in ops:
+                    op()
+            pool = gr.pool()
+            graphs.append(gr)
+        self._graphs = graphs
+
+    def step(self):
+        if self._graphs is None:
+            self.capture()
+        for k in range(len(self.buckets)):
+            if self._graphs[k] is not None:
+                self._graphs[k].replay()
+            self.reducer.launch(k)           # RCCL runs on its own stream, ordered after the replay
+        self.reducer.wait_all()              # compute stream waits for every bucket
+        self._graphs[-1].replay()            # global-norm clip + momentum SGD on the averaged gradient

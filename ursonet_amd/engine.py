@@ -147,6 +147,7 @@ class Engine(object):
         VE = 16 // (4 if dt == hip.F32 else 2)
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
+        self.labels = {"prep": [], "fwd": [], "loss": [], "bwd": [], "opt": []}
         self.convs = OrderedDict()
 
         def act(spec, numel=None):
@@ -159,6 +160,7 @@ class Engine(object):
         img_spec = g.tensors[0]
         x0 = act(img_spec, B * self.H * self.W * 4)               # channels padded 3 -> 4, viewed as pixel pairs
         self.fwd_ops.append(lambda: hip.mold_images(B, self.H, self.W, self.in_images, None, dt, x0.data))
+        self.labels["fwd"].append("mold")
 
         max_ws = 0
         max_fin_ws = 0
@@ -168,6 +170,7 @@ class Engine(object):
                 am = torch.empty(dst.numel, dtype=torch.uint8, device=dev)
                 h, w, c = node.src.h, node.src.w, node.src.c
                 self.fwd_ops.append(lambda s=src, d=dst, am=am, h=h, w=w, c=c: hip.maxpool_fwd(B, h, w, c, dt, s.data, d.data, am))
+                self.labels["fwd"].append("maxpool")
                 node._am = am
                 continue
             c = _Conv()
@@ -215,14 +218,17 @@ class Engine(object):
             if node.stem:
                 self.prep_ops.append(lambda c=c: hip.stem_weight_pack(c.N, dt, c.w, c.b, c.gamma, c.beta, c.mean, c.var, BN_EPS,
                                                                       c.wf, c.biasf, c.scale))
+                self.labels["prep"].append("prep:" + node.name)
             else:
                 self.prep_ops.append(lambda c=c, n=node: hip.conv_weight_prep(n.kh if not n.dense else 1, n.kw if not n.dense else 1,
                                                                               n.cin, c.N, c.npad, dt, c.w, c.b, c.gamma, c.beta, c.mean,
                                                                               c.var, BN_EPS, c.wf, c.wd, c.biasf, c.scale))
+                self.labels["prep"].append("prep:" + node.name)
             # -- forward
             flags = (hip.EPI_RELU if node.relu else 0) | (hip.EPI_OUT_F32 if node.out_f32 else 0)
             self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm(c.gf, dt, f, c.src.data, c.wf, c.biasf,
                                                                     c.res.data if c.res is not None else None, None, c.dst.data))
+            self.labels["fwd"].append("fwd:" + node.name)
             if training:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(c.K_raw if not node.stem else 147, c.N))
@@ -244,6 +250,7 @@ class Engine(object):
                 assert dst.grad_written
                 self.bwd_ops.append((None, lambda d=dst, gs=gsrc, am=node._am, h=h, w=w, cc=cc:
                                      hip.maxpool_bwd(B, h, w, cc, dt, d.data, d.grad, am, 1, gs)))
+                self.labels["bwd"].append("maxpool_bwd")
                 src.grad_written = True
                 continue
             c = self.convs[node.name]
@@ -256,11 +263,13 @@ class Engine(object):
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev)
                 self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad(c.gf, dt, c.src.data, G, self.ws, c.dw_raw, c.colsum)))
+                self.labels["bwd"].append("wgrad:" + node.name)
                 dwr = c.dw_raw
                 Kf = c.K_raw
                 if node.stem:
                     c.dw_unp = torch.empty(147 * c.N, dtype=torch.float32, device=dev)
                     self.bwd_ops.append((node.name, lambda c=c: hip.stem_wgrad_unpack(c.N, c.dw_raw, c.dw_unp)))
+                    self.labels["bwd"].append("unpack:" + node.name)
                     dwr, Kf = c.dw_unp, 147
                 gw = self.gview(node.name, "kernel").reshape(-1)
                 gb = self.gview(node.name, "bias").reshape(-1) if node.bias else None
@@ -270,6 +279,7 @@ class Engine(object):
                 self.bwd_ops.append((node.name, lambda c=c, dwr=dwr, Kf=Kf, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr, ldn=ldn:
                                      hip.param_grad_finalize(Kf, c.N, ldn, dwr, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
                                                              float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
+                self.labels["bwd"].append("finalize:" + node.name)
             # -- residual branch: its gradient IS G (Add); fold it into the next dgrad (post-ReLU tensors) or alias it
             if c.res is not None:
                 R = c.res
@@ -287,6 +297,7 @@ class Engine(object):
                 mask = X.data if X.spec.relu else None
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
                                      hip.conv_igemm(c.gd, dt, 0, G, c.wd, None, add, mask, dstg)))
+                self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         # ---------------------------------------------------------------- optimizer
         n = self.n_flat
@@ -296,6 +307,7 @@ class Engine(object):
         self.sq_ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, dtype=torch.float32, device=dev)
         self.opt_ops.append(lambda: hip.sqnorm(n, self.flat_g, self.sq_ws, self.normsq))
         self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
+        self.labels["opt"] += ["sqnorm", "sgd"]
         self.flat_g.zero_()
 
     def _build_heads_io(self):
@@ -376,6 +388,22 @@ class Engine(object):
     def step_eager(self):
         """One training step, launched kernel by kernel (used for capture, profiling and debugging)."""
         self.run_prep(); self.run_forward(); self.run_backward(); self.run_optimizer()
+
+    def profile_step(self):
+        """One eager training step with the library's HIP-event launch profiler on.
+        Returns [(label, kernel_id, ms, flops, bytes)] in launch order."""
+        labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * len(self.loss_ops) + self.labels["bwd"] + self.labels["opt"])
+        torch.cuda.synchronize(self.device)
+        hip.prof_collect()
+        hip.prof_enable(True)
+        try:
+            self.step_eager()
+            torch.cuda.synchronize(self.device)
+            recs = hip.prof_collect()
+        finally:
+            hip.prof_enable(False)
+        assert len(recs) == len(labels), (len(recs), len(labels))
+        return [(l,) + r for l, r in zip(labels, recs)]
 
     def capture(self):
         """Capture the step (training) or prep+forward (inference) into a hipGraph."""
