@@ -1,0 +1,238 @@
+"""CPU tests of the product's host logic (no GPU): Config, graph inventory, pose codec, image
+resizing, cyclic LR, UrsoNet's checkpoint/log-dir plumbing, weight files, the data generator, the
+C-ABI library (loads, exports every symbol of include/ursonet_hip.h, rejects bad arguments), and
+the repository layout rules (the product never touches oracle/)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import make_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "meta.json")))
+
+
+# ------------------------------------------------------------------ Config
+def test_config_defaults_match_reference():
+    from ursonet_amd.config import Config
+    c = Config()
+    for k, v in META["config_defaults"].items():
+        got = getattr(c, k)
+        got = got.tolist() if isinstance(got, np.ndarray) else got
+        assert got == v, (k, got, v)
+
+
+def test_cli_configs_match_reference_update():
+    cases = {"cfg1": ("resnet18", 128, 128, 2), "cfg2": ("resnet50", 512, 640, 32), "cfg4": ("resnet101", 512, 640, 16),
+             "cfg5": ("resnet50", 640, 960, 32)}
+    for name, (bb, h, w, b) in cases.items():
+        c = make_config(bb, h, w, b)
+        ref = META["cli_configs"][name]
+        assert [int(v) for v in c.IMAGE_SHAPE] == ref["IMAGE_SHAPE"] and c.IMAGE_META_SIZE == ref["IMAGE_META_SIZE"]
+        assert c.BATCH_SIZE == ref["BATCH_SIZE"]
+
+
+def test_config_write_to_file(tmp_path):
+    c = make_config()
+    p = str(tmp_path / "sub" / "config_0.json")
+    c.write_to_file(p)
+    d = json.load(open(p))
+    assert d["BACKBONE"] == "resnet50" and "MEAN_PIXEL" not in d and d["LOSS_WEIGHTS"]["ori_loss"] == 1.0
+
+
+# ------------------------------------------------------------------ graph inventory
+@pytest.mark.parametrize("kw", [dict(backbone="resnet18", regress_ori=True), dict(backbone="resnet34"), dict(backbone="resnet50"),
+                                dict(backbone="resnet101", ori_bins=24), dict(backbone="resnet50", regress_loc=False),
+                                dict(backbone="resnet50", regress_ori=True, ori_param="angle_axis")])
+def test_graph_layer_names_and_shapes_equal_oracle_inventory(kw):
+    from oracle import graph_ref as G
+    from ursonet_amd.graph import build_graph, conv_flops
+    cfg = make_config(h=128, w=192, **kw)
+    g = build_graph(cfg)
+    ref = {n: dict(ws) for n, _, ws in G.layer_specs(cfg)}
+    assert {n: dict(ws) for n, ws in g.params.items()} == ref
+    assert conv_flops(g, 3) == G.algorithmic_flops(cfg, 3)
+
+
+def test_graph_rejects_bad_image_size_like_reference():
+    from ursonet_amd.graph import build_graph
+    cfg = make_config(h=100, w=128)
+    with pytest.raises(Exception, match="dividable by 2 at least 6 times"):
+        build_graph(cfg)
+
+
+def test_trainable_presets():
+    from ursonet_amd.graph import build_graph, layer_regex
+    g = build_graph(make_config("resnet50", 64, 64))
+    heads = [n for n in g.params if re.fullmatch(layer_regex("heads"), n)]
+    assert set(heads) == {"bottleneck_layer", "loc_dense_0", "loc_final", "ori_dense_0", "ori_final"}
+    s4 = [n for n in g.params if re.fullmatch(layer_regex("4+"), n)]
+    assert "res4a_branch2a" in s4 and "bn5c_branch2c" in s4 and "res3d_branch2c" not in s4 and "conv1" not in s4
+    assert all(re.fullmatch(layer_regex("all"), n) for n in g.params)
+
+
+# ------------------------------------------------------------------ pose codec (product side) vs golden
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_product_orientation_codec_matches_reference(n):
+    from ursonet_amd import utils
+    g = np.load(os.path.join(GOLD, "ori_codec.npz"))
+    enc, Hq, red = utils.encode_ori(g["oris"], n, META["beta"], np.array(META["min_lim"]), np.array(META["max_lim"]))
+    assert np.array_equal(Hq, g["Hquat_%d" % n]) and np.array_equal(red, g["red_%d" % n])
+    assert np.allclose(enc, g["enc_%d" % n], rtol=1e-6, atol=1e-9)
+    f = utils.encode_ori_fast(g["oris"][2], META["beta"], Hq, red)
+    assert np.allclose(f, g["fast_%d" % n][2], rtol=1e-12, atol=1e-15)
+
+
+def test_product_encode_loc_and_softmax_match_reference():
+    from ursonet_amd import utils
+    g = np.load(os.path.join(GOLD, "loc_codec.npz"))
+    enc, H = utils.encode_loc(g["locs"], 8, META["beta"], g["max_lim"], g["min_lim"])
+    assert np.allclose(H, g["map_8"], atol=1e-12) and np.allclose(enc, g["enc_8"], rtol=1e-5, atol=1e-9)
+    s = np.load(os.path.join(GOLD, "softmax.npz"))
+    assert np.array_equal(utils.stable_softmax(s["x"][2]), s["y"][2])
+
+
+def test_pose_errors_vectorised():
+    from ursonet_amd.pose import pose_errors
+    from oracle import pose_math as P
+    rng = np.random.default_rng(0)
+    q1 = rng.normal(size=(5, 4)); q1 /= np.linalg.norm(q1, axis=1, keepdims=True)
+    q2 = rng.normal(size=(5, 4)); q2 /= np.linalg.norm(q2, axis=1, keepdims=True)
+    t1, t2 = rng.normal(size=(5, 3)), rng.normal(size=(5, 3)) + 10
+    ang, le, esa = pose_errors(t1, q1, t2, q2)
+    for i in range(5):
+        a, l, e = P.pose_errors(t1[i], q1[i], t2[i], q2[i])
+        assert abs(ang[i] - a) < 1e-9 and abs(le[i] - l) < 1e-12 and abs(esa[i] - e) < 1e-9
+
+
+# ------------------------------------------------------------------ resize / clr
+def test_resize_image_geometry_matches_reference():
+    from ursonet_amd import utils
+    for c in META["resize_geometry"]:
+        img = np.zeros((c["h"], c["w"], 3), dtype=np.uint8); img[c["h"] // 2, c["w"] // 2] = 255
+        out, window, scale, padding, crop = utils.resize_image(img, min_dim=c["min_dim"], max_dim=c["max_dim"], min_scale=0, mode=c["mode"])
+        assert list(out.shape) == c["out_shape"] and list(window) == c["window"] and float(scale) == c["scale"]
+        assert [list(p) for p in padding] == c["padding"]
+        assert out[window[0] + c["h"] // 2, window[1] + c["w"] // 2, 0] == 255 and out.dtype == np.uint8
+
+
+def test_clr_triangular_shape():
+    from ursonet_amd.utils import clr_triangular
+    assert clr_triangular(0, 1e-4, 5e-4, 100) == pytest.approx(1e-4)
+    assert clr_triangular(100, 1e-4, 5e-4, 100) == pytest.approx(5e-4)
+    assert clr_triangular(150, 1e-4, 5e-4, 100) == pytest.approx(3e-4)
+    assert clr_triangular(200, 1e-4, 5e-4, 100) == pytest.approx(1e-4)
+
+
+# ------------------------------------------------------------------ UrsoNet host plumbing (no engine)
+def test_ursonet_logdir_checkpoint_and_find_last(tmp_path):
+    from ursonet_amd import net
+    cfg = make_config("resnet18", 64, 64, regress_ori=True)
+    cfg.NAME = "Soyuz"
+    m = net.UrsoNet("training", cfg, str(tmp_path), build_engine=False)
+    assert m.epoch == 0 and os.path.basename(m.log_dir).startswith("soyuz2")
+    assert m.checkpoint_path.endswith("weights_soyuz_{epoch:04d}.h5")
+    assert m.find_last() == (None, None)
+    d = tmp_path / "soyuz20250101T0000"; d.mkdir()
+    (d / "weights_soyuz_0003.npz").write_bytes(b""); (d / "weights_soyuz_0012.npz").write_bytes(b""); (d / "events.x").write_bytes(b"")
+    ddir, ck = m.find_last()
+    assert ck.endswith("weights_soyuz_0012.npz") and ddir == str(d)
+    assert m.get_last_checkpoint("soyuz20250101T0000")[1] == ck
+    m.set_log_dir(ck)
+    assert m.epoch == 12 and m.log_dir == str(d)
+    m.set_log_dir(str(d / "weights_soyuz_0007.h5"))
+    assert m.epoch == 7
+    with pytest.raises(AssertionError):
+        net.UrsoNet("evaluate", cfg, str(tmp_path), build_engine=False)
+    with pytest.raises(IOError):
+        m.get_imagenet_weights("resnet50")
+    layer = m.keras_model.get_layer("stage1_unit1_bn2")
+    assert layer.weights == ["stage1_unit1_bn2/%s:0" % w for w in ("gamma", "beta", "moving_mean", "moving_variance")]
+
+
+def test_weights_file_roundtrip_npz(tmp_path):
+    from ursonet_amd import net
+    from ursonet_amd.engine import initial_weights
+    from ursonet_amd.graph import build_graph
+    W = initial_weights(build_graph(make_config("resnet18", 64, 64, regress_ori=True)), 1, True)
+    written = net.write_weights_file(str(tmp_path / "weights_x_0001.h5"), W)
+    R = net.read_weights_file(written[0])
+    assert list(R) == list(W) and all(np.array_equal(R[l][w], W[l][w]) for l in W for w in W[l])
+    assert R["conv0"]["kernel"].shape == (7, 7, 3, 64) and "bias" not in R["conv0"]
+
+
+def test_data_generator_and_mold_image():
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    cfg = make_config("resnet50", 64, 128, batch=3, regress_ori=False, ori_bins=4)
+    cfg.ROT_AUG = False
+    ds = SyntheticPoses(7, 64, 128, cfg, seed=1)
+    gen = net.data_generator(ds, cfg, shuffle=False, batch_size=3)
+    (imgs, meta, locs, oris), outs = next(gen)
+    assert imgs.shape == (3, 64, 128, 3) and imgs.dtype == np.float32 and meta.shape == (3, cfg.IMAGE_META_SIZE) and outs == []
+    assert locs.shape == (3, 3) and oris.shape == (3, 64) and np.allclose(oris.sum(1), 1, atol=1e-5)
+    raw = ds.load_image(0)
+    assert np.allclose(imgs[0], raw.astype(np.float32) - cfg.MEAN_PIXEL)              # mold_image net.py:1346
+    # unmold_image truncates (astype(uint8), net.py:1355): off by at most one grey level in float32
+    assert np.abs(net.unmold_image(imgs[0], cfg).astype(int) - raw.astype(int)).max() <= 1
+    img, m, loc, ori = net.load_image_gt(ds, cfg, 2)
+    assert m[0] == 2 and tuple(m[1:4]) == (64, 128, 3) and tuple(m[7:11]) == (0, 0, 64, 128)
+    cfg.ROT_AUG = True
+    with pytest.raises(NotImplementedError):
+        net.load_image_gt(ds, cfg, 0)
+
+
+# ------------------------------------------------------------------ C ABI
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "ursonet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(urso_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ursonet_amd.hip as hip
+    syms = _header_symbols()
+    assert len(syms) >= 24
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "symbol %s declared in include/ursonet_hip.h is not exported" % s
+    assert set(syms) == set(hip.EXPORTED_SYMBOLS), set(syms) ^ set(hip.EXPORTED_SYMBOLS)
+    assert hip._lib.urso_abi_version() == 1
+
+
+def test_cabi_argument_validation_without_gpu():
+    import ursonet_amd.hip as hip
+    g = hip.geom(2, 8, 8, 12, 8, 8, 16, 3, 3, 1, 1, 1, 1)                 # C=12 is not a 16-byte multiple in bf16
+    rc = hip._lib.urso_conv_igemm(ctypes.byref(g), hip.BF16, 0, 1, 1, None, None, None, 1, None)
+    assert rc == -1 and "multiple of 8" in hip.last_error()
+    rc = hip._lib.urso_conv_igemm(ctypes.byref(g), hip.BF16, 0, None, None, None, None, None, None, None)
+    assert rc == -1 and "null" in hip.last_error()
+    g2 = hip.geom(32, 128, 160, 64, 128, 160, 256, 1, 1)
+    ws = hip.conv_wgrad_ws_bytes(g2, hip.BF16)
+    assert ws >= 64 * 256 * 4 and ws < (1 << 31)
+    assert hip.param_grad_finalize_ws_bytes(4608, 512) > 0 and hip.sqnorm_ws_bytes(10 ** 6) >= 4
+    assert hip._lib.urso_sgd_momentum_clip(16, None, None, None, None, None, None) == -1
+
+
+# ------------------------------------------------------------------ layout rules
+def test_product_never_imports_the_oracle_or_reference():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ursonet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, "product files reference oracle/ or /root/reference: %s" % bad
+
+
+def test_bench_uses_oracle_only_in_cpu_baseline():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle", src)]
+    i0 = src.index("def cpu_baseline"); i1 = src.index("def main")
+    assert uses and all(i0 < u < i1 for u in uses)

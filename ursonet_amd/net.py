@@ -1,0 +1,444 @@
+"""Drop-in for the reference's `net.py` model API (class UrsoNet, net.py:566-1308) on MI355X.
+
+`pose_estimator.py` programs against: UrsoNet(mode, config, model_dir), .train(), .detect(),
+.load_weights(), .find_last(), .get_last_checkpoint(), .get_imagenet_weights(), .get_urso_weights(),
+.compile(), .set_trainable(), attributes .config .epoch .log_dir .checkpoint_path .keras_model, and
+the module functions load_image_gt / data_generator / mold_image / compose_image_meta.  All of that
+is provided here with the same names, argument meaning and error behaviour; the numeric work is
+done by ursonet_amd.engine.Engine (HIP kernels through the C ABI) -- there is no Keras/TF and no
+CPU fallback: building a model without an MI355X raises.
+
+Weights files: Keras HDF5 (`.h5`, by-name, nested `model_weights` groups handled) when h5py is
+importable; always a `.npz` twin with the same layer/weight names and layouts
+("<layer>/<weight>" keys), which is what this container (no h5py) reads and writes.
+"""
+import datetime
+import logging
+import os
+import re
+from collections import OrderedDict
+
+import numpy as np
+
+from . import utils
+from .graph import build_graph, layer_regex as _layer_regex
+
+
+def log(text, array=None):
+    """net.py:46-57."""
+    if array is not None:
+        text = text.ljust(25)
+        text += ("shape: {:20}  min: {:10.5f}  max: {:10.5f}  {}".format(
+            str(array.shape), array.min() if array.size else "", array.max() if array.size else "", array.dtype))
+    print(text)
+
+
+############################################################
+#  Keras-model shim: layer names / weights / trainable flags
+############################################################
+class _Layer(object):
+    def __init__(self, model, name, kind, weight_names):
+        self._model, self.name, self.kind = model, name, kind
+        self.weight_names = list(weight_names)
+        self.trainable = True
+
+    @property
+    def weights(self):
+        return ["%s/%s:0" % (self.name, w) for w in self.weight_names]
+
+    def get_weights(self):
+        eng = self._model._engine
+        return [eng.wview(self.name, w).detach().cpu().numpy().copy() for w in self.weight_names]
+
+    def set_weights(self, arrays):
+        self._model._engine.set_weights({self.name: dict(zip(self.weight_names, arrays))}, strict=False)
+
+
+class KerasModelShim(object):
+    """What net.py touches on `keras_model`: .layers, .get_layer(name), .predict(), weight access."""
+
+    def __init__(self, owner, graph):
+        self._owner = owner
+        self.name = "urso_net"
+        self.layers = [_Layer(self, n, graph.kinds[n], ws.keys()) for n, ws in graph.params.items()]
+        self._by_name = {l.name: l for l in self.layers}
+        self.metrics_names = ["loss", "loc_loss", "ori_loss"]
+
+    @property
+    def _engine(self):
+        return self._owner._engine
+
+    def get_layer(self, name):
+        return self._by_name[name]
+
+    def predict(self, molded_images, verbose=0):
+        return self._owner._predict(np.asarray(molded_images))
+
+
+############################################################
+#  Data formatting (net.py:1314-1355)
+############################################################
+def compose_image_meta(image_id, original_image_shape, image_shape, window, scale):
+    return np.array([image_id] + list(original_image_shape) + list(image_shape) + list(window) + [scale])
+
+
+def mold_image(image, config):
+    dt = np.float16 if config.F16 else np.float32
+    if image.shape[-1] == 3:
+        return image.astype(dt) - config.MEAN_PIXEL
+    return image.astype(dt) - np.mean(config.MEAN_PIXEL)
+
+
+def unmold_image(normalized_images, config):
+    return (normalized_images + config.MEAN_PIXEL).astype(np.uint8)
+
+
+############################################################
+#  Data generator (net.py:358-559)
+############################################################
+def load_image_gt(dataset, config, image_id):
+    """Image + pose targets for one sample.  The rotation / sim2real augmentations of the reference
+    (cv2 / imgaug, net.py:390-438) are not implemented yet: asking for them raises instead of
+    silently training on un-augmented data."""
+    image = dataset.load_image(image_id)
+    loc = dataset.load_location(image_id) if config.REGRESS_LOC else dataset.load_location_encoded(image_id)
+    if config.REGRESS_KEYPOINTS:
+        keypoints = dataset.load_keypoints(image_id)
+        k1, k2 = keypoints[0], keypoints[1]
+    if config.REGRESS_KEYPOINTS or config.REGRESS_ORI:
+        if config.ORIENTATION_PARAM == 'quaternion':
+            ori = dataset.load_quaternion(image_id)
+        elif config.ORIENTATION_PARAM == 'euler_angles':
+            ori = dataset.load_euler_angles(image_id)
+        elif config.ORIENTATION_PARAM == 'angle_axis':
+            ori = dataset.load_angle_axis(image_id)
+    else:
+        ori = dataset.load_orientation_encoded(image_id)
+    if config.SIM2REAL_AUG or config.ROT_AUG or config.ROT_IMAGE_AUG:
+        raise NotImplementedError("SIM2REAL_AUG / ROT_AUG / ROT_IMAGE_AUG are not implemented in this build "
+                                  "(GPU-resident augmentation is the next scope row)")
+    original_shape = image.shape
+    image, window, scale, padding, crop = utils.resize_image(
+        image, min_dim=config.IMAGE_MIN_DIM, min_scale=config.IMAGE_MIN_SCALE, max_dim=config.IMAGE_MAX_DIM,
+        mode=config.IMAGE_RESIZE_MODE)
+    image_meta = compose_image_meta(image_id, original_shape, image.shape, window, scale)
+    if config.REGRESS_KEYPOINTS:
+        return image, image_meta, loc, k1.T, k2.T
+    return image, image_meta, loc, ori
+
+
+def data_generator(dataset, config, shuffle=True, batch_size=1):
+    """Yields ([images, image_meta, gt_locs, gt_oris], []) forever; tolerates <= 5 bad samples."""
+    b, image_index, error_count = 0, -1, 0
+    image_ids = np.copy(dataset.image_ids)
+    dt = np.float16 if config.F16 else np.float32
+    while True:
+        try:
+            image_index = (image_index + 1) % len(image_ids)
+            if shuffle and image_index == 0:
+                np.random.shuffle(image_ids)
+            image_id = image_ids[image_index]
+            if config.REGRESS_KEYPOINTS:
+                image, image_meta, gt_loc, gt_k1, gt_k2 = load_image_gt(dataset, config, image_id)
+            else:
+                image, image_meta, gt_loc, gt_ori = load_image_gt(dataset, config, image_id)
+            if b == 0:
+                batch_image_meta = np.zeros((batch_size,) + image_meta.shape, dtype=image_meta.dtype)
+                batch_images = np.zeros((batch_size,) + image.shape, dtype=dt)
+                batch_gt_locs = np.zeros((batch_size, 3 if config.REGRESS_LOC else config.LOC_BINS_PER_DIM ** 3), dtype=dt)
+                if config.REGRESS_KEYPOINTS:
+                    batch_gt_k1 = np.zeros((batch_size, 3), dtype=dt)
+                    batch_gt_k2 = np.zeros((batch_size, 3), dtype=dt)
+                elif config.REGRESS_ORI:
+                    batch_gt_oris = np.zeros((batch_size, 4 if config.ORIENTATION_PARAM == 'quaternion' else 3), dtype=dt)
+                else:
+                    batch_gt_oris = np.zeros((batch_size, config.ORI_BINS_PER_DIM ** 3), dtype=dt)
+            batch_image_meta[b] = image_meta
+            batch_images[b] = mold_image(image.astype(dt), config)
+            batch_gt_locs[b] = gt_loc
+            if config.REGRESS_KEYPOINTS:
+                batch_gt_k1[b], batch_gt_k2[b] = gt_k1, gt_k2
+            else:
+                batch_gt_oris[b] = gt_ori
+            b += 1
+            if b >= batch_size:
+                if config.REGRESS_KEYPOINTS:
+                    yield [batch_images, batch_image_meta, batch_gt_locs, batch_gt_k1, batch_gt_k2], []
+                else:
+                    yield [batch_images, batch_image_meta, batch_gt_locs, batch_gt_oris], []
+                b = 0
+        except (GeneratorExit, KeyboardInterrupt):
+            raise
+        except Exception:
+            logging.exception("Error processing image {}".format(dataset.image_info[image_id]))
+            error_count += 1
+            if error_count > 5:
+                raise
+
+
+############################################################
+#  Weight files
+############################################################
+def read_weights_file(path):
+    """-> {layer: {weight: array}} from a Keras HDF5 file (h5py needed) or an .npz twin."""
+    if path.endswith(".npz"):
+        out = OrderedDict()
+        with np.load(path) as z:
+            for k in z.files:
+                ln, wn = k.rsplit("/", 1)
+                out.setdefault(ln, OrderedDict())[wn] = z[k]
+        return out
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("`load_weights` of a Keras .h5 file requires h5py (absent here); use the .npz twin")
+    out = OrderedDict()
+    with h5py.File(path, mode='r') as f:
+        if 'layer_names' not in f.attrs and 'model_weights' in f:          # net.py:831-832
+            f = f['model_weights']
+        for ln in [n.decode('utf8') if isinstance(n, bytes) else n for n in f.attrs['layer_names']]:
+            grp = f[ln]
+            names = [n.decode('utf8') if isinstance(n, bytes) else n for n in grp.attrs['weight_names']]
+            for wn in names:
+                short = wn.split("/")[-1].split(":")[0]
+                out.setdefault(ln, OrderedDict())[short] = np.asarray(grp[wn])
+    return out
+
+
+def write_weights_file(path, params):
+    """Always writes `<path without ext>.npz`; additionally a Keras-layout .h5 when h5py exists."""
+    base = path[:-3] if path.endswith(".h5") else (path[:-4] if path.endswith(".npz") else path)
+    flat = {"%s/%s" % (ln, wn): a for ln, ws in params.items() for wn, a in ws.items()}
+    np.savez(base + ".npz", **flat)
+    written = [base + ".npz"]
+    if path.endswith(".h5"):
+        try:
+            import h5py
+        except ImportError:
+            return written
+        with h5py.File(path, "w") as f:
+            f.attrs['layer_names'] = [ln.encode('utf8') for ln in params]
+            f.attrs['backend'] = b'tensorflow'
+            f.attrs['keras_version'] = b'2.2.4'
+            for ln, ws in params.items():
+                g = f.create_group(ln)
+                names = ["%s/%s:0" % (ln, wn) for wn in ws]
+                g.attrs['weight_names'] = [n.encode('utf8') for n in names]
+                for n, a in zip(names, ws.values()):
+                    g.create_dataset(n, data=a)
+        written.append(path)
+    return written
+
+
+class BatchLogger(object):
+    """net.py:1106-1115 -- per-batch loss history returned by train()."""
+
+    def __init__(self):
+        self.ori_loss_acc, self.loc_loss_acc = [], []
+
+
+############################################################
+#  UrsoNet
+############################################################
+class UrsoNet(object):
+    def __init__(self, mode, config, model_dir, build_engine=True):
+        assert mode in ['training', 'inference']
+        self.mode, self.config, self.model_dir = mode, config, model_dir
+        self.set_log_dir()
+        self._engine = None
+        self._layer_regex = ".*"
+        self.keras_model = self.build(mode=mode, config=config, build_engine=build_engine)
+
+    def build(self, mode, config, build_engine=True):
+        """net.py:581-699.  Validates the config exactly like the reference (image divisibility
+        exception, FC-layer count assert) and lowers the graph onto the GPU engine."""
+        assert mode in ['training', 'inference']
+        graph = build_graph(config)                   # raises the 'dividable by 2 at least 6 times' Exception
+        self._graph = graph
+        if build_engine:
+            from .engine import Engine
+            self._engine = Engine(config, mode)
+        return KerasModelShim(self, graph)
+
+    # ---------------------------------------------------------------- checkpoints / log dirs
+    def get_last_checkpoint(self, model_name):
+        """net.py:768-788."""
+        dir_names = next(os.walk(self.model_dir))[1]
+        assert model_name in dir_names
+        model_path = os.path.join(self.model_dir, model_name)
+        checkpoints = sorted(f for f in next(os.walk(model_path))[2] if f.startswith("weights"))
+        if not checkpoints:
+            return model_path, None
+        return model_path, os.path.join(model_path, checkpoints[-1])
+
+    def find_last(self):
+        """net.py:791-814."""
+        dir_names = next(os.walk(self.model_dir))[1]
+        key = self.config.NAME.lower()
+        dir_names = sorted(f for f in dir_names if f.startswith(key))
+        if not dir_names:
+            return None, None
+        dir_name = os.path.join(self.model_dir, dir_names[-1])
+        checkpoints = sorted(f for f in next(os.walk(dir_name))[2] if f.startswith("weights"))
+        if not checkpoints:
+            return dir_name, None
+        return dir_name, os.path.join(dir_name, checkpoints[-1])
+
+    def load_weights(self, weights_in_path, weights_out_path, by_name=False, exclude=None):
+        """net.py:816-852: load by name (layers absent from the file keep their values), optional
+        exclude list; then point the log dir at weights_out_path."""
+        if exclude:
+            by_name = True
+        params = read_weights_file(weights_in_path)
+        if exclude:
+            params = OrderedDict((k, v) for k, v in params.items() if k not in exclude)
+        if not by_name:
+            missing = [ln for ln in self._graph.params if ln not in params]
+            if missing:
+                raise ValueError("weights file lacks layers %s (use by_name=True)" % missing[:5])
+        known = OrderedDict((ln, ws) for ln, ws in params.items() if ln in self._graph.params)
+        self._engine.set_weights(known, strict=False)
+        self.set_log_dir(weights_out_path)
+
+    def save_weights(self, path):
+        return write_weights_file(path, self._engine.get_weights())
+
+    def get_imagenet_weights(self, architecture):
+        """net.py:854-884 downloads from GitHub; there is no network here."""
+        raise IOError("get_imagenet_weights(%r): pre-trained weights must be provided locally (no network access); "
+                      "pass the path of a .h5/.npz file to --weights" % (architecture,))
+
+    def get_urso_weights(self, dataset_name):
+        """net.py:886-940."""
+        assert dataset_name in ['soyuz_hard', 'dragon_hard', 'speed']
+        raise IOError("get_urso_weights(%r): released weights must be provided locally (no network access)" % (dataset_name,))
+
+    def set_log_dir(self, model_path=None):
+        """net.py:944-967."""
+        if model_path:
+            self.log_dir = os.path.dirname(model_path)
+            m = re.search(r"(\d{3,4})\.(h5|npz)$", model_path)
+            self.epoch = int(m.group(1)[-3:]) if m else int(model_path[-6:-3])
+        else:
+            self.epoch = 0
+            now = datetime.datetime.now()
+            self.log_dir = os.path.join(self.model_dir, "{}{:%Y%m%dT%H%M}".format(self.config.NAME.lower(), now))
+        self.checkpoint_path = os.path.join(self.log_dir, "weights_{}_*epoch*.h5".format(self.config.NAME.lower()))
+        self.checkpoint_path = self.checkpoint_path.replace("*epoch*", "{epoch:04d}")
+
+    # ---------------------------------------------------------------- training
+    def compile(self, learning_rate, momentum):
+        """net.py:973-1028: (re)creates the optimizer state (momentum buffers reset, as a new Keras
+        optimizer would), sets lr/momentum/clipnorm.  Loss assembly and the L2 term live in the engine."""
+        if self.config.OPTIMIZER != 'SGD':
+            raise NotImplementedError("only OPTIMIZER='SGD' (the CLI's hard-coded choice, pose_estimator.py:830)")
+        eng = self._engine
+        eng.hyper[0] = float(learning_rate)
+        eng.hyper[1] = float(momentum)
+        eng.hyper[2] = float(self.config.GRADIENT_CLIP_NORM or 0.0)
+        eng.reset_optimizer()
+
+    def set_trainable(self, layer_regex, keras_model=None, indent=0, verbose=1):
+        """net.py:1030-1066."""
+        if verbose > 0 and keras_model is None:
+            log("Selecting layers to train")
+        self._layer_regex = layer_regex
+        for layer in self.keras_model.layers:
+            layer.trainable = bool(re.fullmatch(layer_regex, layer.name))
+            if layer.trainable and verbose > 0:
+                log("{}{:20}   ({})".format(" " * indent, layer.name, layer.kind))
+        self._engine.set_trainable(layer_regex)
+
+    def train(self, train_dataset, val_dataset, learning_rate, epochs, layers):
+        """net.py:1068-1167: STEPS_PER_EPOCH steps per epoch, VALIDATION_STEPS forward-only validation
+        batches, a weights checkpoint per epoch, optional CyclicLR; returns the per-batch loss logger."""
+        assert self.mode == "training", "Create model in training mode."
+        layers = _layer_regex(layers)
+        cfg, eng = self.config, self._engine
+        train_generator = data_generator(train_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
+        val_generator = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
+        history_full = BatchLogger()
+        log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
+        log("Checkpoint Path: {}".format(self.checkpoint_path))
+        self.set_trainable(layers)
+        self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
+        os.makedirs(self.log_dir, exist_ok=True)
+        clr_it = 0
+        for epoch in range(self.epoch, epochs):
+            for _ in range(int(cfg.STEPS_PER_EPOCH)):
+                inputs, _o = next(train_generator)
+                if cfg.CLR:
+                    eng.set_lr(utils.clr_triangular(clr_it, cfg.BASE_LEARNING_RATE, cfg.MAX_LEARNING_RATE, cfg.CLR_STEP_SIZE))
+                    clr_it += 1
+                eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
+                eng.step()
+                ls = eng.losses()
+                history_full.ori_loss_acc.append(ls["ori_loss"])
+                history_full.loc_loss_acc.append(ls["loc_loss"])
+            val = {"loc_loss": [], "ori_loss": []}
+            for _ in range(int(cfg.VALIDATION_STEPS)):
+                inputs, _o = next(val_generator)
+                eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
+                eng.run_prep(); eng.run_forward()
+                for op in eng.loss_ops:
+                    op()
+                for k, v in eng.losses().items():
+                    val[k].append(v)
+            log("epoch %d  loc_loss %.5f ori_loss %.5f  val_loc_loss %.5f val_ori_loss %.5f" % (
+                epoch + 1, float(np.mean(history_full.loc_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
+                float(np.mean(history_full.ori_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
+                float(np.mean(val["loc_loss"])) if val["loc_loss"] else float("nan"),
+                float(np.mean(val["ori_loss"])) if val["ori_loss"] else float("nan")))
+            self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))
+        self.epoch = max(self.epoch, epochs)
+        return history_full
+
+    # ---------------------------------------------------------------- inference
+    def mold_inputs(self, images):
+        """net.py:1169-1205."""
+        molded_images, image_metas, windows = [], [], []
+        for image in images:
+            molded_image, window, scale, padding, crop = utils.resize_image(
+                image, min_dim=self.config.IMAGE_MIN_DIM, min_scale=self.config.IMAGE_MIN_SCALE,
+                max_dim=self.config.IMAGE_MAX_DIM, mode=self.config.IMAGE_RESIZE_MODE)
+            molded_image = mold_image(molded_image, self.config)
+            image_metas.append(compose_image_meta(0, image.shape, molded_image.shape, window, scale))
+            molded_images.append(molded_image)
+            windows.append(window)
+        return np.stack(molded_images), np.stack(image_metas), np.stack(windows)
+
+    def _predict(self, molded_images):
+        import torch
+        eng = self._engine
+        assert molded_images.shape[0] == eng.B, "batch %d != engine batch %d" % (molded_images.shape[0], eng.B)
+        eng.load_batch(molded_images.astype(np.float32))
+        eng.forward()
+        loc, ori = eng.outputs()
+        torch.cuda.synchronize()
+        if self.config.REGRESS_KEYPOINTS:
+            g = self._graph
+            ks = [eng.acts[g.outputs[k].id].data.view(eng.B, -1)[:, :3].cpu().numpy() for k in ("k1", "k2", "k3")]
+            return ks
+        return [loc.cpu().numpy(), ori.cpu().numpy()]
+
+    def detect(self, images, verbose=0):
+        """net.py:1207-1259: list of {'loc', 'ori'} (or {'loc','k1','k2'}) dicts with the RAW network outputs."""
+        assert self.mode == "inference", "Create model in inference mode."
+        assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
+        if verbose:
+            log("Processing {} images".format(len(images)))
+            for image in images:
+                log("image", image)
+        molded_images, image_metas, windows = self.mold_inputs(images)
+        image_shape = molded_images[0].shape
+        for g in molded_images[1:]:
+            assert g.shape == image_shape, \
+                "After resizing, all images must have the same size. Check IMAGE_RESIZE_MODE and image sizes."
+        if verbose:
+            log("molded_images", molded_images)
+            log("image_metas", image_metas)
+        if self.config.REGRESS_KEYPOINTS:
+            loc_pred, k1_pred, k2_pred = self.keras_model.predict(molded_images, verbose=0)
+            return [{"loc": loc_pred[i], "k1": k1_pred[i], "k2": k2_pred[i]} for i in range(len(images))]
+        loc_pred, ori_pred = self.keras_model.predict(molded_images, verbose=0)
+        return [{"loc": loc_pred[i], "ori": ori_pred[i]} for i in range(len(images))]

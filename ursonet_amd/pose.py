@@ -37,7 +37,15 @@ class OrientationCodec(object):
         grid = np.asarray(list(itertools.product(bins, repeat=3)))          # same enumeration as the reference
         H_ori = grid * (max_lim - min_lim) + min_lim
         self.H_ori = H_ori
-        self.H_quat = euler2quat(H_ori[:, 0], H_ori[:, 1], H_ori[:, 2]).astype(np.float32)
+        # cos/sin through NumPy's SCALAR path per distinct angle (as the reference's per-bin euler2quat
+        # calls do): the vectorised SIMD path can differ by 1 ulp, and the map must be bit-identical.
+        def trig(col):
+            vals = {float(v): (np.cos(float(v) * np.pi / 360), np.sin(float(v) * np.pi / 360)) for v in np.unique(col)}
+            c = np.array([vals[float(v)][0] for v in col]); s_ = np.array([vals[float(v)][1] for v in col])
+            return c, s_
+        (cp, sp), (cy, sy), (cr, sr) = trig(H_ori[:, 0]), trig(H_ori[:, 1]), trig(H_ori[:, 2])
+        self.H_quat = np.stack([sy * sr * cp - cy * cr * sp, -sy * cr * cp - cy * sr * sp,
+                                -cy * sr * cp + sy * cr * sp, cy * cr * cp + sy * sr * sp], axis=-1).astype(np.float32)
         boundary = np.logical_or(H_ori[:, 0] == max_lim[0], H_ori[:, 2] == max_lim[2])
         gymbal = np.logical_and(np.abs(H_ori[:, 1]) == max_lim[1], H_ori[:, 0] != min_lim[0])
         self.redundant = np.logical_or(boundary, gymbal)
