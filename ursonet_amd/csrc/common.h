@@ -94,6 +94,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 __device__ __forceinline__ i32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
 }
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, i32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);      // out-of-range lanes are dropped
+}
+
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the vector-memory
+// counter (vmcnt(0)): every outstanding global load/store of the wave would have to complete, which
+// serialises an epilogue's stores and kills cross-tile prefetching.  Use only where the data exchanged
+// between waves lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

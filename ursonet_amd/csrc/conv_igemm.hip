@@ -11,193 +11,234 @@
 // of k per row (64 bf16 / 32 fp32), LDS double-buffered, global->register prefetch of the
 // next K-tile while the MFMAs of the current one run, one barrier per K-tile.
 #include "common.h"
+#include <stdlib.h>
 
 struct IgemmArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
-    uint32_t src_bytes, wgt_bytes;
+    uint32_t src_bytes, wgt_bytes, dst_bytes;
     int B, H, W, C, OH, OW, N, KH, KW, SH, SW, PH, PW, DHs, DWs;   // DHs/DWs = log2(D)
     int M;          // B*OH*OW
     int Cc;         // chunks (16 B) per filter tap = C / VE
     int Kc;         // total chunks = KH*KW*Cc
     int nkt;        // K tiles = ceil(Kc / 8)
-    int tilesN, nblk;
+    int tilesN, ntiles;
+    int pointwise;  // 1x1, stride 1, no padding: source pixel index == destination pixel index
     int flags;
 };
 
-template <typename T, int BM, int BN>
+// Persistent, software-pipelined tile stream: the grid is 8*bpx blocks (2-3 per CU, all resident);
+// XCD x (= blockIdx % 8) owns a contiguous range of output tiles and its bpx blocks walk it with
+// stride bpx.  Inside a block the (tile, K-tile) pairs form ONE stream: the global loads of the next
+// K-tile -- or of the NEXT TILE's first K-tile -- are issued before the MFMAs of the current one and
+// stay in flight during the epilogue, so short-K (HBM-bound) layers never expose their load latency.
+template <typename T, int BM, int BN, bool HAS_ADD, bool HAS_MASK>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int VE = Elem<T>::VE;
     constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
     constexpr int TM = WM / 16, TN = WN / 16;        // 16x16 sub-tiles per wave
     constexpr int RA = BM / 32, RB = BN / 32;        // 16-B chunks staged per thread per K-tile
-    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
-    auto sA = [&](int buf) -> char* { return smem + buf * (BM + BN) * 128; };              // pixel tiles  [BM][128 B]
-    auto sB = [&](int buf) -> char* { return smem + buf * (BM + BN) * 128 + BM * 128; };   // weight tiles [BN][128 B]
+    constexpr int BUF = (BM + BN) * 128;             // bytes of one LDS buffer (pixel tile + weight tile)
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    auto sA = [&](int buf) -> char* { return smem + buf * BUF; };              // pixel tiles  [BM][128 B]
+    auto sB = [&](int buf) -> char* { return smem + buf * BUF + BM * 128; };   // weight tiles [BN][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int bid = xcd_remap(blockIdx.x, a.nblk);
-    const int tile_n = bid % a.tilesN, tile_m = bid / a.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
 
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.src, a.src_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wgt, a.wgt_bytes);
+    // epilogue descriptors: an absent tensor gets num_records = 0, i.e. every load returns 0
+    const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
 
-    // ---- staging bookkeeping: this thread owns chunk column c8 of rows r0 + 32*i
-    const int c8 = tid & 7, r0 = tid >> 3;
+    // ---- fetch-side state (belongs to the tile whose K-tiles are being loaded)
+    const int c8 = tid & 7, r0 = tid >> 3;             // this thread stages chunk column c8 of rows r0 + 32*i
     int ty0[RA], tx0[RA], pb[RA];
-    const int ohw = a.OH * a.OW;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        int m = m0 + r0 + 32 * i;
-        if (m < a.M) {
-            int b = m / ohw, rem = m - b * ohw;
-            int oy = rem / a.OW, ox = rem - oy * a.OW;
-            ty0[i] = oy * a.SH - a.PH; tx0[i] = ox * a.SW - a.PW; pb[i] = b * a.H * a.W;
-        } else { ty0[i] = -(1 << 24); tx0[i] = 0; pb[i] = 0; }
-    }
     uint32_t wrow[RB];
+    const int ohw = a.OH * a.OW;
+    const bool fast_tap = (a.Cc & 7) == 0;             // a K-tile never straddles filter taps
+    int ft_cc = 0, ft_ky = 0, ft_kx = 0;               // running (chunk-in-tap, ky, kx) of the next K-tile (fast path)
+    auto setup_fetch = [&](int t) {
+        const int m0f = (t / a.tilesN) * BM, n0f = (t % a.tilesN) * BN;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        int n = n0 + r0 + 32 * i;
-        wrow[i] = (n < a.N) ? (uint32_t)n * (uint32_t)a.Kc * 16u : URSO_OOB_SHIFT;
-    }
-    const bool fast_tap = (a.Cc & 7) == 0;     // a K-tile never straddles filter taps
-    int ft_cc = 0, ft_ky = 0, ft_kx = 0;       // running (chunk-in-tap, ky, kx) of the NEXT tile to fetch (fast path)
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0f + r0 + 32 * i;
+            if (m >= a.M) { ty0[i] = -(1 << 24); tx0[i] = 0; pb[i] = 0; }
+            else if (a.pointwise) { ty0[i] = 0; tx0[i] = 0; pb[i] = m; }
+            else {
+                int b = m / ohw, rem = m - b * ohw;
+                int oy = rem / a.OW, ox = rem - oy * a.OW;
+                ty0[i] = oy * a.SH - a.PH; tx0[i] = ox * a.SW - a.PW; pb[i] = b * a.H * a.W;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0f + r0 + 32 * i;
+            wrow[i] = (n < a.N) ? (uint32_t)n * (uint32_t)a.Kc * 16u : URSO_OOB_SHIFT;
+        }
+        ft_cc = 0; ft_ky = 0; ft_kx = 0;
+    };
 
     i32x4_t ra[RA], rb[RB];
     auto fetch = [&](int kt) {
         int kc = kt * 8 + c8, ky, kx, cc;
-        bool kvalid = kc < a.Kc;
+        const bool kvalid = kc < a.Kc;
         if (fast_tap) { ky = ft_ky; kx = ft_kx; cc = ft_cc + c8;
             ft_cc += 8; if (ft_cc >= a.Cc) { ft_cc = 0; if (++ft_kx == a.KW) { ft_kx = 0; ++ft_ky; } }
         } else { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
         const int dmh = (1 << a.DHs) - 1, dmw = (1 << a.DWs) - 1;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int ty = ty0[i] + ky, tx = tx0[i] + kx;
-            int iy = ty >> a.DHs, ix = tx >> a.DWs;
-            bool ok = kvalid && ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
-            uint32_t off = (uint32_t)((pb[i] + iy * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
+            const int ty = ty0[i] + ky, tx = tx0[i] + kx;
+            const int iy = ty >> a.DHs, ix = tx >> a.DWs;
+            const bool ok = kvalid && ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
+            const uint32_t off = (uint32_t)((pb[i] + iy * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
             ra[i] = buf_load16(rs, ok ? off : URSO_OOB_SHIFT);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             rb[i] = buf_load16(rw, kvalid ? wrow[i] + (uint32_t)kc * 16u : URSO_OOB_SHIFT);
     };
+    // Weight rows are PERMUTED inside each wave's WN-row block on their way into LDS so that an MFMA lane
+    // (fg = lane>>4, D rows 4*fg..4*fg+3 of every sub-tile j) owns whole 16-byte output vectors: vector v of the
+    // lane covers channels v*4*VE + fg*VE .. +VE-1 (sub-tiles j = v*JPV .. v*JPV+JPV-1, JPV = VE/4), i.e. the four
+    // lanes of a pixel write 4*VE contiguous channels (64 B) per store instruction and the epilogue needs no LDS.
+    // Channel (within the wave block) v*4*VE + q*VE + jj*4 + t  <->  LDS row j*16 + q*4 + t,  j = v*JPV + jj.
+    constexpr int CH = TN * 4;          // channels per lane
+    constexpr int JPV = VE / 4;         // sub-tiles per 16-byte vector
+    auto wperm = [&](int n_local) -> int {
+        const int w = n_local / WN, nw = n_local % WN;
+        const int v = nw / (4 * VE), q = (nw % (4 * VE)) / VE, jj = (nw % VE) >> 2, t = nw & 3;
+        return w * WN + (v * JPV + jj) * 16 + q * 4 + t;
+    };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) *(i32x4_t*)(sA(buf) + lds_off(r0 + 32 * i, c8)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *(i32x4_t*)(sB(buf) + lds_off(r0 + 32 * i, c8)) = rb[i];
+        for (int i = 0; i < RB; ++i) *(i32x4_t*)(sB(buf) + lds_off(wperm(r0 + 32 * i), c8)) = rb[i];
     };
 
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < a.nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < a.nkt) fetch(kt + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            i32x4_t fa[TN], fb[TM];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, ks * 4 + fg));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, ks * 4 + fg));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[j], fb[i], acc[i][j]);
-        }
-        if (kt + 1 < a.nkt) stage(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue
     const bool relu = a.flags & URSO_EPI_RELU, outf32 = a.flags & URSO_EPI_OUT_F32;
     const bool nvec = (a.N & 3) == 0;
-    if (!outf32 && (a.N % VE) == 0) {
-        // Coalesced path: the fp32 accumulators of one 64-pixel half of the tile are staged in LDS
-        // ([64][BN+4] floats, conflict-free for both the per-lane 16-B writes and the row reads), then
-        // every thread finishes 16-byte vectors of ONE pixel row: bias + residual + ReLU + mask + cast
-        // with 16-byte global loads/stores that cover whole 256-byte row segments per 16 lanes.
-        constexpr int LROW = BN + 4;
-        constexpr int VPR = BN / VE;                 // 16-byte output vectors per tile row
-        constexpr int EIT = 64 * VPR / 256;          // vectors per thread per half
-        float* stile = (float*)smem;
+    const bool coalesced = !outf32 && (a.N % VE) == 0;
+
+    setup_fetch(tile);
+    fetch(0);
+    stage(0);
+    lds_barrier();
+    int cur = 0;
+    while (true) {
+        const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+        const int next = tile + bpx;
+        const bool has_next = next < t_end;
+        f32x4_t acc[TM][TN];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            if (wm == pass) {
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        // ---- epilogue state of this tile.  vmcnt is an IN-ORDER counter (waiting for a load also waits for every
+        // older load/store), so the epilogue's loads are issued EARLY and branch-free (buffer ops, OOB offset =
+        // lane off): bias at tile start, the residual/mask vectors before the MFMAs of the last K-tile (behind the
+        // next tile's fetch); the epilogue loop itself only computes and stores.
+        constexpr int NV = CH / VE;                  // 16-byte vectors per lane per pixel
+        static_assert(CH % VE == 0, "lane channel run must be whole vectors");
+        const int nb = n0 + wn * WN + fg * VE;       // first channel of this lane's vector 0 (vector v: + v*4*VE)
+        i32x4_t rbias[CH / 4];
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {       // bias of sub-tile q's four channels
+            const int nq = nb + (q / JPV) * 4 * VE + (q % JPV) * 4;
+            rbias[q] = buf_load16(rbi, (coalesced && nq < a.N) ? (uint32_t)nq * 4u : URSO_OOB_SHIFT);
+        }
+        constexpr int NBATCH = (HAS_ADD && HAS_MASK) ? 2 : 1;     // two load batches when both tensors are present
+        constexpr int IPB = TM / NBATCH;                           // pixel sub-tiles per batch
+        i32x4_t radd[HAS_ADD ? IPB * NV : 1], rmsk[HAS_MASK ? IPB * NV : 1];
+        auto eoff = [&](int i, int v) -> uint32_t {
+            const int m = m0 + wm * WM + i * 16 + fr, n = nb + v * 4 * VE;
+            return (coalesced && m < a.M && n < a.N) ? (uint32_t)(((size_t)m * a.N + n) * sizeof(T)) : URSO_OOB_SHIFT;
+        };
+        auto eload = [&](int batch) {
+#pragma unroll
+            for (int ii = 0; ii < IPB; ++ii)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const uint32_t o = eoff(batch * IPB + ii, v);
+                    if constexpr (HAS_ADD) radd[ii * NV + v] = buf_load16(rad, o);
+                    if constexpr (HAS_MASK) rmsk[ii * NV + v] = buf_load16(rmk, o);
+                }
+        };
+
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            const bool last = (kt + 1 == a.nkt);
+            if (!last) fetch(kt + 1);
+            else {
+                if (has_next) { setup_fetch(next); fetch(0); }     // oldest in the queue: lands during the epilogue
+                if (coalesced) eload(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x4_t fa[TN], fb[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        *(f32x4_t*)(stile + (i * 16 + fr) * LROW + wn * WN + j * 16 + fg * 4) = acc[i][j];
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[j], fb[i], acc[i][j]);
             }
-            __syncthreads();
-            i32x4_t radd[EIT], rmsk[EIT];
-#pragma unroll
-            for (int it = 0; it < EIT; ++it) {
-                const int item = tid + 256 * it, row = item / VPR, v = item % VPR;
-                const int m = m0 + pass * 64 + row, n = n0 + v * VE;
-                const bool ok = m < a.M && n < a.N;
-                const size_t o = (size_t)m * a.N + n;
-                radd[it] = (ok && a.add) ? *(const i32x4_t*)((const T*)a.add + o) : i32x4_t{0, 0, 0, 0};
-                rmsk[it] = (ok && a.mask) ? *(const i32x4_t*)((const T*)a.mask + o) : i32x4_t{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int it = 0; it < EIT; ++it) {
-                const int item = tid + 256 * it, row = item / VPR, v = item % VPR;
-                const int m = m0 + pass * 64 + row, n = n0 + v * VE;
-                if (!(m < a.M && n < a.N)) continue;
-                float x[VE];
-#pragma unroll
-                for (int q = 0; q < VE / 4; ++q) {
-                    f32x4_t t = *(const f32x4_t*)(stile + row * LROW + v * VE + q * 4);
-                    x[q * 4] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
-                }
-                if (a.bias) {
-#pragma unroll
-                    for (int q = 0; q < VE / 4; ++q) { f32x4_t b = *(const f32x4_t*)(a.bias + n + q * 4); x[q * 4] += b.x; x[q * 4 + 1] += b.y; x[q * 4 + 2] += b.z; x[q * 4 + 3] += b.w; }
-                }
-                T ea[VE], em[VE], eo[VE];
-                __builtin_memcpy(ea, &radd[it], 16); __builtin_memcpy(em, &rmsk[it], 16);
-#pragma unroll
-                for (int q = 0; q < VE; ++q) {
-                    float y = x[q];
-                    if (a.add) y += Elem<T>::to_f(ea[q]);
-                    if (relu) y = fmaxf(y, 0.f);
-                    if (a.mask && !(Elem<T>::to_f(em[q]) > 0.f)) y = 0.f;
-                    eo[q] = Elem<T>::from_f(y);
-                }
-                i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
-                *(i32x4_t*)((T*)a.dst + (size_t)m * a.N + n) = ov;
-            }
-            __syncthreads();
+            if (!last) { stage(cur ^ 1); lds_barrier(); cur ^= 1; }
         }
-        return;
-    }
-    // scalar-friendly path (fp32 head outputs, channel counts that are not a multiple of the vector)
+        if (a.flags & 0x200) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TM-1][TN-1]), "v"(acc[1][1])); }
+        else if (coalesced) {
+            // Straight from the accumulators: lane (fr, fg) finishes channels nb..nb+CH-1 of pixels i*16 + fr:
+            // bias + residual + ReLU + mask + cast, 16-byte vectors, no LDS, no barrier.
+            float bv[CH];
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) { f32x4_t b = __builtin_bit_cast(f32x4_t, rbias[q]); bv[q * 4] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (NBATCH == 2 && i == IPB) eload(1);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    T ea[VE], em[VE], eo[VE];
+                    if constexpr (HAS_ADD) __builtin_memcpy(ea, &radd[(i % IPB) * NV + v], 16);
+                    if constexpr (HAS_MASK) __builtin_memcpy(em, &rmsk[(i % IPB) * NV + v], 16);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const int c = v * VE + e;                               // = 4*j + r: sub-tile j, D register r
+                        float y = acc[i][c >> 2][c & 3] + bv[c];                // an absent bias reads as 0
+                        if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
+                        y = relu ? fmaxf(y, 0.f) : y;
+                        if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                        eo[e] = Elem<T>::from_f(y);
+                    }
+                    i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                    if (a.flags & 0x100) { asm volatile("" :: "v"(ov)); } else buf_store16(rds, eoff(i, v), ov);
+                }
+            }
+        } else {
+            // scalar-friendly path (fp32 head outputs, channel counts that are not a multiple of the vector)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WM + i * 16 + fr;
         if (m >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn * WN + j * 16 + fg * 4;
-            if (nb >= a.N) continue;
-            const size_t o = (size_t)m * a.N + nb;
+            const int nbj = nb + (j / JPV) * 4 * VE + (j % JPV) * 4;
+            if (nbj >= a.N) continue;
+            const size_t o = (size_t)m * a.N + nbj;
             float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
             if (nvec) {
-                if (a.bias) { f32x4_t bv = *(const f32x4_t*)(a.bias + nb); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+                if (a.bias) { f32x4_t bv = *(const f32x4_t*)(a.bias + nbj); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
                 if (a.add) {
                     const T* ap = (const T*)a.add + o;
                     if constexpr (sizeof(T) == 4) { f32x4_t av = *(const f32x4_t*)ap; v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w; }
@@ -225,9 +266,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                     for (int q = 0; q < 4; ++q) e[q] = Elem<T>::from_f(v[q]);
                     i32x2_t raw; __builtin_memcpy(&raw, e, 8); *(i32x2_t*)((T*)a.dst + o) = raw; }
             } else {
-                for (int q = 0; q < 4 && nb + q < a.N; ++q) {
+                for (int q = 0; q < 4 && nbj + q < a.N; ++q) {
                     float x = v[q];
-                    if (a.bias) x += a.bias[nb + q];
+                    if (a.bias) x += a.bias[nbj + q];
                     if (a.add) x += Elem<T>::to_f(((const T*)a.add)[o + q]);
                     if (relu) x = fmaxf(x, 0.f);
                     if (a.mask && !(Elem<T>::to_f(((const T*)a.mask)[o + q]) > 0.f)) x = 0.f;
@@ -236,20 +277,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
             }
         }
     }
+        }
+        if (!has_next) break;
+        stage(cur ^ 1);                  // the next tile's first K-tile (its loads flew during the epilogue)
+        lds_barrier();
+        cur ^= 1;
+        tile = next;
+    }
 }
 
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
 template <typename T>
 static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, hipStream_t st) {
-    // tile choice: narrow-N layers use the 128x64 tile (no wasted MFMA columns)
-    if (g->N <= 64) {
-        a.tilesN = ceil_div(g->N, 64); a.nblk = ceil_div(a.M, 128) * a.tilesN;
-        hipLaunchKernelGGL((igemm_kernel<T, 128, 64>), dim3(a.nblk), dim3(256), 0, st, a);
-    } else {
-        a.tilesN = ceil_div(g->N, 128); a.nblk = ceil_div(a.M, 128) * a.tilesN;
-        hipLaunchKernelGGL((igemm_kernel<T, 128, 128>), dim3(a.nblk), dim3(256), 0, st, a);
-    }
+    // tile choice: narrow-N layers use the 128x64 tile (no wasted MFMA columns); so do short-K
+    // (HBM-bound) layers: 48 KiB LDS / 120 VGPRs -> 3 resident blocks per CU = more bytes in flight
+    static int shortk = -1;
+    if (shortk < 0) { const char* e = getenv("URSO_IGEMM_SHORTK"); shortk = e ? atoi(e) : 0; }
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+    const bool small = (g->N <= 64 || a.nkt <= shortk);
+    const int bn = small ? 64 : 128;
+    a.tilesN = ceil_div(g->N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = (small ? 3 : 2) * ncu / 8;                     // 48 / 64 KiB LDS: 3 / 2 resident blocks per CU
+    if (bpx > cap) bpx = cap;
+    const dim3 grid(8 * bpx), blk(256);
+    const bool coal = !(flags & URSO_EPI_OUT_F32) && (g->N % (16 / (int)sizeof(T))) == 0;
+    const int sel = coal ? ((a.add ? 1 : 0) | (a.mask ? 2 : 0)) : 0;     // the scalar path reads add/mask through a.*
+#define URSO_LAUNCH(BN_, AD_, MK_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_>), grid, blk, 0, st, a)
+    if (small) { switch (sel) { case 0: URSO_LAUNCH(64, false, false); break; case 1: URSO_LAUNCH(64, true, false); break;
+                                case 2: URSO_LAUNCH(64, false, true); break; default: URSO_LAUNCH(64, true, true); } }
+    else       { switch (sel) { case 0: URSO_LAUNCH(128, false, false); break; case 1: URSO_LAUNCH(128, true, false); break;
+                                case 2: URSO_LAUNCH(128, false, true); break; default: URSO_LAUNCH(128, true, true); } }
+#undef URSO_LAUNCH
     return urso_check_launch("urso_conv_igemm");
 }
 
@@ -268,15 +329,18 @@ extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
     const size_t src_bytes = (size_t)g->B * g->H * g->W * g->C * es;
     const size_t wgt_bytes = (size_t)g->N * g->KH * g->KW * g->C * es;
     const size_t dst_elems = (size_t)g->B * g->OH * g->OW * g->N;
-    if (src_bytes >= 0x7FFFFF00ull || wgt_bytes >= 0x7FFFFF00ull || dst_elems * 4 >= 0x1FFFFFFF00ull) {
+    if (src_bytes >= 0x7FFFFF00ull || wgt_bytes >= 0x7FFFFF00ull || dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) >= 0x7FFFFF00ull) {
         urso_set_error("urso_conv_igemm: tensor exceeds the 2 GiB buffer-addressing limit"); return URSO_EINVAL; }
     IgemmArgs a;
     a.src = src_d; a.wgt = wgt_d; a.bias = bias_d; a.add = add_d; a.mask = mask_d; a.dst = dst_d;
     a.src_bytes = (uint32_t)src_bytes; a.wgt_bytes = (uint32_t)wgt_bytes;
+    a.dst_bytes = (uint32_t)(dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es));
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.OH = g->OH; a.OW = g->OW; a.N = g->N;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     a.M = g->B * g->OH * g->OW; a.Cc = g->C / VE; a.Kc = g->KH * g->KW * a.Cc; a.nkt = ceil_div(a.Kc, 8);
     a.flags = flags;
+    a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 &&
+                   g->H == g->OH && g->W == g->OW) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic work: 2*M*N*K flops; bytes = src + weights + dst (+ add/mask reads)
     double flops = 2.0 * a.M * (double)g->N * g->KH * g->KW * g->C;
