@@ -58,6 +58,11 @@ typedef struct urso_conv_geom {
     int32_t SH, SW;
     int32_t PH, PW;
     int32_t DH, DW;            /* 1 or 2                                           */
+    /* Optional scatter of the destination (0 = dense).  When FH > 0 the destination tensor is [B,FH,FW,N] and the
+     * computed pixel (b,oy,ox) is stored at (b, oy*OSH, ox*OSW); add/mask are read at the same place; all other
+     * destination pixels are left untouched.  Used for the data gradient of stride-2 1x1 convs (res{3,4,5}a_branch2a
+     * / branch1, net.py:138-153): only every other pixel receives gradient, the rest of the (pre-zeroed) buffer is 0. */
+    int32_t FH, FW, OSH, OSW;
 } urso_conv_geom;
 
 /*

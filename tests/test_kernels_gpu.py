@@ -128,6 +128,17 @@ def test_conv_forward_and_gradients(case, dt):
     dx_ref = (x_r.grad + addt) * (x > 0)
     e = relerr(dx, dx_ref)
     assert e < TOL[dt], "dgrad %s dt=%d rel err %.3e" % (name, dt, e)
+    if k == 1 and s == 2:
+        # compact form used for res{3,4,5}a_branch{2a,1}: GEMM over the output pixels, scattered to every 2nd pixel
+        gs = hip.geom(B, OH, OW, N, OH, OW, Ci, 1, 1, FH=H, FW=W, OSH=s, OSW=s)
+        dx2 = torch.zeros(B, H, W, Ci, dtype=hip.TORCH_DT[dt], device="cuda")
+        hip.conv_igemm(gs, dt, 0, dev(dz_ref, dt), wd, None, None, dev(x, dt), dx2)
+        torch.cuda.synchronize()
+        first = x_r.grad * (x > 0)
+        assert relerr(dx2, first) < TOL[dt], "compact dgrad"
+        hip.conv_igemm(gs, dt, 0, dev(dz_ref, dt), wd, None, dx2, dev(x, dt), dx2)      # in-place accumulate
+        torch.cuda.synchronize()
+        assert relerr(dx2, 2 * rnd(first, dt)) < TOL[dt] * 2, "compact dgrad accumulate"
     # ---- weight gradient (raw, w.r.t. the folded filter) + column sums
     ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
     dw = torch.empty(k, k, Ci, N, dtype=torch.float32, device="cuda")

@@ -23,6 +23,7 @@ struct IgemmArgs {
     int nkt;        // K tiles = ceil(Kc / 8)
     int tilesN, ntiles;
     int pointwise;  // 1x1, stride 1, no padding: source pixel index == destination pixel index
+    int FH, FW, OSH, OSW;   // destination scatter (FH == 0: dense)
     int flags;
 };
 
@@ -161,9 +162,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         constexpr int NBATCH = (HAS_ADD && HAS_MASK) ? 2 : 1;     // two load batches when both tensors are present
         constexpr int IPB = TM / NBATCH;                           // pixel sub-tiles per batch
         i32x4_t radd[HAS_ADD ? IPB * NV : 1], rmsk[HAS_MASK ? IPB * NV : 1];
+        // destination pixel index of this lane's row of sub-tile i (scattered destinations: stride-2 dgrad)
+        int dpix[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + fr;
+            if (a.FH == 0 || m >= a.M) dpix[i] = m;
+            else { const int b = m / ohw, rem = m - b * ohw, oy = rem / a.OW, ox = rem - oy * a.OW;
+                   dpix[i] = (b * a.FH + oy * a.OSH) * a.FW + ox * a.OSW; }
+        }
         auto eoff = [&](int i, int v) -> uint32_t {
             const int m = m0 + wm * WM + i * 16 + fr, n = nb + v * 4 * VE;
-            return (coalesced && m < a.M && n < a.N) ? (uint32_t)(((size_t)m * a.N + n) * sizeof(T)) : URSO_OOB_SHIFT;
+            return (coalesced && m < a.M && n < a.N) ? (uint32_t)(((size_t)dpix[i] * a.N + n) * sizeof(T)) : URSO_OOB_SHIFT;
         };
         auto eload = [&](int batch) {
 #pragma unroll
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         for (int j = 0; j < TN; ++j) {
             const int nbj = nb + (j / JPV) * 4 * VE + (j % JPV) * 4;
             if (nbj >= a.N) continue;
-            const size_t o = (size_t)m * a.N + nbj;
+            const size_t o = (size_t)dpix[i] * a.N + nbj;
             float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
             if (nvec) {
                 if (a.bias) { f32x4_t bv = *(const f32x4_t*)(a.bias + nbj); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
@@ -328,7 +338,10 @@ extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
     if (dhs < 0 || dws < 0) { urso_set_error("urso_conv_igemm: D must be 1, 2 or 4"); return URSO_EINVAL; }
     const size_t src_bytes = (size_t)g->B * g->H * g->W * g->C * es;
     const size_t wgt_bytes = (size_t)g->N * g->KH * g->KW * g->C * es;
-    const size_t dst_elems = (size_t)g->B * g->OH * g->OW * g->N;
+    const bool scatter = g->FH > 0;
+    if (scatter && (g->FW <= 0 || g->OSH <= 0 || g->OSW <= 0 || (g->OH - 1) * g->OSH >= g->FH || (g->OW - 1) * g->OSW >= g->FW)) {
+        urso_set_error("urso_conv_igemm: bad destination scatter"); return URSO_EINVAL; }
+    const size_t dst_elems = scatter ? (size_t)g->B * g->FH * g->FW * g->N : (size_t)g->B * g->OH * g->OW * g->N;
     if (src_bytes >= 0x7FFFFF00ull || wgt_bytes >= 0x7FFFFF00ull || dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) >= 0x7FFFFF00ull) {
         urso_set_error("urso_conv_igemm: tensor exceeds the 2 GiB buffer-addressing limit"); return URSO_EINVAL; }
     IgemmArgs a;
@@ -339,6 +352,7 @@ extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     a.M = g->B * g->OH * g->OW; a.Cc = g->C / VE; a.Kc = g->KH * g->KW * a.Cc; a.nkt = ceil_div(a.Kc, 8);
     a.flags = flags;
+    a.FH = scatter ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
     a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 &&
                    g->H == g->OH && g->W == g->OW) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;

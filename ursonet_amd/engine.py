@@ -196,8 +196,15 @@ class Engine(object):
             else:
                 s, (pt, pl) = node.stride, node.pad
                 c.gf = hip.geom(B, node.src.h, node.src.w, node.cin, node.dst.h, node.dst.w, c.npad, node.kh, node.kw, s, s, pt, pl)
-                c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.src.h, node.src.w, node.cin, node.kh, node.kw,
-                                1, 1, node.kh - 1 - pt, node.kw - 1 - pl, s, s)
+                if node.kh == 1 and node.kw == 1 and s > 1:
+                    # compact data gradient: GEMM over the forward-output pixels, scattered to every s-th pixel
+                    # of the (pre-zeroed) input-gradient buffer instead of a 4x wasteful gather over all pixels
+                    c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.dst.h, node.dst.w, node.cin, 1, 1,
+                                    FH=node.src.h, FW=node.src.w, OSH=s, OSW=s)
+                    c.gd_scatter = True
+                else:
+                    c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.src.h, node.src.w, node.cin, node.kh, node.kw,
+                                    1, 1, node.kh - 1 - pt, node.kw - 1 - pl, s, s)
                 c.K_raw = node.kh * node.kw * node.cin
             if node.cin % VE and not node.stem:
                 raise ValueError("layer %s: %d input channels is not a multiple of %d" % (node.name, node.cin, VE))
@@ -295,6 +302,11 @@ class Engine(object):
                 add = X.grad if X.grad_written else X.pending
                 dstg = X.grad_buf()
                 mask = X.data if X.spec.relu else None
+                if getattr(c, "gd_scatter", False):
+                    if add is None:                       # first contribution: everything off the sampled grid is zero
+                        self.bwd_ops.append((None, lambda t=dstg: t.zero_()))       # torch fill: no profiler record
+                    elif add is not dstg:
+                        raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
                                      hip.conv_igemm(c.gd, dt, 0, G, c.wd, None, add, mask, dstg)))
                 self.labels["bwd"].append("dgrad:" + node.name)

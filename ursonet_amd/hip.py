@@ -24,7 +24,8 @@ DT_NAME = {F32: "f32", BF16: "bf16", F16: "f16"}
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "H", "W", "C", "OH", "OW", "N", "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW")]
+                ("B", "H", "W", "C", "OH", "OW", "N", "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW",
+                 "FH", "FW", "OSH", "OSW")]
 
     def __repr__(self):
         return "ConvGeom(" + ", ".join("%s=%d" % (n, getattr(self, n)) for n, _ in self._fields_) + ")"
@@ -101,8 +102,8 @@ def stream_ptr(stream=None):
     return s.cuda_stream
 
 
-def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1):
-    return ConvGeom(B, H, W, Cin, OH, OW, N, KH, KW, SH, SW, PH, PW, DH, DW)
+def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1, FH=0, FW=0, OSH=0, OSW=0):
+    return ConvGeom(B, H, W, Cin, OH, OW, N, KH, KW, SH, SW, PH, PW, DH, DW, FH, FW, OSH, OSW)
 
 
 # ---------------------------------------------------------------- thin typed wrappers
