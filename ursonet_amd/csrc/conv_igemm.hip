@@ -207,8 +207,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
             }
             if (!last) { stage(cur ^ 1); lds_barrier(); cur ^= 1; }
         }
-        if (a.flags & 0x200) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TM-1][TN-1]), "v"(acc[1][1])); }
-        else if (coalesced) {
+        if (coalesced) {
             // Straight from the accumulators: lane (fr, fg) finishes channels nb..nb+CH-1 of pixels i*16 + fr:
             // bias + residual + ReLU + mask + cast, 16-byte vectors, no LDS, no barrier.
             float bv[CH];
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                         eo[e] = Elem<T>::from_f(y);
                     }
                     i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
-                    if (a.flags & 0x100) { asm volatile("" :: "v"(ov)); } else buf_store16(rds, eoff(i, v), ov);
+                    buf_store16(rds, eoff(i, v), ov);
                 }
             }
         } else {

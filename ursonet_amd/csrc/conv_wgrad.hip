@@ -23,9 +23,14 @@ struct WgradArgs {
     int B, H, W, C, OH, OW, N, KH, KW, SH, SW, PH, PW;
     int M, Cc, Kc, K;          // K = Kc*VE
     int ktiles, ntiles, splits, m_per_split;   // m_per_split multiple of RM
+    int dbg;
+    int pointwise;             // 1x1 / stride 1 / no padding: source pixel == destination pixel
+    float rcp_ohw, rcp_ow;
 };
 
-template <typename T>
+// MODE 0: pointwise conv (source pixel == destination pixel); 1: wide rows (OW >= RM: carried coordinates, single
+// wrap); 2: narrow rows (coordinates recomputed by divmod every step).  Compile-time so the unrolled fetch stays straight-line.
+template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int VE = Elem<T>::VE;
     constexpr int RM = 128 / (int)sizeof(T);          // pixels per reduction step (64 / 32)
@@ -57,18 +62,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int ncol = n0 + ch * VE;
     const bool nvalid = ncol < a.N;                 // N is a multiple of VE for vector loads (checked on host)
 
-    // running (b, oy, ox) of every pixel this thread stages: pixel index p = (prow + PSTEP*it)*PIX + q
-    int pb[ITEMS * PIX], poy[ITEMS * PIX], pox[ITEMS * PIX];
+    // pixel p = (prow + PSTEP*it)*PIX + q of every step is staged by this thread; its (b, oy, ox) is recomputed
+    // per step with a branch-free exact division (float reciprocal + one correction; pixel indices < 2^24)
     const int ohw = a.OH * a.OW;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it)
-#pragma unroll
-        for (int q = 0; q < PIX; ++q) {
-            int m = m_begin + (prow + PSTEP * it) * PIX + q;
-            int b = m / ohw, rem = m - b * ohw;
-            pb[it * PIX + q] = b; poy[it * PIX + q] = rem / a.OW; pox[it * PIX + q] = rem - (rem / a.OW) * a.OW;
-        }
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
     int mcur = m_begin;                              // first pixel of the step being fetched
+    // wide rows (OW >= RM): a step advances a pixel by RM < one row, so (b, oy, ox) are carried and updated with a
+    // branch-free single wrap; narrow rows: recomputed by divmod every step; pointwise convs need no coordinates.
+    int pb[ITEMS * PIX], poy[ITEMS * PIX], pox[ITEMS * PIX];
+#pragma unroll
+    for (int e = 0; e < ITEMS * PIX; ++e) {
+        const int m = m_begin + ((prow + PSTEP * (e / PIX)) * PIX + (e % PIX));
+        int rem;
+        divmod(m, ohw, a.rcp_ohw, pb[e], rem);
+        divmod(rem, a.OW, a.rcp_ow, poy[e], pox[e]);
+    }
 
     i32x4_t rxv[ITEMS * PIX], rzv[ITEMS * PIX];
     auto fetch = [&]() {
@@ -79,15 +93,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 const int e = it * PIX + q;
                 const int m = mcur + (prow + PSTEP * it) * PIX + q;
                 const bool mvalid = m < m_end;
-                int iy = poy[e] * a.SH - a.PH + ky, ix = pox[e] * a.SW - a.PW + kx;
-                bool ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
-                uint32_t off = (uint32_t)(((pb[e] * a.H + iy) * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
+                uint32_t off; bool ok;
+                if constexpr (MODE == 0) { off = (uint32_t)(m * a.C + cc * VE) * (uint32_t)sizeof(T); ok = mvalid && kvalid; }
+                else {
+                    int b, oy, ox;
+                    if constexpr (MODE == 1) {
+                        b = pb[e]; oy = poy[e]; ox = pox[e];
+                        int nx = ox + RM; const bool w1 = nx >= a.OW; nx -= w1 ? a.OW : 0;
+                        int ny = oy + (w1 ? 1 : 0); const bool w2 = ny >= a.OH; ny = w2 ? 0 : ny;
+                        pox[e] = nx; poy[e] = ny; pb[e] = b + (w2 ? 1 : 0);
+                    } else { int rem; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); }
+                    const int iy = oy * a.SH - a.PH + ky, ix = ox * a.SW - a.PW + kx;
+                    ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                    off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
+                }
                 rxv[e] = buf_load16(rx, ok ? off : URSO_OOB_SHIFT);
                 uint32_t zoff = ((uint32_t)m * (uint32_t)a.N + (uint32_t)ncol) * (uint32_t)sizeof(T);
                 rzv[e] = buf_load16(rz, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
-                // advance this pixel by RM for the next step
-                pox[e] += RM;
-                while (pox[e] >= a.OW) { pox[e] -= a.OW; if (++poy[e] == a.OH) { poy[e] = 0; ++pb[e]; } }
             }
         mcur += RM;
     };
@@ -230,7 +252,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     // every extra split costs a K*N fp32 partial written and re-read, so do not over-split
     static int target = 0;
     if (!target) { const char* e = getenv("URSO_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
-    int splits = ceil_div(target, tiles);
+    int splits = target / tiles;                       // never more blocks than resident slots: no second wave
     splits = splits < 1 ? 1 : splits;
     int max_splits = steps / 8; if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
@@ -268,15 +290,23 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
     a.colpart = colsum_d ? (direct ? colsum_d : colpart) : nullptr;
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.OH = g->OH; a.OW = g->OW; a.N = g->N;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    a.dbg = 0;
+    a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW) ? 1 : 0;
+    a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW;
+    if ((size_t)g->B * g->OH * g->OW >= (1u << 24)) { urso_set_error("urso_conv_wgrad: more than 2^24 output pixels"); return URSO_EINVAL; }
     a.M = p.M; a.Cc = p.Cc; a.Kc = p.Kc; a.K = p.K; a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
     hipStream_t st = (hipStream_t)stream;
     double flops = 2.0 * p.M * (double)g->N * g->KH * g->KW * g->C;
     double bytes = (double)x_bytes + (double)dz_bytes + (double)p.K * g->N * 4;
     ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
     dim3 grid(p.ktiles * p.ntiles, p.splits);
-    if (dt == URSO_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, st, a);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<_Float16>), grid, dim3(256), 0, st, a);
+    const int rm = 128 / (int)dt_size(dt);
+    const int mode = a.pointwise ? 0 : (g->OW >= rm ? 1 : 2);
+#define URSO_WG(TT) do { if (mode == 0) hipLaunchKernelGGL((wgrad_kernel<TT, 0>), grid, dim3(256), 0, st, a); \
+                         else if (mode == 1) hipLaunchKernelGGL((wgrad_kernel<TT, 1>), grid, dim3(256), 0, st, a); \
+                         else hipLaunchKernelGGL((wgrad_kernel<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
+    if (dt == URSO_F32) URSO_WG(float); else if (dt == URSO_BF16) URSO_WG(__bf16); else URSO_WG(_Float16);
+#undef URSO_WG
     int rc = urso_check_launch("urso_conv_wgrad");
     if (rc != URSO_OK) return rc;
     if (!direct) {
