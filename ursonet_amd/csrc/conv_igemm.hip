@@ -89,20 +89,37 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     };
 
     i32x4_t ra[RA], rb[RB];
+    uint32_t rowbase[RA];      // fast path: byte offset of (row pixel, current tap, channel 0), or OOB when the tap is padding
     auto fetch = [&](int kt) {
-        int kc = kt * 8 + c8, ky, kx, cc;
+        const int kc = kt * 8 + c8;
         const bool kvalid = kc < a.Kc;
-        if (fast_tap) { ky = ft_ky; kx = ft_kx; cc = ft_cc + c8;
-            ft_cc += 8; if (ft_cc >= a.Cc) { ft_cc = 0; if (++ft_kx == a.KW) { ft_kx = 0; ++ft_ky; } }
-        } else { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
         const int dmh = (1 << a.DHs) - 1, dmw = (1 << a.DWs) - 1;
+        if (fast_tap) {
+            // all 8 chunks of the K-tile belong to ONE filter tap: the per-row pixel offset is recomputed only when
+            // the tap changes (every Cc/8 K-tiles); in between a K-tile costs one add per row.
+            if (ft_cc == 0) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int ty = ty0[i] + ky, tx = tx0[i] + kx;
-            const int iy = ty >> a.DHs, ix = tx >> a.DWs;
-            const bool ok = kvalid && ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
-            const uint32_t off = (uint32_t)((pb[i] + iy * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
-            ra[i] = buf_load16(rs, ok ? off : URSO_OOB_SHIFT);
+                for (int i = 0; i < RA; ++i) {
+                    const int ty = ty0[i] + ft_ky, tx = tx0[i] + ft_kx;
+                    const int iy = ty >> a.DHs, ix = tx >> a.DWs;
+                    const bool ok = ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
+                    rowbase[i] = ok ? (uint32_t)((pb[i] + iy * a.W + ix) * a.C) * (uint32_t)sizeof(T) : URSO_OOB_SHIFT;
+                }
+            }
+            const uint32_t coff = (uint32_t)(ft_cc + c8) * 16u;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = buf_load16(rs, rowbase[i] + coff);      // OOB_SHIFT + small stays out of range
+            ft_cc += 8; if (ft_cc >= a.Cc) { ft_cc = 0; if (++ft_kx == a.KW) { ft_kx = 0; ++ft_ky; } }
+        } else {
+            const int tap = kc / a.Cc, cc = kc - tap * a.Cc, ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ty = ty0[i] + ky, tx = tx0[i] + kx;
+                const int iy = ty >> a.DHs, ix = tx >> a.DWs;
+                const bool ok = kvalid && ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
+                const uint32_t off = (uint32_t)((pb[i] + iy * a.W + ix) * a.C + cc * VE) * (uint32_t)sizeof(T);
+                ra[i] = buf_load16(rs, ok ? off : URSO_OOB_SHIFT);
+            }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
