@@ -78,6 +78,13 @@ typedef struct urso_conv_geom {
 int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
                     const void* src_d, const void* wgt_d, const float* bias_d,
                     const void* add_d, const void* mask_d, void* dst_d, void* stream);
+/* Same, with an optional fp32 workspace: layers whose output has too few tiles to fill the chip but a deep reduction
+ * (bottleneck_layer: K = 18,432 on 20 tiles; the Dense heads: M = batch) are then split along K over extra blocks and
+ * finished by a second kernel.  urso_conv_igemm_ws_bytes() returns the size that enables it (0 = no split for `g`). */
+size_t urso_conv_igemm_ws_bytes(const urso_conv_geom* g, int dt);
+int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
+                       const void* src_d, const void* wgt_d, const float* bias_d,
+                       const void* add_d, const void* mask_d, void* dst_d, void* ws_d, size_t ws_bytes, void* stream);
 
 /*
  * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):

@@ -218,6 +218,33 @@ def test_stem_pixel_pair_conv(dt):
     assert relerr(dw, w_fold.grad) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_split_k_small_grid_layers(dt):
+    """bottleneck_layer-like (K = 3*3*512 on a handful of tiles) and Dense-like shapes through the split-K path
+    (urso_conv_igemm_ws) must equal the unsplit kernel's math: bias + residual + ReLU + mask after the reduction."""
+    hip = _hip()
+    torch.manual_seed(21)
+    for (B, H, W, Ci, N, k, s, pad, relu) in [(2, 8, 10, 512, 32, 3, 2, (0, 0), False), (8, 1, 1, 2560, 256, 1, 1, (0, 0), True)]:
+        OH, OW = (-(-H // s), -(-W // s)) if k == 3 else (1, 1)
+        x = rnd(torch.randn(B, H, W, Ci), dt)
+        w = torch.randn(k, k, Ci, N) / np.sqrt(k * k * Ci)
+        bias = torch.randn(N)
+        res = rnd(torch.randn(B, OH, OW, N), dt)
+        wf, wd, biasf, scale = prep_weights(w, dt, bias, None)
+        g = hip.geom(B, H, W, Ci, OH, OW, N, k, k, s, s, pad[0], pad[1])
+        nbytes = hip.conv_igemm_ws_bytes(g, dt)
+        assert nbytes > 0, "expected the split-K plan for this shape"
+        ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device="cuda")
+        y = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
+        hip.conv_igemm_ws(g, dt, hip.EPI_RELU if relu else 0, dev(x, dt), wf, biasf, dev(res, dt), dev(res, dt), y, ws)
+        y2 = torch.empty_like(y)
+        hip.conv_igemm(g, dt, hip.EPI_RELU if relu else 0, dev(x, dt), wf, biasf, dev(res, dt), dev(res, dt), y2)
+        torch.cuda.synchronize()
+        z = _ref_conv(x, rnd(w, dt), s, pad, OH, OW) + bias + res
+        ref = (torch.relu(z) if relu else z) * (res > 0)
+        assert relerr(y, ref) < TOL[dt] and relerr(y2, ref) < TOL[dt]
+
+
 def test_weight_prep_layouts():
     hip = _hip()
     torch.manual_seed(3)

@@ -24,6 +24,8 @@ struct IgemmArgs {
     int tilesN, ntiles;
     int pointwise;  // 1x1, stride 1, no padding: source pixel index == destination pixel index
     int FH, FW, OSH, OSW;   // destination scatter (FH == 0: dense)
+    int ksplit, kps;        // split-K: number of K slices (1 = off) and K-tiles per slice
+    float* part;            // split-K: fp32 partial sums [ksplit][M][N]
     int flags;
 };
 
@@ -32,7 +34,9 @@ struct IgemmArgs {
 // stride bpx.  Inside a block the (tile, K-tile) pairs form ONE stream: the global loads of the next
 // K-tile -- or of the NEXT TILE's first K-tile -- are issued before the MFMAs of the current one and
 // stay in flight during the epilogue, so short-K (HBM-bound) layers never expose their load latency.
-template <typename T, int BM, int BN, bool HAS_ADD, bool HAS_MASK>
+// SPLIT: the tile stream enumerates (tile, K-slice) pairs and the epilogue stores raw fp32 partial sums (split-K for
+// tiny-grid / deep-K layers); compiled separately so the common kernels carry none of its state.
+template <typename T, int BM, int BN, bool HAS_ADD, bool HAS_MASK, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int VE = Elem<T>::VE;
     constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
@@ -67,7 +71,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     const int ohw = a.OH * a.OW;
     const bool fast_tap = (a.Cc & 7) == 0;             // a K-tile never straddles filter taps
     int ft_cc = 0, ft_ky = 0, ft_kx = 0;               // running (chunk-in-tap, ky, kx) of the next K-tile (fast path)
-    auto setup_fetch = [&](int t) {
+    const int KS = SPLIT ? a.ksplit : 1;
+    bool tap_dirty = true;     // (SPLIT) a K-slice may start in the middle of a filter tap
+    auto setup_fetch = [&](int ts) {
+        const int t = ts / KS;
         const int m0f = (t / a.tilesN) * BM, n0f = (t % a.tilesN) * BN;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -85,7 +92,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
             const int n = n0f + r0 + 32 * i;
             wrow[i] = (n < a.N) ? (uint32_t)n * (uint32_t)a.Kc * 16u : URSO_OOB_SHIFT;
         }
-        ft_cc = 0; ft_ky = 0; ft_kx = 0;
+        // running filter-tap counters of the fast path start at the slice's first K-tile
+        if constexpr (SPLIT) {
+            const int kc0 = (ts % KS) * a.kps * 8, tap0 = kc0 / a.Cc;
+            ft_cc = kc0 - tap0 * a.Cc; ft_ky = tap0 / a.KW; ft_kx = tap0 - ft_ky * a.KW;
+            tap_dirty = true;
+        } else { ft_cc = 0; ft_ky = 0; ft_kx = 0; }
     };
 
     i32x4_t ra[RA], rb[RB];
@@ -97,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         if (fast_tap) {
             // all 8 chunks of the K-tile belong to ONE filter tap: the per-row pixel offset is recomputed only when
             // the tap changes (every Cc/8 K-tiles); in between a K-tile costs one add per row.
-            if (ft_cc == 0) {
+            if (ft_cc == 0 || (SPLIT && tap_dirty)) {
+                tap_dirty = false;
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
                     const int ty = ty0[i] + ft_ky, tx = tx0[i] + ft_kx;
@@ -146,15 +159,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
     const bool relu = a.flags & URSO_EPI_RELU, outf32 = a.flags & URSO_EPI_OUT_F32;
     const bool nvec = (a.N & 3) == 0;
-    const bool coalesced = !outf32 && (a.N % VE) == 0;
+    const bool coalesced = !SPLIT && !outf32 && (a.N % VE) == 0;
 
     setup_fetch(tile);
-    fetch(0);
+    fetch(SPLIT ? (tile % KS) * a.kps : 0);
     stage(0);
     lds_barrier();
     int cur = 0;
     while (true) {
-        const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+        const int otile = tile / KS, slice = tile % KS;
+        const int kt_begin = SPLIT ? slice * a.kps : 0, kt_end = SPLIT ? min(a.nkt, kt_begin + a.kps) : a.nkt;
+        const int m0 = (otile / a.tilesN) * BM, n0 = (otile % a.tilesN) * BN;
         const int next = tile + bpx;
         const bool has_next = next < t_end;
         f32x4_t acc[TM][TN];
@@ -203,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                 }
         };
 
-        for (int kt = 0; kt < a.nkt; ++kt) {
-            const bool last = (kt + 1 == a.nkt);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool last = (kt + 1 == kt_end);
             if (!last) fetch(kt + 1);
             else {
-                if (has_next) { setup_fetch(next); fetch(0); }     // oldest in the queue: lands during the epilogue
+                if (has_next) { setup_fetch(next); fetch(SPLIT ? (next % KS) * a.kps : 0); }   // oldest in the queue: lands during the epilogue
                 if (coalesced) eload(0);
             }
 #pragma unroll
@@ -224,7 +239,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
             }
             if (!last) { stage(cur ^ 1); lds_barrier(); cur ^= 1; }
         }
-        if (coalesced) {
+        if constexpr (SPLIT) {
+            // split-K: raw fp32 partial sums; bias / residual / activation happen in splitk_finish_kernel
+            float* pbase = a.part + (size_t)slice * a.M * a.N;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = nb + (j / JPV) * 4 * VE + (j % JPV) * 4;
+                    if (m < a.M && n < a.N) *(f32x4_t*)(pbase + (size_t)m * a.N + n) = acc[i][j];
+                }
+            }
+        } else if (coalesced) {
             // Straight from the accumulators: lane (fr, fg) finishes channels nb..nb+CH-1 of pixels i*16 + fr:
             // bias + residual + ReLU + mask + cast, 16-byte vectors, no LDS, no barrier.
             float bv[CH];
@@ -312,37 +339,110 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
+// split-K finish: out = epilogue(sum_s part[s] + bias + add), 4 channels per thread
+template <typename T>
+__global__ void splitk_finish_kernel(size_t n4, int N, int S, size_t slice_elems, const float* __restrict__ part, const float* __restrict__ bias,
+                                     const T* __restrict__ add, const T* __restrict__ mask, void* __restrict__ dst, int flags) {
+    const bool relu = flags & URSO_EPI_RELU, outf32 = flags & URSO_EPI_OUT_F32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        f32x4_t s0 = *(const f32x4_t*)(part + e), s1 = {0.f, 0.f, 0.f, 0.f};
+        int p = 1;
+        for (; p + 1 < S; p += 2) { s0 += *(const f32x4_t*)(part + (size_t)p * slice_elems + e); s1 += *(const f32x4_t*)(part + (size_t)(p + 1) * slice_elems + e); }
+        if (p < S) s0 += *(const f32x4_t*)(part + (size_t)p * slice_elems + e);
+        s0 += s1;
+        float v[4] = {s0.x, s0.y, s0.z, s0.w};
+        const int n = (int)(e % (size_t)N);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y = v[q] + (bias ? bias[n + q] : 0.f);
+            if (add) y += Elem<T>::to_f(add[e + q]);
+            if (relu) y = fmaxf(y, 0.f);
+            if (mask && !(Elem<T>::to_f(mask[e + q]) > 0.f)) y = 0.f;
+            if (outf32) ((float*)dst)[e + q] = y; else ((T*)dst)[e + q] = Elem<T>::from_f(y);
+        }
+    }
+}
+
+static void plan_splitk(int ntiles, int nkt, int ncu, int& S, int& kps) {
+    S = 1; kps = nkt;
+    if (ntiles * 2 > ncu || nkt < 8) return;
+    int want = ceil_div(2 * ncu, ntiles), cap = nkt / 4;
+    S = want < cap ? want : cap;
+    if (S < 2) { S = 1; return; }
+    kps = ceil_div(nkt, S); S = ceil_div(nkt, kps);
+}
+
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
+static int device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
 template <typename T>
-static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, hipStream_t st) {
+static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     // tile choice: narrow-N layers use the 128x64 tile (no wasted MFMA columns); so do short-K
     // (HBM-bound) layers: 48 KiB LDS / 120 VGPRs -> 3 resident blocks per CU = more bytes in flight
     static int shortk = -1;
     if (shortk < 0) { const char* e = getenv("URSO_IGEMM_SHORTK"); shortk = e ? atoi(e) : 0; }
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+    const int ncu = device_cus();
     const bool small = (g->N <= 64 || a.nkt <= shortk);
     const int bn = small ? 64 : 128;
     a.tilesN = ceil_div(g->N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
+    a.ksplit = 1; a.kps = a.nkt; a.part = nullptr;
+    if (ws && a.FH == 0 && (g->N & 3) == 0) {
+        int S, kps; plan_splitk(a.ntiles, a.nkt, ncu, S, kps);
+        if (S > 1 && (size_t)S * a.M * g->N * sizeof(float) <= ws_bytes) { a.ksplit = S; a.kps = kps; a.part = (float*)ws; }
+    }
+    const int out_tiles = a.ntiles;
+    a.ntiles = out_tiles * a.ksplit;                                // the tile stream enumerates (tile, K-slice) pairs
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = (small ? 3 : 2) * ncu / 8;                     // 48 / 64 KiB LDS: 3 / 2 resident blocks per CU
     if (bpx > cap) bpx = cap;
     const dim3 grid(8 * bpx), blk(256);
     const bool coal = !(flags & URSO_EPI_OUT_F32) && (g->N % (16 / (int)sizeof(T))) == 0;
-    const int sel = coal ? ((a.add ? 1 : 0) | (a.mask ? 2 : 0)) : 0;     // the scalar path reads add/mask through a.*
-#define URSO_LAUNCH(BN_, AD_, MK_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_>), grid, blk, 0, st, a)
-    if (small) { switch (sel) { case 0: URSO_LAUNCH(64, false, false); break; case 1: URSO_LAUNCH(64, true, false); break;
-                                case 2: URSO_LAUNCH(64, false, true); break; default: URSO_LAUNCH(64, true, true); } }
-    else       { switch (sel) { case 0: URSO_LAUNCH(128, false, false); break; case 1: URSO_LAUNCH(128, true, false); break;
-                                case 2: URSO_LAUNCH(128, false, true); break; default: URSO_LAUNCH(128, true, true); } }
+    const int sel = (coal && a.ksplit == 1) ? ((a.add ? 1 : 0) | (a.mask ? 2 : 0)) : 0;     // the scalar path reads add/mask through a.*
+#define URSO_LAUNCH(BN_, AD_, MK_, SP_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_, SP_>), grid, blk, 0, st, a)
+    if (a.ksplit > 1) { if (small) URSO_LAUNCH(64, false, false, true); else URSO_LAUNCH(128, false, false, true); }
+    else if (small) { switch (sel) { case 0: URSO_LAUNCH(64, false, false, false); break; case 1: URSO_LAUNCH(64, true, false, false); break;
+                                     case 2: URSO_LAUNCH(64, false, true, false); break; default: URSO_LAUNCH(64, true, true, false); } }
+    else            { switch (sel) { case 0: URSO_LAUNCH(128, false, false, false); break; case 1: URSO_LAUNCH(128, true, false, false); break;
+                                     case 2: URSO_LAUNCH(128, false, true, false); break; default: URSO_LAUNCH(128, true, true, false); } }
 #undef URSO_LAUNCH
+    if (a.ksplit > 1) {
+        const size_t elems = (size_t)a.M * g->N, n4 = elems / 4;
+        int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3(blocks), dim3(256), 0, st, n4, g->N, a.ksplit, elems, (const float*)a.part, a.bias,
+                           (const T*)a.add, (const T*)a.mask, a.dst, flags);
+    }
     return urso_check_launch("urso_conv_igemm");
+}
+
+extern "C" size_t urso_conv_igemm_ws_bytes(const urso_conv_geom* g, int dt) {
+    if (!g || g->FH > 0 || (g->N & 3)) return 0;
+    const int VE = 16 / (int)dt_size(dt);
+    if (g->C % VE) return 0;
+    const int M = g->B * g->OH * g->OW, nkt = ceil_div(g->KH * g->KW * (g->C / VE), 8);
+    const int bn = (g->N <= 64) ? 64 : 128;
+    int S, kps; plan_splitk(ceil_div(M, 128) * ceil_div(g->N, bn), nkt, device_cus(), S, kps);
+    return S > 1 ? (size_t)S * M * g->N * sizeof(float) : 0;
 }
 
 extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
                                const void* src_d, const void* wgt_d, const float* bias_d,
                                const void* add_d, const void* mask_d, void* dst_d, void* stream) {
+    return urso_conv_igemm_ws(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d, nullptr, 0, stream);
+}
+
+extern "C" int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
+                                  const void* src_d, const void* wgt_d, const float* bias_d,
+                                  const void* add_d, const void* mask_d, void* dst_d, void* ws_d, size_t ws_bytes, void* stream) {
     if (!g || !src_d || !wgt_d || !dst_d) { urso_set_error("urso_conv_igemm: null argument"); return URSO_EINVAL; }
     if (dt != URSO_F32 && dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_conv_igemm: bad dtype %d", dt); return URSO_EINVAL; }
     const size_t es = dt_size(dt);
@@ -378,7 +478,7 @@ extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
     double bytes = (double)src_bytes + (double)wgt_bytes + (double)dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
                    (add_d ? dst_elems * es : 0) + (mask_d ? dst_elems * es : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, st);
-    if (dt == URSO_BF16) return launch_igemm<__bf16>(g, flags, a, st);
-    return launch_igemm<_Float16>(g, flags, a, st);
+    if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, ws_d, ws_bytes, st);
+    if (dt == URSO_BF16) return launch_igemm<__bf16>(g, flags, a, ws_d, ws_bytes, st);
+    return launch_igemm<_Float16>(g, flags, a, ws_d, ws_bytes, st);
 }

@@ -164,6 +164,7 @@ class Engine(object):
 
         max_ws = 0
         max_fin_ws = 0
+        max_igemm_ws = 0
         for node in g.nodes:
             if node.op == "pool":
                 src, dst = act(node.src), act(node.dst)
@@ -233,12 +234,18 @@ class Engine(object):
                 self.labels["prep"].append("prep:" + node.name)
             # -- forward
             flags = (hip.EPI_RELU if node.relu else 0) | (hip.EPI_OUT_F32 if node.out_f32 else 0)
-            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm(c.gf, dt, f, c.src.data, c.wf, c.biasf,
-                                                                    c.res.data if c.res is not None else None, None, c.dst.data))
+            # split-K workspace (tiny-grid / deep-K layers: bottleneck_layer, Dense heads); 0 = not split
+            c.ws_f = hip.conv_igemm_ws_bytes(c.gf, dt)
+            c.ws_d = hip.conv_igemm_ws_bytes(c.gd, dt) if (c.gd is not None and training) else 0
+            max_igemm_ws = max(max_igemm_ws, c.ws_f, c.ws_d)
+            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ws(c.gf, dt, f, c.src.data, c.wf, c.biasf,
+                                                                       c.res.data if c.res is not None else None, None, c.dst.data,
+                                                                       self.igemm_ws if c.ws_f else None))
             self.labels["fwd"].append("fwd:" + node.name)
             if training:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(c.K_raw if not node.stem else 147, c.N))
+        self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
         self.out_loc = self.acts[g.outputs["loc"].id]
         self.out_ori = self.acts[g.outputs["ori"].id]
         self._build_heads_io()
@@ -308,7 +315,7 @@ class Engine(object):
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
-                                     hip.conv_igemm(c.gd, dt, 0, G, c.wd, None, add, mask, dstg)))
+                                     hip.conv_igemm_ws(c.gd, dt, 0, G, c.wd, None, add, mask, dstg, self.igemm_ws if c.ws_d else None)))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         # ---------------------------------------------------------------- optimizer

@@ -50,6 +50,8 @@ _SIGS = {
     "urso_last_error": (C.c_char_p, []),
     "urso_abi_version": (_i, []),
     "urso_conv_igemm": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp]),
+    "urso_conv_igemm_ws_bytes": (_sz, [_gp, _i]),
+    "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_wgrad": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
     "urso_conv_weight_prep": (_i, [_i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _vp, _fp, _fp, _vp]),
@@ -110,6 +112,16 @@ def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1, FH
 def conv_igemm(g, dt, flags, src, wgt, bias, add, mask, dst, stream=None):
     _chk(_lib.urso_conv_igemm(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
                               stream_ptr(stream)), "urso_conv_igemm")
+
+
+def conv_igemm_ws_bytes(g, dt):
+    return int(_lib.urso_conv_igemm_ws_bytes(C.byref(g), dt))
+
+
+def conv_igemm_ws(g, dt, flags, src, wgt, bias, add, mask, dst, ws, stream=None):
+    _chk(_lib.urso_conv_igemm_ws(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
+                                 ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, stream_ptr(stream)),
+         "urso_conv_igemm_ws")
 
 
 def conv_wgrad_ws_bytes(g, dt):
