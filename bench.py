@@ -94,7 +94,8 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("URSO_DP_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -107,7 +108,7 @@ def main():
     img, loc, ori, _ = synthetic_batch(cfg, args.batch, seed=1234 + rank)
     eng.load_batch(img, loc, ori)                  # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dp:
         from ursonet_amd.dp import DataParallelEngine
         runner = DataParallelEngine(eng)
     else:
@@ -132,7 +133,7 @@ def main():
         elapsed = float(t.item())
     losses = eng.losses()
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -160,8 +161,18 @@ def main():
     dname, (dn, dms, dfl, dby) = dom
     peak = PEAK_MFMA[args.dtype]
     achieved = dfl / (dms * 1e9) if dms > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
+    # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if pm.get("workload") == [args.backbone, args.batch, args.height, args.width, args.dtype]:
+            traffic = pm["igemm_hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(dms / dn, 4), "launches": dn // args.profile_steps,
                 "algorithmic_flops_per_launch": dfl / dn,
                 "whole_step_frac_of_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
@@ -177,13 +188,13 @@ def main():
                    "step_tflop": round(step_flops / 1e12, 3), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
         "roofline": roofline, "kernels": kernels,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline({"h": args.height, "w": args.width, "backbone": args.backbone, "ori_bins": args.ori_bins},
                                            args.cpu_sample_batch, args.cpu_steps)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
