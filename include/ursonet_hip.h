@@ -213,6 +213,22 @@ int urso_quat_wavg_decode(int B, int K, const float* logits_d, const float* hqua
                           float* q_d, float* a_d, void* stream);
 
 /*
+ * Rotation augmentation on the GPU ("next" scope row f-1; reference: utils.rotate_cam / rotate_image utils.py:30-86 called
+ * from load_image_gt net.py:415-438, and utils.encode_ori_fast utils.py:319-346 for the re-encoded target).
+ *   urso_warp_perspective: OpenCV warpPerspective arithmetic on uint8 images [B,H,W,C], constant-0 border.  M [B][9]
+ *     (fp64, row-major) maps DESTINATION pixels to source coordinates (the host inverts the forward homography, as
+ *     cv2 does when WARP_INVERSE_MAP is not set).  interp 0 = INTER_NEAREST (cvRound), 1 = INTER_LINEAR with cv2's
+ *     8-bit fixed point (1/32-pixel coordinates, 15-bit weights).  The reference's call
+ *     cv2.warpPerspective(image, M, (w, h), cv2.WARP_INVERSE_MAP) passes that constant in the `dst` slot of the Python
+ *     binding, so what runs is the default: forward M, INTER_LINEAR.
+ *   urso_encode_ori: out[b,:] = Gaussian soft assignment of quaternion q[b] (fp64 [B][4]) to the bin map hquat [K][4]
+ *     (kernel exp(-2 (acos(min(1,|q.h|))/pi)^2 / var)), redundant bins zeroed, normalised to a PMF (fp32 [B][K]).
+ */
+int urso_warp_perspective(int B, int H, int W, int C, int interp, const uint8_t* src_d, const double* m_d, uint8_t* dst_d, void* stream);
+int urso_encode_ori(int B, int K, const double* q_d, const float* hquat_d, const uint8_t* redundant_d, double var,
+                    float* out_d, void* stream);
+
+/*
  * Opt-in launch profiler: when enabled every urso_* launch is bracketed by HIP events on
  * its stream.  urso_prof_collect() synchronises and returns per-record milliseconds.
  */

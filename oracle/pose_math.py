@@ -254,3 +254,74 @@ def pose_errors(loc_est, q_est, loc_gt, q_gt):
     loc_err = np.linalg.norm(np.asarray(loc_est, dtype=np.float64).ravel() - np.asarray(loc_gt, dtype=np.float64).ravel())
     esa = loc_err / np.linalg.norm(loc_gt) + 2 * np.arccos(d)
     return ang, loc_err, esa
+
+
+# --------------------------------------------------------------------------
+# rotation augmentation (utils.py:30-86).  The image warp is OpenCV's (cv2 is absent here and on the GPU box), restated
+# from OpenCV's published warpPerspective / remap algorithm for 8-bit images.  What the reference's call runs:
+# `cv2.warpPerspective(image, M, (width, height), cv2.WARP_INVERSE_MAP)` -- in the Python binding the 4th positional
+# parameter is `dst`, not `flags` (signature: src, M, dsize[, dst[, flags[, borderMode[, borderValue]]]]), so the
+# constant lands in the output-array slot and the call runs with the DEFAULT flags: M is the forward map
+# (dst(p) = src(M^-1 p)), INTER_LINEAR, BORDER_CONSTANT 0.  This is also the only reading under which the warped image
+# agrees with the updated pose (K t_new = M K t; tests/test_augment_gpu.py checks it).
+# PARITY UNPINNED for the image part (no cv2 output to compare with); pinned for the pose update (se3lib goldens).
+# --------------------------------------------------------------------------
+def invert3x3(M):
+    """cv::invert of a 3x3 (closed form: adjugate / determinant), float64."""
+    M = np.asarray(M, dtype=np.float64).reshape(3, 3)
+    a, b, c, d, e, f, g, h, i = M.ravel()
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    adj = np.array([[e * i - f * h, c * h - b * i, b * f - c * e],
+                    [f * g - d * i, a * i - c * g, c * d - a * f],
+                    [d * h - e * g, b * g - a * h, a * e - b * d]])
+    return adj * (1.0 / det)
+
+
+def warp_perspective(image, M, inverse_map=False, interp="linear"):
+    """cv2.warpPerspective(image, M, (W, H), flags=interp | (WARP_INVERSE_MAP if inverse_map)) for uint8 images,
+    constant-0 border.  Per destination pixel (Python loop over pixels: the checker, small images only).
+      nearest: src(cvRound(X/W), cvRound(Y/W));
+      linear : coordinates quantised to 1/32 pixel (cvRound(32 X/W)), taps weighted by the 15-bit table
+               w = round((1-ax/32)(1-ay/32) 2^15) ..., result (sum + 2^14) >> 15; taps outside the image read 0."""
+    image = np.asarray(image)
+    assert image.dtype == np.uint8
+    H, W = image.shape[:2]
+    Mi = np.asarray(M, dtype=np.float64).reshape(3, 3) if inverse_map else invert3x3(M)
+    out = np.zeros_like(image)
+    scale = 32.0 if interp == "linear" else 1.0
+    lo, hi = -2147483648.0, 2147483647.0
+
+    def tap(yy, xx):
+        if 0 <= yy < H and 0 <= xx < W:
+            return image[yy, xx].astype(np.int64)
+        return np.zeros(image.shape[2:], dtype=np.int64)
+
+    for y in range(H):
+        for x in range(W):
+            X = Mi[0, 0] * x + Mi[0, 1] * y + Mi[0, 2]
+            Y = Mi[1, 0] * x + Mi[1, 1] * y + Mi[1, 2]
+            Wd = Mi[2, 0] * x + Mi[2, 1] * y + Mi[2, 2]
+            w = scale / Wd if Wd != 0 else 0.0
+            qx = int(np.rint(min(max(X * w, lo), hi)))          # cvRound: half to even
+            qy = int(np.rint(min(max(Y * w, lo), hi)))
+            if interp != "linear":
+                out[y, x] = tap(qy, qx)
+                continue
+            sx, sy, ax, ay = qx >> 5, qy >> 5, qx & 31, qy & 31
+            tab = np.array([(1 - ax / 32.0) * (1 - ay / 32.0), (ax / 32.0) * (1 - ay / 32.0),
+                            (1 - ax / 32.0) * (ay / 32.0), (ax / 32.0) * (ay / 32.0)], dtype=np.float32)
+            wt = np.rint(tab * np.float32(32768)).astype(np.int64)          # exact: multiples of 32 summing to 2^15
+            acc = wt[0] * tap(sy, sx) + wt[1] * tap(sy, sx + 1) + wt[2] * tap(sy + 1, sx) + wt[3] * tap(sy + 1, sx + 1)
+            out[y, x] = ((acc + (1 << 14)) >> 15).astype(np.uint8)
+    return out
+
+
+def rotate_cam_given(image, t, q, K, pyr_change):
+    """utils.rotate_cam (utils.py:30-58) / rotate_image (:60-86) for a GIVEN Euler perturbation (deg)."""
+    R = euler2SO3_left(pyr_change[0], pyr_change[1], pyr_change[2])
+    K = np.asarray(K, dtype=np.float64)
+    M = K @ R @ np.linalg.inv(K)
+    warped = warp_perspective(image, M)
+    t_new = np.asarray(t, dtype=np.float64) @ R.T
+    q_new = quat_mult(SO32quat(R), q)
+    return warped, t_new, q_new

@@ -1,0 +1,131 @@
+"""Rotation augmentation on the GPU (scope row f-1): urso_encode_ori against the reference's own
+encode_ori_fast outputs (golden), urso_warp_perspective against the oracle restatement of
+cv2.warpPerspective (parity unpinned for the image part: cv2 is absent), and
+net.load_image_gt(ROT_AUG / ROT_IMAGE_AUG) end to end against the oracle with the same RNG draws."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import make_config
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_encode_ori_kernel_against_reference_golden(n):
+    from ursonet_amd import augment as A
+    g = np.load(os.path.join(GOLD, "ori_codec.npz"))
+    beta = json.load(open(os.path.join(GOLD, "meta.json")))["beta"]
+    out = A.encode_orientations(g["oris"], g["Hquat_%d" % n], g["red_%d" % n], beta).cpu().numpy()
+    fast = g["fast_%d" % n]                                   # float64 PMFs from utils.encode_ori_fast
+    assert out.dtype == np.float32 and out.shape == fast.shape
+    assert np.abs(out - fast).max() <= 1e-7 + 1e-6 * fast.max()
+    assert np.abs(out - g["enc_%d" % n]).max() <= 2e-7        # float32 rows of utils.encode_ori
+    assert np.all(out[:, g["red_%d" % n].astype(bool)] == 0)
+    assert np.allclose(out.sum(1), 1, atol=1e-5)
+    assert np.array_equal(out.argmax(1), fast.argmax(1))
+
+
+def test_encode_ori_kernel_full_resolution_properties():
+    """ori_resolution 24 (13824 bins, BASELINE configs[3]): PMF properties and the peak bin = nearest bin."""
+    from ursonet_amd import augment as A
+    from ursonet_amd.pose import OrientationCodec
+    codec = OrientationCodec(24, 6.0)
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=(16, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    out = A.encode_orientations(q, codec.H_quat, codec.redundant, 6.0).cpu().numpy()
+    ref = codec.encode(q, dtype=np.float64)
+    assert np.abs(out - ref).max() <= 1e-6 * ref.max() + 1e-7
+    assert np.allclose(out.sum(1), 1, atol=1e-5) and np.all(out[:, codec.redundant] == 0)
+
+
+@pytest.mark.parametrize("interp", ["linear", "nearest"])
+@pytest.mark.parametrize("shape", [(2, 48, 64, 3), (1, 60, 80, 1), (3, 33, 47, 3)])
+def test_warp_kernel_against_oracle(shape, interp):
+    from ursonet_amd import augment as A
+    from ursonet_amd.dataset import Camera
+    from oracle import pose_math as P
+    B, H, W, C = shape
+    rng = np.random.default_rng(B * 100 + H)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    cam = Camera(W, H)
+    pyr = (rng.random((B, 3)) - 0.5) * np.array([20, 20, 170])
+    Ms = np.stack([A.rotation_homography(cam.K, A.euler2SO3_left(*p)) for p in pyr])
+    out = A.warp_images(img, Ms, interp=interp).cpu().numpy()
+    for b in range(B):
+        ref = P.warp_perspective(img[b], Ms[b], interp=interp)
+        mism = (out[b] != ref).any(-1).mean()
+        assert mism == 0.0, "sample %d: %.4f%% of pixels differ" % (b, 100 * mism)
+        assert (ref == 0).all(-1).mean() < 0.9                 # the case really samples the image
+        inv = A.warp_images(img[b:b + 1], P.invert3x3(Ms[b])[None], inverse_map=True, interp=interp).cpu().numpy()[0]
+        assert (inv != ref).any(-1).mean() < 0.002             # same map handed over pre-inverted (1-ulp coordinate ties only)
+    ident = A.warp_images(img, np.tile(np.eye(3), (B, 1, 1)), interp=interp).cpu().numpy()
+    assert np.array_equal(ident, img)
+    shift = np.array([[1, 0, 2.0], [0, 1, -3.0], [0, 0, 1]])   # inverse map: dst(x,y) = src(x+2, y-3), zero outside
+    sh = A.warp_images(img, np.tile(shift, (B, 1, 1)), inverse_map=True, interp=interp).cpu().numpy()
+    assert np.array_equal(sh[:, 3:, :W - 2], img[:, :H - 3, 2:]) and (sh[:, :3] == 0).all() and (sh[:, :, W - 2:] == 0).all()
+    half = np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1]])     # dst(x,y) = src(x+0.5, y): average of neighbours, rounded half up
+    if interp == "linear":
+        hf = A.warp_images(img, np.tile(half, (B, 1, 1)), inverse_map=True).cpu().numpy()
+        exp = (img[:, :, :-1].astype(int) + img[:, :, 1:].astype(int) + 1) >> 1
+        assert np.array_equal(hf[:, :, :-1], exp)
+
+
+def test_rotate_cam_batch_pose_and_image_consistency():
+    """Rotating the camera moves the projection of the object's centre exactly as the warp moves pixels."""
+    from ursonet_amd import augment as A
+    from ursonet_amd.dataset import Camera
+    H, W = 240, 320
+    cam = Camera(W, H)
+    t = np.array([[0.4, -0.3, 8.0]])
+    q = np.array([[0.0, 0.0, 0.0, 1.0]])
+    # the reference's convention: pixel = K [x/z, y/z, 1] with fy < 0
+    u0 = cam.K @ (t[0] / t[0, 2])
+    img = np.zeros((1, H, W, 3), dtype=np.uint8)
+    cx, cy = int(round(u0[0])), int(round(u0[1]))
+    img[0, cy - 2:cy + 3, cx - 2:cx + 3] = 255
+    pyr = np.array([[4.0, -6.0, 10.0]])
+    out, tn, qn = A.rotate_cam_batch(img, t, q, cam.K, pyr)
+    out = out.cpu().numpy()
+    ys, xs = np.nonzero(out[0, :, :, 0])
+    assert len(ys) > 0
+    u1 = cam.K @ (tn[0] / tn[0, 2])
+    assert abs(xs.mean() - u1[0]) < 1.5 and abs(ys.mean() - u1[1]) < 1.5
+    assert abs(np.linalg.norm(qn[0]) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["cam_class", "image_regress"])
+def test_load_image_gt_rotation_augmentation_matches_oracle(mode):
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    from oracle import pose_math as P
+    regress = mode == "image_regress"
+    cfg = make_config("resnet18", 64, 128, batch=2, regress_ori=regress, ori_bins=8)
+    cfg.ROT_AUG, cfg.ROT_IMAGE_AUG = (mode == "cam_class"), regress
+    ds = SyntheticPoses(5, 64, 128, cfg, seed=2)
+    hit = 0
+    for seed in range(8):
+        np.random.seed(seed)
+        img, meta, loc, ori = net.load_image_gt(ds, cfg, 1)
+        np.random.seed(seed)
+        dice = np.random.rand(1)
+        raw, t0, q0 = ds.load_image(1), ds.load_location(1), ds.load_quaternion(1)
+        apply = (dice > 0.5) if mode == "cam_class" else (dice <= 0.5)
+        if not apply:
+            assert np.array_equal(img, raw) and np.array_equal(loc, t0)
+            continue
+        hit += 1
+        pyr = (np.random.rand(3) - 0.5) * 20 if mode == "cam_class" else np.array([0, 0, ((np.random.rand(1) - 0.5) * 170)[0]])
+        w, tn, qn = P.rotate_cam_given(raw, t0, q0, ds.camera.K, pyr)
+        assert np.array_equal(img, w) and not np.array_equal(img, raw)
+        assert np.allclose(loc, tn, atol=1e-12)
+        if regress:
+            assert np.allclose(ori, qn, atol=1e-12)
+        else:
+            ref = P.encode_ori_fast(qn, cfg.BETA, ds.ori_histogram_map, ds.ori_output_mask)
+            assert np.abs(ori - ref).max() <= 1e-6 * ref.max() + 1e-7
+    assert hit >= 2

@@ -182,9 +182,30 @@ def test_data_generator_and_mold_image():
     assert np.abs(net.unmold_image(imgs[0], cfg).astype(int) - raw.astype(int)).max() <= 1
     img, m, loc, ori = net.load_image_gt(ds, cfg, 2)
     assert m[0] == 2 and tuple(m[1:4]) == (64, 128, 3) and tuple(m[7:11]) == (0, 0, 64, 128)
-    cfg.ROT_AUG = True
+    cfg.SIM2REAL_AUG = True
     with pytest.raises(NotImplementedError):
         net.load_image_gt(ds, cfg, 0)
+
+
+def test_augment_host_math_matches_reference_goldens():
+    """ursonet_amd.augment's se3 helpers against the reference's own outputs (tests/golden/se3lib_basic.npz)."""
+    from ursonet_amd import augment as A
+    from ursonet_amd.dataset import Camera
+    from oracle import pose_math as P
+    g = np.load(os.path.join(ROOT, "tests", "golden", "se3lib_basic.npz"))
+    for i in range(len(g["eul"])):
+        R = A.euler2SO3_left(*g["eul"][i])
+        assert np.array_equal(R, g["e2R"][i])
+        assert np.allclose(A.SO32quat(g["e2R"][i]), g["R2q"][i], rtol=0, atol=1e-15)
+        assert np.allclose(A.quat_mult(g["qs"][i], g["qs2"][i]), g["qmul"][i], rtol=0, atol=1e-15)
+        t = np.array([0.3, -0.2, 7.0])
+        tn, qn = A.rotate_pose(t, g["qs2"][i], R)
+        assert np.allclose(tn, t @ g["e2R"][i].T) and abs(np.linalg.norm(tn) - np.linalg.norm(t)) < 1e-12
+        assert np.allclose(qn, P.quat_mult(P.SO32quat(R), g["qs2"][i]), atol=1e-15)
+    cam = Camera()                                                           # urso.py:12-22
+    assert abs(cam.fx - 640.0) < 1e-9 and cam.fy < 0 and np.allclose(cam.K[:2, 2], [640, 480])
+    M = A.rotation_homography(cam.K, np.eye(3))
+    assert np.allclose(M, np.eye(3), atol=1e-12)
 
 
 # ------------------------------------------------------------------ C ABI

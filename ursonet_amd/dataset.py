@@ -47,6 +47,18 @@ class Dataset(object):
         return self.image_info[image_id]["ori_map"]
 
 
+class Camera(object):
+    """Pinhole intrinsics from the fields of view, as the reference's dataset modules define them
+    (urso.py:12-22, speed.py:15-25): fx = W / (2 tan(fov_x/2)), fy = -H / (2 tan(fov_y/2)), principal point at the centre."""
+
+    def __init__(self, width=1280, height=960, fov_x=90.0, fov_y=73.7):
+        self.width, self.height = width, height
+        self.fov_x, self.fov_y = fov_x * np.pi / 180, fov_y * np.pi / 180
+        self.fx = width / (2 * np.tan(self.fov_x / 2))
+        self.fy = -height / (2 * np.tan(self.fov_y / 2))
+        self.K = np.array([[self.fx, 0, width / 2], [0, self.fy, height / 2], [0, 0, 1]])
+
+
 class SyntheticPoses(Dataset):
     """`n` synthetic images of `height` x `width` (uint8 RGB) generated on the fly from a seed."""
 
@@ -54,6 +66,7 @@ class SyntheticPoses(Dataset):
         super(SyntheticPoses, self).__init__()
         self.name = "Synthetic"
         self.height, self.width, self.seed = height, width, seed
+        self.camera = Camera(width, height)
         rng = np.random.default_rng(seed)
         q = rng.normal(size=(n, 4)).astype(np.float32)
         q /= np.linalg.norm(q, axis=1, keepdims=True)

@@ -72,6 +72,8 @@ _SIGS = {
     "urso_sgd_momentum_clip": (_i, [_sz, _fp, _fp, _fp, _fp, _fp, _vp]),
     "urso_scale_f32": (_i, [_sz, _fp, _f, _vp]),
     "urso_quat_wavg_decode": (_i, [_i, _i, _fp, _fp, _fp, _fp, _vp]),
+    "urso_warp_perspective": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "urso_encode_ori": (_i, [_i, _i, _vp, _fp, _vp, C.c_double, _fp, _vp]),
     "urso_prof_enable": (_i, [_i]),
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
 }
@@ -215,6 +217,16 @@ def scale_f32(n, x, s, stream=None):
 def quat_wavg_decode(B, K, logits, hquat, q, a=None, stream=None):
     _chk(_lib.urso_quat_wavg_decode(B, K, ptr(logits), ptr(hquat), ptr(q), ptr(a), stream_ptr(stream)),
          "urso_quat_wavg_decode")
+
+
+def warp_perspective(B, H, W, Cc, interp, src, m, dst, stream=None):
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and m.dtype == torch.float64
+    _chk(_lib.urso_warp_perspective(B, H, W, Cc, int(interp), ptr(src), ptr(m), ptr(dst), stream_ptr(stream)), "urso_warp_perspective")
+
+
+def encode_ori(B, K, q, hquat, redundant, var, out, stream=None):
+    assert q.dtype == torch.float64 and redundant.dtype == torch.uint8
+    _chk(_lib.urso_encode_ori(B, K, ptr(q), ptr(hquat), ptr(redundant), float(var), ptr(out), stream_ptr(stream)), "urso_encode_ori")
 
 
 def prof_enable(on):

@@ -97,9 +97,8 @@ def unmold_image(normalized_images, config):
 #  Data generator (net.py:358-559)
 ############################################################
 def load_image_gt(dataset, config, image_id):
-    """Image + pose targets for one sample.  The rotation / sim2real augmentations of the reference
-    (cv2 / imgaug, net.py:390-438) are not implemented yet: asking for them raises instead of
-    silently training on un-augmented data."""
+    """Image + pose targets for one sample (net.py:363-461).  ROT_AUG / ROT_IMAGE_AUG warp on the GPU;
+    SIM2REAL_AUG (imgaug) raises instead of silently training on un-augmented data."""
     image = dataset.load_image(image_id)
     loc = dataset.load_location(image_id) if config.REGRESS_LOC else dataset.load_location_encoded(image_id)
     if config.REGRESS_KEYPOINTS:
@@ -114,9 +113,27 @@ def load_image_gt(dataset, config, image_id):
             ori = dataset.load_angle_axis(image_id)
     else:
         ori = dataset.load_orientation_encoded(image_id)
-    if config.SIM2REAL_AUG or config.ROT_AUG or config.ROT_IMAGE_AUG:
-        raise NotImplementedError("SIM2REAL_AUG / ROT_AUG / ROT_IMAGE_AUG are not implemented in this build "
-                                  "(GPU-resident augmentation is the next scope row)")
+    if config.SIM2REAL_AUG:
+        raise NotImplementedError("SIM2REAL_AUG (imgaug pipeline, net.py:390-413) is not implemented in this build")
+    if config.ROT_AUG or config.ROT_IMAGE_AUG:
+        # net.py:415-438: camera-rotation / in-plane-rotation warps (mutually exclusive, one dice throw); the warp and
+        # the target re-encode run on the GPU (ursonet_amd.augment), same NumPy global-RNG draws as the reference
+        assert config.REGRESS_LOC
+        assert config.ORIENTATION_PARAM == 'quaternion'
+        if config.REGRESS_KEYPOINTS:
+            raise NotImplementedError("rotation augmentation with REGRESS_KEYPOINTS (utils.encode_as_keypoints) is not implemented")
+        from . import augment
+        dice = np.random.rand(1)
+        which = "cam" if (config.ROT_AUG and dice > 0.5) else ("image" if (config.ROT_IMAGE_AUG and dice <= 0.5) else None)
+        if which is not None:
+            if not config.REGRESS_ORI:
+                ori = dataset.load_quaternion(image_id)
+            if which == "cam":
+                image, loc, ori = augment.rotate_cam(image, loc, ori, dataset.camera.K, 20)
+            else:
+                image, loc, ori = augment.rotate_image(image, loc, ori, dataset.camera.K)
+            if not config.REGRESS_ORI:
+                ori = augment.encode_orientations(ori, dataset.ori_histogram_map, dataset.ori_output_mask, config.BETA)[0].cpu().numpy()
     original_shape = image.shape
     image, window, scale, padding, crop = utils.resize_image(
         image, min_dim=config.IMAGE_MIN_DIM, min_scale=config.IMAGE_MIN_SCALE, max_dim=config.IMAGE_MAX_DIM,
