@@ -147,6 +147,41 @@ int urso_param_grad_finalize(int K, int N, int ldn /* row stride of dw_raw (= np
                              float* ws_d, size_t ws_bytes, void* stream);
 size_t urso_param_grad_finalize_ws_bytes(int K, int N);
 
+/*
+ * Batched parameter-side phases.  ResNet-50 has 58 weight layers; per-layer launches of the four small kernels above
+ * (weight prep, split reduction of the weight-gradient partials, the two finalisation passes) cost ~2 ms of a 14.6 ms
+ * step in launch latency.  One urso_param_desc per layer (plain C, device pointers) lives in a device array; a host-built
+ * block map (2 x int32 per block: layer index, local block id) lets ONE launch per phase cover any subset of layers,
+ * e.g. all layers of one gradient bucket.  Arithmetic and summation order are those of the per-layer entry points.
+ *   urso_conv_wgrad_partial  : urso_conv_wgrad without the split reduction; ws_d = part[splits][K][npad] fp32 followed by
+ *                              colpart[splits][npad] (urso_conv_wgrad_ws_bytes).  urso_conv_wgrad_splits gives `splits`.
+ *   urso_param_desc_init     : fills geometry, k-slab plan and L2 coefficients (regc = 2 wd/(K N), regb = 2 wd/N).
+ *   urso_param_batch_plan    : host; writes the block map for `phase` over descs_h[layer_ids[0..n_ids)] and returns the
+ *                              block count (call with blockmap_h = NULL to size it).
+ *   urso_param_batch_run     : device; one launch.  Phases run in enum order for a set of layers; FINALIZE_* read
+ *                              `part`/`colpart` directly when splits == 1 (REDUCE then emits no blocks for that layer).
+ */
+typedef struct urso_param_desc {
+    int32_t KH, KW, C, N, npad, K;        /* K = KH*KW*C; dw rows and wd rows have stride npad, w and gw rows stride N */
+    int32_t splits, ks, kb;               /* wgrad partial count; finalisation k-slabs */
+    int32_t trainable, bn_trainable;
+    float eps, regc, regb;
+    const float *w, *b, *gamma, *beta, *mean, *var;     /* fp32 parameters (b / BN tensors may be NULL) */
+    void *wf, *wd;                                       /* compute-dtype layouts written by PREP (wd may be NULL) */
+    float *biasf, *scale;
+    const float *part, *colpart;                         /* wgrad partials */
+    float *dw_raw, *colsum, *dotpart;                    /* REDUCE outputs; FINALIZE_MAT scratch [ks][N] */
+    float *gw, *gb, *ggamma, *gbeta;                     /* gradient slices (gb / ggamma+gbeta may be NULL) */
+} urso_param_desc;
+enum { URSO_PB_PREP = 0, URSO_PB_REDUCE = 1, URSO_PB_FINALIZE_MAT = 2, URSO_PB_FINALIZE_VEC = 3 };
+int urso_conv_wgrad_splits(const urso_conv_geom* g, int dt);
+int urso_conv_wgrad_partial(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                            void* ws_d, size_t ws_bytes, void* stream);
+int urso_param_desc_init(urso_param_desc* d, int KH, int KW, int C, int N, int npad, int splits, float eps, float weight_decay);
+int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32_t* layer_ids, int n_ids,
+                          int32_t* blockmap_h, int cap_blocks);
+int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream);
+
 /* Input molding (mold_image, net.py:1337-1348): dst[b,h,w,0..3] = (src[b,h,w,c] - mean[c], 0) in dt.
  * src is uint8 (src_is_u8=1) or float32 [B,H,W,3]; mean may be NULL (already molded). */
 int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,

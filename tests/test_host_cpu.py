@@ -223,7 +223,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "symbol %s declared in include/ursonet_hip.h is not exported" % s
     assert set(syms) == set(hip.EXPORTED_SYMBOLS), set(syms) ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip._lib.urso_abi_version() == 2
+    assert hip._lib.urso_abi_version() == 3
 
 
 def test_cabi_argument_validation_without_gpu():

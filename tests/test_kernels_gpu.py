@@ -410,3 +410,71 @@ def test_quat_weighted_average_decode_against_golden():
         dots = np.abs((q.cpu().numpy() * qref).sum(-1))
         assert dots.min() > 1 - 1e-5, dots
         assert np.abs(A.cpu().numpy().reshape(B, 4, 4) - Aref).max() < 2e-5
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_batched_param_phases_equal_per_layer_entry_points(dt):
+    """urso_param_batch_run (prep / split reduction / finalisation over several layers in ONE launch each) is
+    bit-identical to the per-layer entry points, including a layer whose wgrad is not split."""
+    hip = _hip()
+    torch.manual_seed(5)
+    tdt = hip.TORCH_DT[dt]
+    wd_ = 1e-3
+    layers = [dict(KH=3, KW=3, C=32, N=40, npad=40, B=4, H=48, W=40, bn=True, bias=False),
+              dict(KH=1, KW=1, C=64, N=24, npad=24, B=2, H=40, W=36, bn=True, bias=True),
+              dict(KH=1, KW=1, C=16, N=13, npad=16, B=3, H=1, W=1, bn=False, bias=True)]         # dense head, single split
+    descs, keep, ref = [], [], []
+    for L in layers:
+        KH, KW, Ci, N, NP = L["KH"], L["KW"], L["C"], L["N"], L["npad"]
+        K = KH * KW * Ci
+        w = dev(torch.randn(K, N)); b = dev(torch.randn(N)) if L["bias"] else None
+        bn = [dev(t) for t in (torch.rand(N) + 0.5, torch.randn(N), torch.randn(N), torch.rand(N) + 0.5)] if L["bn"] else [None] * 4
+        g = hip.geom(L["B"], L["H"], L["W"], Ci, L["H"], L["W"], NP, KH, KW, 1, 1, KH // 2, KW // 2)
+        x = dev(torch.randn(L["B"], L["H"], L["W"], Ci)).to(tdt)
+        dz = dev(torch.randn(L["B"], L["H"], L["W"], NP)).to(tdt)
+        if NP > N:
+            dz[..., N:] = 0
+        # ---- per-layer reference path
+        wf = torch.empty(NP * K, dtype=tdt, device="cuda"); wdl = torch.empty(NP * K, dtype=tdt, device="cuda")
+        biasf = torch.empty(NP, device="cuda"); scale = torch.empty(NP, device="cuda")
+        hip.conv_weight_prep(KH, KW, Ci, N, NP, dt, w, b, bn[0], bn[1], bn[2], bn[3], 1e-3, wf, wdl, biasf, scale)
+        ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 64, device="cuda")
+        dwr = torch.empty(K * NP, device="cuda"); cs = torch.empty(NP, device="cuda")
+        hip.conv_wgrad(g, dt, x, dz, ws, dwr, cs)
+        gw = torch.empty(K * N, device="cuda"); gb = torch.empty(N, device="cuda") if L["bias"] else None
+        gg = torch.empty(N, device="cuda") if L["bn"] else None; gbe = torch.empty(N, device="cuda") if L["bn"] else None
+        fws = torch.empty(hip.param_grad_finalize_ws_bytes(K, N) // 4 + 64, device="cuda")
+        hip.param_grad_finalize(K, N, NP, dwr, cs, w, b, bn[0], bn[2], bn[3], 1e-3, wd_, 1, 1, gw, gb, gg, gbe, fws)
+        ref.append((wf, wdl, biasf, scale, gw, gb, gg, gbe))
+        # ---- batched path
+        d = hip.ParamDesc()
+        splits = hip.conv_wgrad_splits(g, dt)
+        hip.param_desc_init(d, KH, KW, Ci, N, NP, splits, 1e-3, wd_)
+        t = dict(wf=torch.empty_like(wf), wd=torch.empty_like(wdl), biasf=torch.empty_like(biasf), scale=torch.empty_like(scale),
+                 ws=torch.empty_like(ws), dw_raw=torch.empty_like(dwr), colsum=torch.empty_like(cs),
+                 dotpart=torch.empty(d.ks * N + 16, device="cuda"), gw=torch.empty_like(gw),
+                 gb=torch.empty_like(gb) if gb is not None else None, gg=torch.empty_like(gg) if gg is not None else None,
+                 gbe=torch.empty_like(gbe) if gbe is not None else None, x=x, dz=dz, g=g, w=w, b=b, bn=bn)
+        keep.append(t)
+        for f, v in (("w", w), ("b", b), ("gamma", bn[0]), ("beta", bn[1]), ("mean", bn[2]), ("var", bn[3]), ("wf", t["wf"]),
+                     ("wd", t["wd"]), ("biasf", t["biasf"]), ("scale", t["scale"]), ("dw_raw", t["dw_raw"]), ("colsum", t["colsum"]),
+                     ("dotpart", t["dotpart"]), ("gw", t["gw"]), ("gb", t["gb"]), ("ggamma", t["gg"]), ("gbeta", t["gbe"])):
+            setattr(d, f, hip.ptr(v))
+        d.part = t["ws"].data_ptr(); d.colpart = t["ws"].data_ptr() + 4 * splits * K * NP
+        d.trainable, d.bn_trainable = 1, 1
+        descs.append(d)
+    assert descs[0].splits > 1 and descs[2].splits == 1
+    pb = hip.ParamBatch(descs, torch.device("cuda"))
+    ids = list(range(len(descs)))
+    for ph in (hip.PB_PREP, hip.PB_REDUCE, hip.PB_FINALIZE_MAT, hip.PB_FINALIZE_VEC):
+        assert pb.plan(ph, "t", ids) > 0
+    pb.run(hip.PB_PREP, "t", dt)
+    for t in keep:
+        hip.conv_wgrad_partial(t["g"], dt, t["x"], t["dz"], t["ws"])
+    for ph in (hip.PB_REDUCE, hip.PB_FINALIZE_MAT, hip.PB_FINALIZE_VEC):
+        pb.run(ph, "t", dt)
+    torch.cuda.synchronize()
+    for t, r in zip(keep, ref):
+        for got, exp in zip((t["wf"], t["wd"], t["biasf"], t["scale"], t["gw"], t["gb"], t["gg"], t["gbe"]), r):
+            if exp is not None:
+                assert torch.equal(got, exp)

@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
 // float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
 // sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
+__device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
     __shared__ f32x4_t red[16][17];
     const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const size_t q = (size_t)blockIdx.x * 16 + col;          // float4 index
+    const size_t q = (size_t)bid * 16 + col;          // float4 index
     const size_t nq = (count + 3) / 4;
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     const bool full = (q * 4 + 3 < count);
@@ -235,6 +235,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
             for (size_t e = q * 4; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * count + e]; out[e] = t; }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
+    reduce_partials_body(blockIdx.x, part, out, count, splits);
+}
+
+// Batched over layers (see urso_param_batch_run): a layer's first blocks reduce its weight partials, the rest its column sums.
+__global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+    const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
+    const int local = blockmap[2 * blockIdx.x + 1];
+    const size_t cnt = (size_t)d.K * d.npad;
+    const int nb_dw = (int)(((cnt + 3) / 4 + 15) / 16);
+    if (local < nb_dw) reduce_partials_body(local, d.part, d.dw_raw, cnt, d.splits);
+    else reduce_partials_body(local - nb_dw, d.colpart, d.colsum, (size_t)d.npad, d.splits);
+}
+
+void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
 }
 
 struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split; size_t part_elems, col_elems; };
@@ -270,9 +288,15 @@ extern "C" size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt) {
     return (p.part_elems + p.col_elems) * sizeof(float) + 256;
 }
 
-extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
-                               void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream) {
-    if (!g || !x_d || !dz_d || !ws_d || !dw_raw_d) { urso_set_error("urso_conv_wgrad: null argument"); return URSO_EINVAL; }
+extern "C" int urso_conv_wgrad_splits(const urso_conv_geom* g, int dt) {
+    WgradPlan p;
+    if (!g || plan_wgrad(g, dt, p) != URSO_OK) return 0;
+    return p.splits;
+}
+
+static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                      void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, bool keep_partials, void* stream) {
+    if (!g || !x_d || !dz_d || !ws_d || (!dw_raw_d && !keep_partials)) { urso_set_error("urso_conv_wgrad: null argument"); return URSO_EINVAL; }
     if (dt != URSO_F32 && dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_conv_wgrad: bad dtype"); return URSO_EINVAL; }
     if (g->DH != 1 || g->DW != 1) { urso_set_error("urso_conv_wgrad: expects the forward geometry (D=1)"); return URSO_EINVAL; }
     WgradPlan p;
@@ -285,9 +309,9 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
     WgradArgs a;
     a.x = x_d; a.dz = dz_d; a.x_bytes = (uint32_t)x_bytes; a.dz_bytes = (uint32_t)dz_bytes;
     float* part = (float*)ws_d; float* colpart = part + p.part_elems;
-    const bool direct = (p.splits == 1);
+    const bool direct = (p.splits == 1) && !keep_partials;
     a.part = direct ? dw_raw_d : part;
-    a.colpart = colsum_d ? (direct ? colsum_d : colpart) : nullptr;
+    a.colpart = keep_partials ? colpart : (colsum_d ? (direct ? colsum_d : colpart) : nullptr);
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.OH = g->OH; a.OW = g->OW; a.N = g->N;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
     a.dbg = 0;
@@ -309,7 +333,7 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
 #undef URSO_WG
     int rc = urso_check_launch("urso_conv_wgrad");
     if (rc != URSO_OK) return rc;
-    if (!direct) {
+    if (!direct && !keep_partials) {
         size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
         int blocks = (int)(((cnt + 3) / 4 + 15) / 16);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits);
@@ -317,4 +341,16 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;
+}
+
+extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                               void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream) {
+    return wgrad_impl(g, dt, x_d, dz_d, ws_d, ws_bytes, dw_raw_d, colsum_d, false, stream);
+}
+
+// Partials only: part[splits][K][N] followed by colpart[splits][N] in ws_d (layout of urso_conv_wgrad_ws_bytes); the
+// fixed-order sum over splits is left to urso_param_batch_run(URSO_PB_REDUCE), batched over many layers.
+extern "C" int urso_conv_wgrad_partial(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
+                                       void* ws_d, size_t ws_bytes, void* stream) {
+    return wgrad_impl(g, dt, x_d, dz_d, ws_d, ws_bytes, nullptr, nullptr, true, stream);
 }

@@ -12,13 +12,13 @@ __device__ __forceinline__ float bn_scale(const float* gamma, const float* var, 
 // One block = one (tap, 32-channel, 32-filter) tile: reads W[tap][c][n] coalesced along n, writes
 // wd[c][ftap][n] coalesced along n and wf[n][tap][c] coalesced along c through an LDS transpose.
 template <typename T>
-__global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
+__device__ __forceinline__ void weight_prep_body(int bx, int by, int tap, int KH, int KW, int C, int N, int npad,
                                    const float* __restrict__ w, const float* __restrict__ b,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                    void* wf, void* wd, float* biasf, float* scale) {
     __shared__ float tile[32][33];
-    const int tap = blockIdx.z, c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int c0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads: 32 x 8
     const int taps = KH * KW;
     const int ftap = taps - 1 - tap;                               // (KH-1-ky)*KW + (KW-1-kx)
@@ -36,7 +36,7 @@ __global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
         const int nn = n0 + ny, c = c0 + tx;
         if (nn < npad && c < C) store_elem<T>(wf, ((size_t)nn * taps + tap) * C + c, tile[tx][ny]);
     }
-    if (tap == 0 && blockIdx.x == 0 && ty == 0 && n < npad) {
+    if (tap == 0 && bx == 0 && ty == 0 && n < npad) {
         float bf = 0.f, sc = 1.f;
         if (n < N) {
             sc = s;
@@ -45,6 +45,26 @@ __global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
         }
         biasf[n] = bf; scale[n] = sc;
     }
+}
+
+template <typename T>
+__global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
+                                   const float* __restrict__ w, const float* __restrict__ b,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                   void* wf, void* wd, float* biasf, float* scale) {
+    weight_prep_body<T>(blockIdx.x, blockIdx.y, blockIdx.z, KH, KW, C, N, npad, w, b, gamma, beta, mean, var, eps, wf, wd, biasf, scale);
+}
+
+// Batched form: blockmap[2*blockIdx.x] = layer index into descs, [2*blockIdx.x+1] = that layer's local block id.
+template <typename T>
+__global__ void weight_prep_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+    const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
+    const int local = blockmap[2 * blockIdx.x + 1];
+    const int gx = ceil_div(d.C, 32), gy = ceil_div(d.npad, 32);
+    const int bx = local % gx, by = (local / gx) % gy, tap = local / (gx * gy);
+    weight_prep_body<T>(bx, by, tap, d.KH, d.KW, d.C, d.N, d.npad, d.w, d.b, d.gamma, d.beta, d.mean, d.var, d.eps,
+                        d.wf, d.wd, d.biasf, d.scale);
 }
 
 extern "C" int urso_conv_weight_prep(int KH, int KW, int C, int N, int npad, int dt,
@@ -120,13 +140,13 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
 
 // ------------------------------------------------------------------ parameter-gradient finalisation
 // pass 1: grid (ceil(N/64), KS): gW = s*dw_raw + c*W, partial column dots of W*dw_raw
-__global__ void finalize_mat_kernel(int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
+__device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
                                     const float* __restrict__ gamma, const float* __restrict__ var, float eps,
                                     float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
     __shared__ float red[4][64];
     const int tn = threadIdx.x & 63, tk = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + tn;
-    const int kbeg = blockIdx.y * kb, kend = min(K, kbeg + kb);
+    const int n = bx * 64 + tn;
+    const int kbeg = by * kb, kend = min(K, kbeg + kb);
     float dot = 0.f;
     if (n < N) {
         const float s = bn_scale(gamma, var, eps, n);
@@ -138,16 +158,29 @@ __global__ void finalize_mat_kernel(int K, int N, int ldn, int kb, const float* 
     }
     red[tk][tn] = dot;
     __syncthreads();
-    if (tk == 0 && n < N) dotpart[(size_t)blockIdx.y * N + n] = red[0][tn] + red[1][tn] + red[2][tn] + red[3][tn];
+    if (tk == 0 && n < N) dotpart[(size_t)by * N + n] = red[0][tn] + red[1][tn] + red[2][tn] + red[3][tn];
+}
+
+__global__ void finalize_mat_kernel(int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
+                                    const float* __restrict__ gamma, const float* __restrict__ var, float eps,
+                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
+    finalize_mat_body(blockIdx.x, blockIdx.y, K, N, ldn, kb, dwr, w, gamma, var, eps, regc, trainable, gw, dotpart);
+}
+
+__global__ void finalize_mat_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+    const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
+    const int local = blockmap[2 * blockIdx.x + 1];
+    const int gx = ceil_div(d.N, 64);
+    finalize_mat_body(local % gx, local / gx, d.K, d.N, d.npad, d.kb, d.splits == 1 ? d.part : d.dw_raw, d.w, d.gamma, d.var, d.eps,
+                      d.regc, d.trainable, d.gw, d.dotpart);
 }
 
 // pass 2: one thread per channel
-__global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dotpart, const float* __restrict__ colsum,
+__device__ __forceinline__ void finalize_vec_body(int n, int N, int ks, const float* __restrict__ dotpart, const float* __restrict__ colsum,
                                     const float* __restrict__ b, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                     float regb, int trainable, int bn_trainable,
                                     float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float cs = colsum ? colsum[n] : 0.f;
     const float s = bn_scale(gamma, var, eps, n);
@@ -163,6 +196,22 @@ __global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dot
         ggamma[n] = bn_trainable ? rstd * (dot + ((b ? b[n] : 0.f) - mean[n]) * cs) : 0.f;
         gbeta[n] = bn_trainable ? cs : 0.f;
     }
+}
+
+__global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dotpart, const float* __restrict__ colsum,
+                                    const float* __restrict__ b, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                    float regb, int trainable, int bn_trainable,
+                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    finalize_vec_body(blockIdx.x * blockDim.x + threadIdx.x, N, ks, dotpart, colsum, b, gamma, mean, var, eps, regb, trainable, bn_trainable, gb, ggamma, gbeta);
+}
+
+__global__ void finalize_vec_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+    const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
+    const int local = blockmap[2 * blockIdx.x + 1];
+    if (!d.gb && !d.ggamma) return;
+    finalize_vec_body(local * blockDim.x + threadIdx.x, d.N, d.ks, d.dotpart, d.splits == 1 ? d.colpart : d.colsum, d.b, d.gamma, d.mean, d.var, d.eps,
+                      d.regb, d.trainable, d.bn_trainable, d.gb, d.ggamma, d.gbeta);
 }
 
 static int finalize_ks(int K, int N) {
@@ -192,6 +241,70 @@ extern "C" int urso_param_grad_finalize(int K, int N, int ldn, const float* dw_r
     if (gb_d || ggamma_d)
         hipLaunchKernelGGL(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d);
     return urso_check_launch("urso_param_grad_finalize");
+}
+
+// ------------------------------------------------------------------ batched parameter-side phases
+// One launch covers many layers: every block looks its layer up in a (layer, local block) map built on the host by
+// urso_param_batch_plan.  Same arithmetic, in the same order, as the per-layer entry points above.
+void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, hipStream_t st);   // conv_wgrad.hip
+
+static int batch_layer_blocks(int phase, const urso_param_desc& d) {
+    switch (phase) {
+    case URSO_PB_PREP: return ceil_div(d.C, 32) * ceil_div(d.npad, 32) * d.KH * d.KW;
+    case URSO_PB_REDUCE: {
+        if (d.splits <= 1) return 0;
+        const size_t cnt = (size_t)d.K * d.npad;
+        return (int)(((cnt + 3) / 4 + 15) / 16) + (int)(((size_t)(d.npad + 3) / 4 + 15) / 16);
+    }
+    case URSO_PB_FINALIZE_MAT: return ceil_div(d.N, 64) * d.ks;
+    case URSO_PB_FINALIZE_VEC: return ceil_div(d.N, 256);
+    }
+    return -1;
+}
+
+extern "C" int urso_param_desc_init(urso_param_desc* d, int KH, int KW, int C, int N, int npad, int splits, float eps, float weight_decay) {
+    if (!d || KH <= 0 || KW <= 0 || C <= 0 || N <= 0 || npad < N || splits < 1) { urso_set_error("urso_param_desc_init: bad argument"); return URSO_EINVAL; }
+    d->KH = KH; d->KW = KW; d->C = C; d->N = N; d->npad = npad; d->K = KH * KW * C; d->splits = splits;
+    d->ks = finalize_ks(d->K, N); d->kb = ceil_div(d->K, d->ks);
+    d->eps = eps;
+    d->regc = 2.0f * weight_decay / ((float)d->K * (float)N); d->regb = 2.0f * weight_decay / (float)N;
+    return URSO_OK;
+}
+
+extern "C" int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32_t* layer_ids, int n_ids,
+                                     int32_t* blockmap_h, int cap_blocks) {
+    if (!descs_h || !layer_ids || n_ids < 0 || phase < URSO_PB_PREP || phase > URSO_PB_FINALIZE_VEC) { urso_set_error("urso_param_batch_plan: bad argument"); return URSO_EINVAL; }
+    int total = 0;
+    for (int i = 0; i < n_ids; ++i) {
+        const urso_param_desc& d = descs_h[layer_ids[i]];
+        const int nb = batch_layer_blocks(phase, d);
+        if (nb < 0) return URSO_EINVAL;
+        for (int l = 0; l < nb; ++l, ++total)
+            if (blockmap_h && total < cap_blocks) { blockmap_h[2 * total] = layer_ids[i]; blockmap_h[2 * total + 1] = l; }
+    }
+    return total;
+}
+
+extern "C" int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream) {
+    if (!descs_d || !blockmap_d || nblocks < 0) { urso_set_error("urso_param_batch_run: bad argument"); return URSO_EINVAL; }
+    if (nblocks == 0) return URSO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (phase) {
+    case URSO_PB_PREP: {
+        ProfScope ps(st, URSO_K_PREP, 0, 0);
+        if (dt == URSO_F32) hipLaunchKernelGGL((weight_prep_batch_kernel<float>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        else if (dt == URSO_BF16) hipLaunchKernelGGL((weight_prep_batch_kernel<__bf16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        else if (dt == URSO_F16) hipLaunchKernelGGL((weight_prep_batch_kernel<_Float16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        else { urso_set_error("urso_param_batch_run: bad dtype"); return URSO_EINVAL; }
+        break; }
+    case URSO_PB_REDUCE: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0); urso_reduce_partials_batch_launch(descs_d, blockmap_d, nblocks, st); break; }
+    case URSO_PB_FINALIZE_MAT: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
+        hipLaunchKernelGGL(finalize_mat_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+    case URSO_PB_FINALIZE_VEC: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
+        hipLaunchKernelGGL(finalize_vec_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+    default: urso_set_error("urso_param_batch_run: bad phase"); return URSO_EINVAL;
+    }
+    return urso_check_launch("urso_param_batch_run");
 }
 
 // ------------------------------------------------------------------ input molding

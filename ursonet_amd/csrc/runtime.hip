@@ -19,7 +19,7 @@ int urso_check_launch(const char* what) {
 }
 
 extern "C" const char* urso_last_error(void) { return g_err; }
-extern "C" int urso_abi_version(void) { return 2; }
+extern "C" int urso_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------- profiler
 struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; };

@@ -74,20 +74,19 @@ class DataParallelEngine(object):
         eng = engine
         dist.broadcast(eng.flat_w, src=0, group=group)
         dist.broadcast(eng.flat_stats, src=0, group=group)
-        # layer extents in the flat buffer
-        ext = {}
-        for (ln, wn), (o, n, _) in eng.slices.items():
-            s, e = ext.get(ln, (o, o))
-            ext[ln] = (min(s, o), max(e, o + ((n + 3) // 4) * 4))
-        layers = sorted(((ln, s, e) for ln, (s, e) in ext.items()), key=lambda t: t[1])
-        self.buckets = plan_buckets(layers, bucket_bytes)
+        # gradient buckets are planned by the engine (it batches the gradient finalisation per bucket)
+        if bucket_bytes != eng.grad_bucket_bytes:
+            eng.grad_bucket_bytes = int(bucket_bytes)
+            eng._graphs = None
+            eng._build_plan()
+        self.buckets = eng.buckets
         self.reducer = GradReducer(eng.flat_g, self.buckets, group)
         # split the backward op list where each bucket becomes complete
         last_op_of_layer = {}
         for i, (tag, _) in enumerate(eng.bwd_ops):
-            if tag is not None:
-                last_op_of_layer[tag] = i
-                bn = eng.convs[tag].bn
+            for name in ((tag,) if isinstance(tag, str) else (tag or ())):       # an op may complete several layers (batched)
+                last_op_of_layer[name] = i
+                bn = eng.convs[name].bn
                 if bn:
                     last_op_of_layer[bn] = i
         cuts = []

@@ -52,8 +52,9 @@ class _Conv(object):
 
 
 class Engine(object):
-    def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False):
+    def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False, grad_bucket_bytes=32 << 20):
         assert mode in ("training", "inference")
+        self.grad_bucket_bytes = int(grad_bucket_bytes)
         if not torch.cuda.is_available():
             raise RuntimeError("ursonet_amd.Engine needs an AMD GPU (MI355X / gfx950); there is no CPU fallback")
         self.config, self.mode = config, mode
@@ -165,6 +166,7 @@ class Engine(object):
         max_ws = 0
         max_fin_ws = 0
         max_igemm_ws = 0
+        descs = []                                 # hip.ParamDesc of every non-stem weight layer
         for node in g.nodes:
             if node.op == "pool":
                 src, dst = act(node.src), act(node.dst)
@@ -222,16 +224,23 @@ class Engine(object):
             c.mean = self._ptr_or_none(node.bn, "moving_mean") if node.bn else None
             c.var = self._ptr_or_none(node.bn, "moving_variance") if node.bn else None
             self.convs[node.name] = c
-            # -- weight prep (per step in training; once in inference)
+            # -- weight prep (per step in training; once in inference): the stem has its own packing kernel, every other
+            #    layer gets a descriptor and ONE batched launch covers them all (urso_param_batch_run)
             if node.stem:
                 self.prep_ops.append(lambda c=c: hip.stem_weight_pack(c.N, dt, c.w, c.b, c.gamma, c.beta, c.mean, c.var, BN_EPS,
                                                                       c.wf, c.biasf, c.scale))
                 self.labels["prep"].append("prep:" + node.name)
             else:
-                self.prep_ops.append(lambda c=c, n=node: hip.conv_weight_prep(n.kh if not n.dense else 1, n.kw if not n.dense else 1,
-                                                                              n.cin, c.N, c.npad, dt, c.w, c.b, c.gamma, c.beta, c.mean,
-                                                                              c.var, BN_EPS, c.wf, c.wd, c.biasf, c.scale))
-                self.labels["prep"].append("prep:" + node.name)
+                d = hip.ParamDesc()
+                c.splits = hip.conv_wgrad_splits(c.gf, dt) if training else 1
+                hip.param_desc_init(d, node.kh if not node.dense else 1, node.kw if not node.dense else 1, node.cin, c.N, c.npad,
+                                    max(c.splits, 1), BN_EPS, float(cfg.WEIGHT_DECAY))
+                for f, t in (("w", c.w), ("b", c.b), ("gamma", c.gamma), ("beta", c.beta), ("mean", c.mean), ("var", c.var),
+                             ("wf", c.wf), ("wd", c.wd), ("biasf", c.biasf), ("scale", c.scale)):
+                    setattr(d, f, hip.ptr(t))
+                c.desc_id = len(descs)
+                c.desc = d
+                descs.append(d)
             # -- forward
             flags = (hip.EPI_RELU if node.relu else 0) | (hip.EPI_OUT_F32 if node.out_f32 else 0)
             # split-K workspace (tiny-grid / deep-K layers: bottleneck_layer, Dense heads); 0 = not split
@@ -242,10 +251,16 @@ class Engine(object):
                                                                        c.res.data if c.res is not None else None, None, c.dst.data,
                                                                        self.igemm_ws if c.ws_f else None))
             self.labels["fwd"].append("fwd:" + node.name)
-            if training:
+            if training and node.stem:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
-                max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(c.K_raw if not node.stem else 147, c.N))
+                max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(147, c.N))
         self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
+        self._descs = descs
+        if descs:
+            self.prep_ops.append(lambda: self.pbatch.run(hip.PB_PREP, "all", dt))
+            self.labels["prep"].append("prep:batched[%d layers]" % len(descs))
+        if not training:
+            self._upload_param_table()
         self.out_loc = self.acts[g.outputs["loc"].id]
         self.out_ori = self.acts[g.outputs["ori"].id]
         self._build_heads_io()
@@ -255,7 +270,24 @@ class Engine(object):
         self.ws = torch.empty(max_ws // 4 + 64, dtype=torch.float32, device=dev)
         self.fin_ws = torch.empty(max_fin_ws // 4 + 64, dtype=torch.float32, device=dev)
         self._build_losses()
-        self.bucket_of_op = []
+        # gradient buckets (contiguous slices of the flat gradient buffer, in the order the backward pass completes them):
+        # the split reduction + finalisation of all layers of a bucket is three batched launches issued once the last of
+        # their weight-gradient partials is enqueued; ursonet_amd/dp.py starts the bucket's all-reduce right after.
+        from .dp import plan_buckets
+        pending_groups = []
+        ext = {}
+        for (ln, wn), (o, n, _) in self.slices.items():
+            s0, e0 = ext.get(ln, (o, o))
+            ext[ln] = (min(s0, o), max(e0, o + _round_up(n, 4)))
+        self.buckets = plan_buckets(sorted(((ln, s0, e0) for ln, (s0, e0) in ext.items()), key=lambda t: t[1]), self.grad_bucket_bytes)
+        bucket_of = {ln: k for k, (_, _, names) in enumerate(self.buckets) for ln in names}
+        groups = OrderedDict()                      # bucket index -> [conv names], backward order
+        for node in reversed(g.nodes):
+            if node.op == "pool" or node.stem:
+                continue
+            if self.layer_trainable[node.name] or (node.bn and self.layer_trainable[node.bn]):
+                groups.setdefault(bucket_of[node.name], []).append(node.name)
+        last_of_group = {names[-1]: k for k, names in groups.items()}
         for node in reversed(g.nodes):
             if node.op == "pool":
                 src, dst = self.acts[node.src.id], self.acts[node.dst.id]
@@ -273,27 +305,44 @@ class Engine(object):
             tr = self.layer_trainable[node.name]
             bn_tr = self.layer_trainable[node.bn] if node.bn else False
             # -- weight gradient + finalisation (skipped for fully frozen layers; their grads stay zero)
-            if tr or bn_tr:
+            if (tr or bn_tr) and node.stem:
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev)
                 self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad(c.gf, dt, c.src.data, G, self.ws, c.dw_raw, c.colsum)))
                 self.labels["bwd"].append("wgrad:" + node.name)
-                dwr = c.dw_raw
-                Kf = c.K_raw
-                if node.stem:
-                    c.dw_unp = torch.empty(147 * c.N, dtype=torch.float32, device=dev)
-                    self.bwd_ops.append((node.name, lambda c=c: hip.stem_wgrad_unpack(c.N, c.dw_raw, c.dw_unp)))
-                    self.labels["bwd"].append("unpack:" + node.name)
-                    dwr, Kf = c.dw_unp, 147
+                c.dw_unp = torch.empty(147 * c.N, dtype=torch.float32, device=dev)
+                self.bwd_ops.append((node.name, lambda c=c: hip.stem_wgrad_unpack(c.N, c.dw_raw, c.dw_unp)))
+                self.labels["bwd"].append("unpack:" + node.name)
                 gw = self.gview(node.name, "kernel").reshape(-1)
                 gb = self.gview(node.name, "bias").reshape(-1) if node.bias else None
                 gg = self.gview(node.bn, "gamma").reshape(-1) if node.bn else None
                 gbe = self.gview(node.bn, "beta").reshape(-1) if node.bn else None
-                ldn = c.npad if not node.stem else c.N
-                self.bwd_ops.append((node.name, lambda c=c, dwr=dwr, Kf=Kf, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr, ldn=ldn:
-                                     hip.param_grad_finalize(Kf, c.N, ldn, dwr, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
+                self.bwd_ops.append((node.name, lambda c=c, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr:
+                                     hip.param_grad_finalize(147, c.N, c.N, c.dw_unp, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
                                                              float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
                 self.labels["bwd"].append("finalize:" + node.name)
+            elif tr or bn_tr:
+                d = c.desc
+                c.wg_ws = torch.empty(hip.conv_wgrad_ws_bytes(c.gf, dt) // 4 + 64, dtype=torch.float32, device=dev)
+                n_part = c.splits * c.K_raw * c.npad
+                c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
+                c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
+                c.dotpart = torch.empty(d.ks * c.N + 16, dtype=torch.float32, device=dev)
+                d.part, d.colpart = c.wg_ws.data_ptr(), c.wg_ws.data_ptr() + 4 * n_part
+                d.dw_raw, d.colsum, d.dotpart = hip.ptr(c.dw_raw), hip.ptr(c.colsum), hip.ptr(c.dotpart)
+                d.trainable, d.bn_trainable = int(tr), int(bn_tr)
+                d.gw = hip.ptr(self.gview(node.name, "kernel").reshape(-1))
+                d.gb = hip.ptr(self.gview(node.name, "bias").reshape(-1)) if node.bias else None
+                d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if node.bn else None
+                d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if node.bn else None
+                self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad_partial(c.gf, dt, c.src.data, G, c.wg_ws)))
+                self.labels["bwd"].append("wgrad:" + node.name)
+                if node.name in last_of_group:
+                    k = last_of_group[node.name]
+                    pending_groups.append((k, tuple(groups[k]), len(self.bwd_ops)))
+                    for ph, nm in ((hip.PB_REDUCE, "reduce"), (hip.PB_FINALIZE_MAT, "finalize_mat"), (hip.PB_FINALIZE_VEC, "finalize_vec")):
+                        self.bwd_ops.append((tuple(groups[k]), (ph, k)))          # resolved to launches once the table is on the device
+                        self.labels["bwd"].append("%s:bucket%d" % (nm, k))
             # -- residual branch: its gradient IS G (Add); fold it into the next dgrad (post-ReLU tensors) or alias it
             if c.res is not None:
                 R = c.res
@@ -312,12 +361,26 @@ class Engine(object):
                 if getattr(c, "gd_scatter", False):
                     if add is None:                       # first contribution: everything off the sampled grid is zero
                         self.bwd_ops.append((None, lambda t=dstg: t.zero_()))       # torch fill: no profiler record
+                        self.labels["bwd"].append(None)
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
                                      hip.conv_igemm_ws(c.gd, dt, 0, G, c.wd, None, add, mask, dstg, self.igemm_ws if c.ws_d else None)))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
+        # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
+        self._upload_param_table()
+        resolved, labels = [], []
+        assert len(self.bwd_ops) == len(self.labels["bwd"])
+        for (tag, op), lab in zip(self.bwd_ops, self.labels["bwd"]):
+            if isinstance(op, tuple):
+                ph, k = op
+                ids = [self.convs[nm].desc_id for nm in groups[k]]
+                if self.pbatch.plan(ph, k, ids) == 0:
+                    continue                                   # nothing to launch (e.g. no split layer in the bucket)
+                op = (lambda ph=ph, k=k: self.pbatch.run(ph, k, dt))
+            resolved.append((tag, op)); labels.append(lab)
+        self.bwd_ops, self.labels["bwd"] = resolved, labels
         # ---------------------------------------------------------------- optimizer
         n = self.n_flat
         self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), float(cfg.GRADIENT_CLIP_NORM or 0.0)],
@@ -328,6 +391,11 @@ class Engine(object):
         self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
         self.labels["opt"] += ["sqnorm", "sgd"]
         self.flat_g.zero_()
+
+    def _upload_param_table(self):
+        self.pbatch = hip.ParamBatch(self._descs, self.device) if self._descs else None
+        if self.pbatch is not None:
+            self.pbatch.plan(hip.PB_PREP, "all", list(range(len(self._descs))))
 
     def _build_heads_io(self):
         cfg, B, dev = self.config, self.B, self.device
@@ -411,7 +479,8 @@ class Engine(object):
     def profile_step(self):
         """One eager training step with the library's HIP-event launch profiler on.
         Returns [(label, kernel_id, ms, flops, bytes)] in launch order."""
-        labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * len(self.loss_ops) + self.labels["bwd"] + self.labels["opt"])
+        labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * len(self.loss_ops) +
+                  [l for l in self.labels["bwd"] if l is not None] + self.labels["opt"])
         torch.cuda.synchronize(self.device)
         hip.prof_collect()
         hip.prof_enable(True)

@@ -46,6 +46,18 @@ _lib = C.CDLL(LIB_PATH)
 
 _vp, _fp, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _gp = C.POINTER(ConvGeom)
+
+
+class ParamDesc(C.Structure):
+    """urso_param_desc (include/ursonet_hip.h): one weight layer's parameter-side tensors for the batched phases."""
+    _fields_ = ([(n, C.c_int32) for n in ("KH", "KW", "C", "N", "npad", "K", "splits", "ks", "kb", "trainable", "bn_trainable")] +
+                [(n, C.c_float) for n in ("eps", "regc", "regb")] +
+                [(n, C.c_void_p) for n in ("w", "b", "gamma", "beta", "mean", "var", "wf", "wd", "biasf", "scale", "part", "colpart",
+                                           "dw_raw", "colsum", "dotpart", "gw", "gb", "ggamma", "gbeta")])
+
+
+PB_PREP, PB_REDUCE, PB_FINALIZE_MAT, PB_FINALIZE_VEC = 0, 1, 2, 3
+_dp = C.POINTER(ParamDesc)
 _SIGS = {
     "urso_last_error": (C.c_char_p, []),
     "urso_abi_version": (_i, []),
@@ -54,6 +66,11 @@ _SIGS = {
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_wgrad": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
+    "urso_conv_wgrad_splits": (_i, [_gp, _i]),
+    "urso_conv_wgrad_partial": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "urso_param_desc_init": (_i, [_dp, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "urso_param_batch_plan": (_i, [_i, _dp, C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _i]),
+    "urso_param_batch_run": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "urso_conv_weight_prep": (_i, [_i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _vp, _fp, _fp, _vp]),
     "urso_stem_weight_pack": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _fp, _fp, _vp]),
     "urso_stem_wgrad_unpack": (_i, [_i, _fp, _fp, _vp]),
@@ -133,6 +150,46 @@ def conv_wgrad_ws_bytes(g, dt):
 def conv_wgrad(g, dt, x, dz, ws, dw_raw, colsum, stream=None):
     _chk(_lib.urso_conv_wgrad(C.byref(g), dt, ptr(x), ptr(dz), ptr(ws), ws.numel() * ws.element_size(), ptr(dw_raw),
                               ptr(colsum), stream_ptr(stream)), "urso_conv_wgrad")
+
+
+def conv_wgrad_splits(g, dt):
+    return int(_lib.urso_conv_wgrad_splits(C.byref(g), dt))
+
+
+def conv_wgrad_partial(g, dt, x, dz, ws, stream=None):
+    _chk(_lib.urso_conv_wgrad_partial(C.byref(g), dt, ptr(x), ptr(dz), ptr(ws), ws.numel() * ws.element_size(), stream_ptr(stream)),
+         "urso_conv_wgrad_partial")
+
+
+def param_desc_init(d, KH, KW, Cin, N, npad, splits, eps, weight_decay):
+    _chk(_lib.urso_param_desc_init(C.byref(d), KH, KW, Cin, N, npad, splits, eps, weight_decay), "urso_param_desc_init")
+
+
+class ParamBatch(object):
+    """A device copy of a ParamDesc array plus per-(phase, layer subset) block maps; run(phase, key) is one launch."""
+
+    def __init__(self, descs, device):
+        self.n = len(descs)
+        self.host = (ParamDesc * self.n)(*descs)
+        raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8)
+        self.dev = raw.to(device)
+        self.maps = {}
+
+    def plan(self, phase, key, layer_ids):
+        ids = (C.c_int32 * len(layer_ids))(*layer_ids)
+        nb = _lib.urso_param_batch_plan(phase, self.host, ids, len(layer_ids), None, 0)
+        if nb < 0:
+            raise UrsoHipError("urso_param_batch_plan: " + last_error())
+        buf = (C.c_int32 * (2 * max(nb, 1)))()
+        _lib.urso_param_batch_plan(phase, self.host, ids, len(layer_ids), buf, nb)
+        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.int32).to(self.dev.device)
+        self.maps[(phase, key)] = (t, nb)
+        return nb
+
+    def run(self, phase, key, dt, stream=None):
+        t, nb = self.maps[(phase, key)]
+        if nb:
+            _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
 
 
 def conv_weight_prep(KH, KW, Cin, N, npad, dt, w, b, gamma, beta, mean, var, eps, wf, wd, biasf, scale, stream=None):
