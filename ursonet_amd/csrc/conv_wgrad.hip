@@ -203,6 +203,182 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ 16-bit path: row-major staging + LDS transpose reads
+// For bf16/f16 the transposition is done by the LDS itself: both operand chunks are staged exactly as they lie in
+// HBM (pixel-major rows of 128 channels, plain ds_write_b128) and the MFMA fragments are fetched with
+// ds_read_b64_tr_b16, which hands lane (c = l&15, g = l>>4) the four pixels {row0+4g .. +3} of channel c -- two of them
+// make one 16x16x32 operand (k-index <-> pixel map {16r + 4g + j}; the same map for both operands, so the product is
+// unchanged).  This removes the 32 ds_write_b32 + ~100 VALU bit-shuffles per step of the kernel above, which made it
+// VALU-issue bound (PMC: 10 VALU instructions per MFMA, MFMA pipe 18 % busy).
+// LDS image of a chunk: row p = pixel (256 B), 16-B slot s of the row at position s ^ (2*(p&7)): 32-B channel blocks stay
+// contiguous, the 8 pixel rows a half-wave reads hit 8 disjoint bank groups, the staging writes fill whole rows.
+// colsum comes from the same fragments: one extra MFMA per n-block against an all-ones operand.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x2_t lds_read_tr16(const char* p) {
+    return __builtin_bit_cast(i32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p));
+}
+template <typename T> struct OnesFrag;
+template <> struct OnesFrag<__bf16> { static constexpr int W = 0x3F803F80; };
+template <> struct OnesFrag<_Float16> { static constexpr int W = 0x3C003C00; };
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int VE = 8, RM = 64, ITEMS = 4;          // 64 pixels x 128 channels per operand per step; 4 x 16 B per thread
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * RM * 256];
+    auto sX = [&](int buf) -> char* { return smem + buf * 2 * RM * 256; };
+    auto sZ = [&](int buf) -> char* { return smem + buf * 2 * RM * 256 + RM * 256; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wn = wave >> 1;
+    const int kt = blockIdx.x % a.ktiles, nt = blockIdx.x / a.ktiles, sp = blockIdx.y;
+    const int k0c = kt * 16, n0 = nt * 128;
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz, a.dz_bytes);
+
+    // staging role: 16-B slot `ch` of pixel rows prow, prow+16, prow+32, prow+48
+    const int ch = tid & 15, prow = tid >> 4;
+    const int kc = k0c + ch;
+    const bool kvalid = kc < a.Kc;
+    int ky = 0, kx = 0, cc = 0;
+    if (kvalid) { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
+    const int ncol = n0 + ch * VE;
+    const bool nvalid = ncol < a.N;
+    const int st_off = prow * 256 + ((ch ^ ((prow & 7) << 1)) << 4);       // + it*16*256
+
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    int mcur = m_begin;
+    int pb[ITEMS], poy[ITEMS], pox[ITEMS];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            int rem;
+            divmod(m_begin + prow + 16 * e, ohw, a.rcp_ohw, pb[e], rem);
+            divmod(rem, a.OW, a.rcp_ow, poy[e], pox[e]);
+        }
+    }
+    const int dq = RM / a.OW, dr = RM - dq * a.OW;                          // MODE 1: a step advances dq rows + dr pixels
+    const uint32_t xc_off = (uint32_t)(cc * VE) * 2u, z_off0 = (uint32_t)ncol * 2u;
+
+    i32x4_t rxv[ITEMS], rzv[ITEMS];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int m = mcur + prow + 16 * e;
+            const bool mvalid = m < m_end;
+            uint32_t off; bool ok;
+            if constexpr (MODE == 0) { off = (uint32_t)(m * a.C) * 2u + xc_off; ok = mvalid && kvalid; }
+            else {
+                int b, oy, ox;
+                if constexpr (MODE == 1) {
+                    b = pb[e]; oy = poy[e]; ox = pox[e];
+                    int nx = ox + dr; const bool w1 = nx >= a.OW; nx -= w1 ? a.OW : 0;
+                    int ny = oy + dq + (w1 ? 1 : 0); const bool w2 = ny >= a.OH; ny -= w2 ? a.OH : 0;
+                    pox[e] = nx; poy[e] = ny; pb[e] = b + (w2 ? 1 : 0);
+                } else { int rem; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); }
+                const int iy = oy * a.SH - a.PH + ky, ix = ox * a.SW - a.PW + kx;
+                ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off;
+            }
+            rxv[e] = buf_load16(rx, ok ? off : URSO_OOB_SHIFT);
+            const uint32_t zoff = (uint32_t)m * (uint32_t)a.N * 2u + z_off0;
+            rzv[e] = buf_load16(rz, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
+        }
+        mcur += RM;
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            *(i32x4_t*)(sX(buf) + st_off + e * 16 * 256) = rxv[e];
+            *(i32x4_t*)(sZ(buf) + st_off + e * 16 * 256) = rzv[e];
+        }
+    };
+
+    // fragment role: lane (c = lane&15, g = lane>>4); this lane's part of the address of channel block cb:
+    //   row (16r + 32ks) + 4g + (c>>2), 32-B block cb ^ (row&7), 8-B piece c&3
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frow = fg * 4 + (fr >> 2), fsw = frow & 7;
+    const int fbase = frow * 256 + (fr & 3) * 8;
+    int offx[4], offz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offx[i] = fbase + (((wk * 4 + i) ^ fsw) << 5);
+        offz[i] = fbase + (((wn * 4 + i) ^ fsw) << 5);
+    }
+
+    f32x4_t acc[4][4], accc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_col = (kt == 0) && (wk == 0) && a.colpart;
+    const i32x4_t ones = {OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W};
+
+    const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
+    if (nsteps > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) fetch();
+        const char* bx = sX(cur); const char* bz = sZ(cur);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i32x4_t fz[4], fx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const i32x2_t lo = lds_read_tr16(bz + offz[j] + ks * 32 * 256), hi = lds_read_tr16(bz + offz[j] + ks * 32 * 256 + 16 * 256);
+                fz[j] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i32x2_t lo = lds_read_tr16(bx + offx[i] + ks * 32 * 256), hi = lds_read_tr16(bx + offx[i] + ks * 32 * 256 + 16 * 256);
+                fx[i] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], fx[i], acc[i][j]);   // D rows -> n, cols -> k
+            if (do_col) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], ones, accc[j]);      // every column = sum over the 32 pixels
+            }
+        }
+        if (s + 1 < nsteps) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (size_t)sp * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kt * 128 + wk * 64 + i * 16 + fr;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb >= a.N) continue;
+            *(f32x4_t*)(out + (size_t)k * a.N + nb) = acc[i][j];                    // N % 8 == 0 on this path
+        }
+    }
+    if (do_col && fr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb < a.N) *(f32x4_t*)(a.colpart + (size_t)sp * a.N + nb) = accc[j];
+        }
+    }
+}
+
 // Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
 // float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
 // sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
@@ -326,10 +502,13 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     dim3 grid(p.ktiles * p.ntiles, p.splits);
     const int rm = 128 / (int)dt_size(dt);
     const int mode = a.pointwise ? 0 : (g->OW >= rm ? 1 : 2);
-#define URSO_WG(TT) do { if (mode == 0) hipLaunchKernelGGL((wgrad_kernel<TT, 0>), grid, dim3(256), 0, st, a); \
-                         else if (mode == 1) hipLaunchKernelGGL((wgrad_kernel<TT, 1>), grid, dim3(256), 0, st, a); \
-                         else hipLaunchKernelGGL((wgrad_kernel<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
-    if (dt == URSO_F32) URSO_WG(float); else if (dt == URSO_BF16) URSO_WG(__bf16); else URSO_WG(_Float16);
+    const int tmode = a.pointwise ? 0 : ((64 / g->OW + 1 <= g->OH) ? 1 : 2);     // 16-bit kernel: carried coordinates whenever one wrap suffices
+#define URSO_WG(KERN, TT, MD) do { if (MD == 0) hipLaunchKernelGGL((KERN<TT, 0>), grid, dim3(256), 0, st, a); \
+                         else if (MD == 1) hipLaunchKernelGGL((KERN<TT, 1>), grid, dim3(256), 0, st, a); \
+                         else hipLaunchKernelGGL((KERN<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
+    if (dt == URSO_F32) URSO_WG(wgrad_kernel, float, mode);
+    else if (dt == URSO_BF16) URSO_WG(wgrad_tr_kernel, __bf16, tmode);
+    else URSO_WG(wgrad_tr_kernel, _Float16, tmode);
 #undef URSO_WG
     int rc = urso_check_launch("urso_conv_wgrad");
     if (rc != URSO_OK) return rc;
