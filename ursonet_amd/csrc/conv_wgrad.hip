@@ -217,6 +217,18 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x2_t lds_read_tr16(const char* p) {
     return __builtin_bit_cast(i32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p));
 }
+// buffer_load_dwordx4 ... lds issued behind the compiler's back: through the builtin, hipcc waits vmcnt(0) before the next
+// LDS read of ANY buffer (it cannot tell the DMA's destination from the buffer being multiplied), which serialises the
+// copy with the MFMAs.  The caller orders it by hand: s_waitcnt vmcnt(0) before the barrier that publishes the buffer.
+__device__ __forceinline__ void lds_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t raw_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
 template <typename T> struct OnesFrag;
 template <> struct OnesFrag<__bf16> { static constexpr int W = 0x3F803F80; };
 template <> struct OnesFrag<_Float16> { static constexpr int W = 0x3C003C00; };
@@ -229,24 +241,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     auto sX = [&](int buf) -> char* { return smem + buf * 2 * RM * 256; };
     auto sZ = [&](int buf) -> char* { return smem + buf * 2 * RM * 256 + RM * 256; };
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;
-    const int kt = blockIdx.x % a.ktiles, nt = blockIdx.x / a.ktiles, sp = blockIdx.y;
+    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a CONTIGUOUS run of the split-major work list, so
+    // that the tiles sharing a pixel range (same x / dz chunks) sit behind one L2 instead of being fetched by all eight
+    const int tiles = a.ktiles * a.ntiles;
+    const int wid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * a.splits);
+    const int sp = wid / tiles, tile = wid - sp * tiles;
+    const int kt = tile % a.ktiles, nt = tile / a.ktiles;
     const int k0c = kt * 16, n0 = nt * 128;
     const int m_begin = sp * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
-    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz, a.dz_bytes);
+    const i32x4_t rx = raw_rsrc(a.x, a.x_bytes), rz = raw_rsrc(a.dz, a.dz_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    // staging role: 16-B slot `ch` of pixel rows prow, prow+16, prow+32, prow+48
-    const int ch = tid & 15, prow = tid >> 4;
+    // staging role: the chunks go from HBM straight into LDS (buffer_load ... lds: the wave's 64 lanes fill 1 KiB = 4 pixel
+    // rows in lane order, out-of-range lanes write zeros), so the swizzle is applied on the SOURCE side: the lane that
+    // lands in physical slot tid&15 of row p loads logical 16-B chunk (tid&15) ^ 2(p&7).  Rows prow, +16, +32, +48.
+    const int prow = tid >> 4, ch = (tid & 15) ^ ((prow & 7) << 1);
     const int kc = k0c + ch;
     const bool kvalid = kc < a.Kc;
     int ky = 0, kx = 0, cc = 0;
     if (kvalid) { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
     const int ncol = n0 + ch * VE;
     const bool nvalid = ncol < a.N;
-    const int st_off = prow * 256 + ((ch ^ ((prow & 7) << 1)) << 4);       // + it*16*256
 
     const int ohw = a.OH * a.OW;
     auto divmod = [](int n, int d, float rcp, int& q, int& r) {
@@ -269,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     const int dq = RM / a.OW, dr = RM - dq * a.OW;                          // MODE 1: a step advances dq rows + dr pixels
     const uint32_t xc_off = (uint32_t)(cc * VE) * 2u, z_off0 = (uint32_t)ncol * 2u;
 
-    i32x4_t rxv[ITEMS], rzv[ITEMS];
-    auto fetch = [&]() {
+    auto dma = [&](int buf) {
+        const uint32_t dx = lds0 + buf * 2 * RM * 256 + wave * 1024, dz = dx + RM * 256;
 #pragma unroll
         for (int e = 0; e < ITEMS; ++e) {
             const int m = mcur + prow + 16 * e;
@@ -289,18 +307,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
                 ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
                 off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off;
             }
-            rxv[e] = buf_load16(rx, ok ? off : URSO_OOB_SHIFT);
+            lds_dma16(rx, dx + e * 16 * 256, ok ? off : URSO_OOB_SHIFT);
             const uint32_t zoff = (uint32_t)m * (uint32_t)a.N * 2u + z_off0;
-            rzv[e] = buf_load16(rz, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
+            lds_dma16(rz, dz + e * 16 * 256, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
         }
         mcur += RM;
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < ITEMS; ++e) {
-            *(i32x4_t*)(sX(buf) + st_off + e * 16 * 256) = rxv[e];
-            *(i32x4_t*)(sZ(buf) + st_off + e * 16 * 256) = rzv[e];
-        }
     };
 
     // fragment role: lane (c = lane&15, g = lane>>4); this lane's part of the address of channel block cb:
@@ -326,11 +337,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     const i32x4_t ones = {OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W};
 
     const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
-    if (nsteps > 0) { fetch(); stage(0); }
+    if (nsteps > 0) dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk has landed in LDS
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
-        if (s + 1 < nsteps) fetch();
+        if (s + 1 < nsteps) dma(cur ^ 1);             // that buffer was released by the barrier that ended step s-1
         const char* bx = sX(cur); const char* bz = sZ(cur);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
                 for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], ones, accc[j]);      // every column = sum over the 32 pixels
             }
         }
-        if (s + 1 < nsteps) stage(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
