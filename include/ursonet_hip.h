@@ -36,6 +36,8 @@ enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
 /* epilogue flags for urso_conv_igemm */
 #define URSO_EPI_RELU      1   /* y = max(y, 0)                 Activation('relu') net.py:104,109,116 ... */
 #define URSO_EPI_OUT_F32   2   /* store fp32 regardless of dt (head outputs)                              */
+#define URSO_EPI_MASK_BITS 4   /* urso_conv_igemm_ex: mask_d is a BIT mask (1 byte per 8 elements of dst) */
+#define URSO_EPI_EMIT_BITS 8   /* urso_conv_igemm_ex: also write the bit mask of (dst > 0) to bits_out_d  */
 
 const char* urso_last_error(void);
 int         urso_abi_version(void);           /* bumped on any signature change */
@@ -85,6 +87,17 @@ size_t urso_conv_igemm_ws_bytes(const urso_conv_geom* g, int dt);
 int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
                        const void* src_d, const void* wgt_d, const float* bias_d,
                        const void* add_d, const void* mask_d, void* dst_d, void* ws_d, size_t ws_bytes, void* stream);
+/* Same, with ReLU masks as BIT masks.  The data gradient into a post-ReLU tensor X must be zeroed where X <= 0
+ * (the gradient of Activation('relu')); reading X itself for that costs as much HBM traffic as the gradient.  With
+ * URSO_EPI_EMIT_BITS the forward pass of the layer that produces X also writes bits_out_d: [pixels][N/8] bytes, bit e
+ * of byte j <-> channel 8j + e, set where the stored value is > 0; with URSO_EPI_MASK_BITS the data-gradient pass takes
+ * that array as mask_d (1/16 of the bytes).  16-bit dtypes, N % 8 == 0, no fp32 output, no split-K:
+ * urso_conv_igemm_bits_ok() tells whether (g, dt, flags, ws_bytes) qualifies. */
+int urso_conv_igemm_bits_ok(const urso_conv_geom* g, int dt, int flags, size_t ws_bytes);
+int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
+                       const void* src_d, const void* wgt_d, const float* bias_d,
+                       const void* add_d, const void* mask_d, void* dst_d, void* bits_out_d,
+                       void* ws_d, size_t ws_bytes, void* stream);
 
 /*
  * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):

@@ -478,3 +478,65 @@ def test_batched_param_phases_equal_per_layer_entry_points(dt):
         for got, exp in zip((t["wf"], t["wd"], t["biasf"], t["scale"], t["gw"], t["gb"], t["gg"], t["gbe"]), r):
             if exp is not None:
                 assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 64, 128, 1, 1), (2, 17, 19, 32, 40, 3, 1), (3, 16, 16, 64, 256, 1, 2)])
+def test_relu_bit_masks_emit_and_consume(dt, shape):
+    """urso_conv_igemm_ex: (a) the forward epilogue's bit mask == (stored output > 0) bit for bit; (b) a data-gradient
+    pass masked by the bit array is identical to one masked by the activation tensor itself (incl. the scattered
+    stride-2 1x1 form and a residual add)."""
+    hip = _hip()
+    B, H, W, Ci, N, k, s = shape
+    torch.manual_seed(sum(shape) + dt)
+    tdt = hip.TORCH_DT[dt]
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = dev(torch.randn(B, H, W, Ci), dt)
+    w = torch.randn(k, k, Ci, N) / (k * k * Ci) ** 0.5
+    wf, wd, biasf, _ = prep_weights(w, dt, bias=torch.randn(N) * 0.1)
+    res = dev(torch.randn(B, OH, OW, N), dt)
+    g = hip.geom(B, H, W, Ci, OH, OW, N, k, k, s, s, pad, pad)
+    assert hip.conv_igemm_bits_ok(g, dt, hip.EPI_RELU)
+    y = torch.empty(B, OH, OW, N, dtype=tdt, device="cuda")
+    bits = torch.full((B * OH * OW * N // 8,), 0xAA, dtype=torch.uint8, device="cuda")
+    hip.conv_igemm_ex(g, dt, hip.EPI_RELU | hip.EPI_EMIT_BITS, x, wf, biasf, res, None, y, bits)
+    y0 = torch.empty_like(y)
+    hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, biasf, res, None, y0)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    pos = (y.float() > 0).reshape(-1, 8).to(torch.int32)
+    exp = (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, exp)
+    assert 0.2 < float(pos.float().mean()) < 0.8
+    # ---- consume: gradient w.r.t. an input tensor X that is itself post-ReLU
+    xr = torch.relu(x.float()).to(tdt)                      # the forward input as a post-ReLU activation
+    xpos = (xr.float() > 0).reshape(-1, 8).to(torch.int32)
+    xbits = (xpos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    dy = dev(torch.randn(B, OH, OW, N), dt)
+    add = dev(torch.randn(B, H, W, Ci), dt)
+    if k == 1 and s > 1:
+        gd = hip.geom(B, OH, OW, N, OH, OW, Ci, 1, 1, FH=H, FW=W, OSH=s, OSW=s)
+        d_a = add.clone(); d_b = add.clone()
+        hip.conv_igemm_ex(gd, dt, 0, dy, wd, None, d_a, xr, d_a)
+        hip.conv_igemm_ex(gd, dt, hip.EPI_MASK_BITS, dy, wd, None, d_b, xbits, d_b)
+    else:
+        gd = hip.geom(B, OH, OW, N, H, W, Ci, k, k, 1, 1, k - 1 - pad, k - 1 - pad, s, s)
+        d_a = torch.empty(B, H, W, Ci, dtype=tdt, device="cuda"); d_b = torch.empty_like(d_a)
+        hip.conv_igemm_ex(gd, dt, 0, dy, wd, None, add, xr, d_a)
+        hip.conv_igemm_ex(gd, dt, hip.EPI_MASK_BITS, dy, wd, None, add, xbits, d_b)
+    assert hip.conv_igemm_bits_ok(gd, dt, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a, d_b)
+    assert float((d_b.float() != 0).float().mean()) > 0.1
+
+
+def test_bit_masks_refused_where_unsupported():
+    hip = _hip()
+    g = hip.geom(2, 8, 8, 16, 8, 8, 16, 1, 1)
+    assert not hip.conv_igemm_bits_ok(g, 0, hip.EPI_RELU)                          # fp32
+    assert not hip.conv_igemm_bits_ok(g, 1, hip.EPI_RELU | hip.EPI_OUT_F32)
+    x = torch.randn(2, 8, 8, 16, device="cuda"); w = torch.randn(16, 16, device="cuda"); y = torch.empty_like(x)
+    bits = torch.zeros(2 * 8 * 8 * 2, dtype=torch.uint8, device="cuda")
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_igemm_ex(g, 0, hip.EPI_RELU | hip.EPI_EMIT_BITS, x, w, None, None, None, y, bits)

@@ -27,6 +27,8 @@ struct IgemmArgs {
     int ksplit, kps;        // split-K: number of K slices (1 = off) and K-tiles per slice
     float* part;            // split-K: fp32 partial sums [ksplit][M][N]
     int flags;
+    void* bits_out;         // EMIT: bit mask of (dst > 0), one byte per 16-byte output vector, laid out like dst
+    uint32_t bits_bytes;    // bytes of a bit mask shaped like dst (= dst elements / 8)
 };
 
 // Persistent, software-pipelined tile stream: the grid is 8*bpx blocks (2-3 per CU, all resident);
@@ -36,8 +38,12 @@ struct IgemmArgs {
 // stay in flight during the epilogue, so short-K (HBM-bound) layers never expose their load latency.
 // SPLIT: the tile stream enumerates (tile, K-slice) pairs and the epilogue stores raw fp32 partial sums (split-K for
 // tiny-grid / deep-K layers); compiled separately so the common kernels carry none of its state.
-template <typename T, int BM, int BN, bool HAS_ADD, bool HAS_MASK, bool SPLIT>
+// MASK: 0 none, 1 mask_d is a tensor shaped like dst (keep where > 0), 2 mask_d is a BIT mask (one byte per 16-byte
+// vector of dst, bit e <-> element e): 1/16 of the bytes of the activation it stands for.  EMIT: also write such a bit
+// mask of (dst > 0) to bits_out (forward ReLU layers; consumed by the data-gradient pass of the next layer).
+template <typename T, int BM, int BN, bool HAS_ADD, int MASK, bool SPLIT, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+    constexpr bool HAS_MASK = MASK == 1;
     constexpr int VE = Elem<T>::VE;
     constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
     constexpr int TM = WM / 16, TN = WN / 16;        // 16x16 sub-tiles per wave
@@ -61,7 +67,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     // epilogue descriptors: an absent tensor gets num_records = 0, i.e. every load returns 0
     const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? (MASK == 2 ? a.bits_bytes : a.dst_bytes) : 0u);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(EMIT ? a.bits_out : a.dst, EMIT ? a.bits_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
 
     // ---- fetch-side state (belongs to the tile whose K-tiles are being loaded)
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         constexpr int NBATCH = (HAS_ADD && HAS_MASK) ? 2 : 1;     // two load batches when both tensors are present
         constexpr int IPB = TM / NBATCH;                           // pixel sub-tiles per batch
         i32x4_t radd[HAS_ADD ? IPB * NV : 1], rmsk[HAS_MASK ? IPB * NV : 1];
+        uint32_t rbit[MASK == 2 ? TM * NV : 1];       // bit masks: one byte per vector, all loaded in batch 0
         // destination pixel index of this lane's row of sub-tile i (scattered destinations: stride-2 dgrad)
         int dpix[TM];
 #pragma unroll
@@ -216,6 +224,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                     if constexpr (HAS_ADD) radd[ii * NV + v] = buf_load16(rad, o);
                     if constexpr (HAS_MASK) rmsk[ii * NV + v] = buf_load16(rmk, o);
                 }
+            if constexpr (MASK == 2) {
+                if (batch == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int v = 0; v < NV; ++v)          // out-of-range vectors: 0x80000000 >> 4 is beyond any bit mask
+                            rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b8(rmk, eoff(i, v) >> 4, 0, 0);
+                }
+            }
         };
 
         for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                     T ea[VE], em[VE], eo[VE];
                     if constexpr (HAS_ADD) __builtin_memcpy(ea, &radd[(i % IPB) * NV + v], 16);
                     if constexpr (HAS_MASK) __builtin_memcpy(em, &rmsk[(i % IPB) * NV + v], 16);
+                    uint32_t mbits = 0;
 #pragma unroll
                     for (int e = 0; e < VE; ++e) {
                         const int c = v * VE + e;                               // = 4*j + r: sub-tile j, D register r
@@ -272,10 +290,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
                         if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
                         y = relu ? fmaxf(y, 0.f) : y;
                         if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                        if constexpr (MASK == 2) y = ((rbit[i * NV + v] >> e) & 1u) ? y : 0.f;
                         eo[e] = Elem<T>::from_f(y);
+                        if constexpr (EMIT) mbits |= (Elem<T>::to_f(eo[e]) > 0.f) ? (1u << e) : 0u;   // of the STORED value
                     }
                     i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
                     buf_store16(rds, eoff(i, v), ov);
+                    if constexpr (EMIT) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mbits, rmo, eoff(i, v) >> 4, 0, 0);
                 }
             }
         } else {
@@ -407,13 +428,28 @@ static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* 
     if (bpx > cap) bpx = cap;
     const dim3 grid(8 * bpx), blk(256);
     const bool coal = !(flags & URSO_EPI_OUT_F32) && (g->N % (16 / (int)sizeof(T))) == 0;
-    const int sel = (coal && a.ksplit == 1) ? ((a.add ? 1 : 0) | (a.mask ? 2 : 0)) : 0;     // the scalar path reads add/mask through a.*
-#define URSO_LAUNCH(BN_, AD_, MK_, SP_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_, SP_>), grid, blk, 0, st, a)
-    if (a.ksplit > 1) { if (small) URSO_LAUNCH(64, false, false, true); else URSO_LAUNCH(128, false, false, true); }
-    else if (small) { switch (sel) { case 0: URSO_LAUNCH(64, false, false, false); break; case 1: URSO_LAUNCH(64, true, false, false); break;
-                                     case 2: URSO_LAUNCH(64, false, true, false); break; default: URSO_LAUNCH(64, true, true, false); } }
-    else            { switch (sel) { case 0: URSO_LAUNCH(128, false, false, false); break; case 1: URSO_LAUNCH(128, true, false, false); break;
-                                     case 2: URSO_LAUNCH(128, false, true, false); break; default: URSO_LAUNCH(128, true, true, false); } }
+    const bool fastepi = coal && a.ksplit == 1;
+    const bool mbits = (flags & URSO_EPI_MASK_BITS) && a.mask, emit = (flags & URSO_EPI_EMIT_BITS) != 0;
+    if ((mbits || emit) && !(fastepi && sizeof(T) == 2)) {
+        urso_set_error("urso_conv_igemm: bit masks need a 16-bit dtype, N %% 8 == 0, no fp32 output and no split-K (urso_conv_igemm_bits_ok)");
+        return URSO_EINVAL;
+    }
+    if (emit && (a.mask || !a.bits_out)) { urso_set_error("urso_conv_igemm: EMIT_BITS needs bits_out and no mask"); return URSO_EINVAL; }
+    // the scalar path reads add/mask through a.*
+    const int sel = fastepi ? ((a.add ? 1 : 0) | (a.mask ? (mbits ? 4 : 2) : 0) | (emit ? 8 : 0)) : 0;
+#define URSO_LAUNCH(BN_, AD_, MK_, SP_, EM_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_, SP_, EM_>), grid, blk, 0, st, a)
+#define URSO_SEL(BN_) switch (sel) { \
+        case 0: URSO_LAUNCH(BN_, false, 0, false, false); break; case 1: URSO_LAUNCH(BN_, true, 0, false, false); break; \
+        case 2: URSO_LAUNCH(BN_, false, 1, false, false); break; case 3: URSO_LAUNCH(BN_, true, 1, false, false); break; \
+        case 4: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, false, 2, false, false); break; \
+        case 5: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, true, 2, false, false); break; \
+        case 8: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, false, 0, false, true); break; \
+        case 9: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, true, 0, false, true); break; \
+        default: urso_set_error("urso_conv_igemm: unsupported epilogue combination"); return URSO_EINVAL; }
+    if (a.ksplit > 1) { if (small) URSO_LAUNCH(64, false, 0, true, false); else URSO_LAUNCH(128, false, 0, true, false); }
+    else if (small) { URSO_SEL(64) }
+    else { URSO_SEL(128) }
+#undef URSO_SEL
 #undef URSO_LAUNCH
     if (a.ksplit > 1) {
         const size_t elems = (size_t)a.M * g->N, n4 = elems / 4;
@@ -443,6 +479,20 @@ extern "C" int urso_conv_igemm(const urso_conv_geom* g, int dt, int flags,
 extern "C" int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
                                   const void* src_d, const void* wgt_d, const float* bias_d,
                                   const void* add_d, const void* mask_d, void* dst_d, void* ws_d, size_t ws_bytes, void* stream) {
+    return urso_conv_igemm_ex(g, dt, flags & ~(URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS), src_d, wgt_d, bias_d, add_d, mask_d, dst_d, nullptr,
+                              ws_d, ws_bytes, stream);
+}
+
+extern "C" int urso_conv_igemm_bits_ok(const urso_conv_geom* g, int dt, int flags, size_t ws_bytes) {
+    if (!g || dt == URSO_F32 || (flags & URSO_EPI_OUT_F32) || (g->N % 8) || (g->C % 8)) return 0;
+    if (ws_bytes && urso_conv_igemm_ws_bytes(g, dt)) return 0;          // split-K would be chosen
+    return 1;
+}
+
+extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
+                                  const void* src_d, const void* wgt_d, const float* bias_d,
+                                  const void* add_d, const void* mask_d, void* dst_d, void* bits_out_d,
+                                  void* ws_d, size_t ws_bytes, void* stream) {
     if (!g || !src_d || !wgt_d || !dst_d) { urso_set_error("urso_conv_igemm: null argument"); return URSO_EINVAL; }
     if (dt != URSO_F32 && dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_conv_igemm: bad dtype %d", dt); return URSO_EINVAL; }
     const size_t es = dt_size(dt);
@@ -468,6 +518,7 @@ extern "C" int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     a.M = g->B * g->OH * g->OW; a.Cc = g->C / VE; a.Kc = g->KH * g->KW * a.Cc; a.nkt = ceil_div(a.Kc, 8);
     a.flags = flags;
+    a.bits_out = bits_out_d; a.bits_bytes = (uint32_t)(dst_elems / 8);
     a.FH = scatter ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
     a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 &&
                    g->H == g->OH && g->W == g->OW) ? 1 : 0;
@@ -476,7 +527,8 @@ extern "C" int urso_conv_igemm_ws(const urso_conv_geom* g, int dt, int flags,
     double flops = 2.0 * a.M * (double)g->N * g->KH * g->KW * g->C;
     if (g->DH > 1 || g->DW > 1) flops /= (double)(g->DH * g->DW);     // gather-form dgrad: only 1/(DH*DW) taps are real
     double bytes = (double)src_bytes + (double)wgt_bytes + (double)dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
-                   (add_d ? dst_elems * es : 0) + (mask_d ? dst_elems * es : 0);
+                   (add_d ? dst_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? dst_elems / 8 : dst_elems * es) : 0) +
+                   ((flags & URSO_EPI_EMIT_BITS) ? dst_elems / 8 : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, ws_d, ws_bytes, st);
     if (dt == URSO_BF16) return launch_igemm<__bf16>(g, flags, a, ws_d, ws_bytes, st);

@@ -39,6 +39,7 @@ class _Act(object):
         self.grad = None
         self.grad_written = False
         self.pending = None          # gradient tensor to be folded into the next dgrad into this tensor
+        self.bits = None             # ReLU bit mask (1 byte per 8 elements), written by the producing conv's forward epilogue
         self.eng = eng
 
     def grad_buf(self):
@@ -247,9 +248,10 @@ class Engine(object):
             c.ws_f = hip.conv_igemm_ws_bytes(c.gf, dt)
             c.ws_d = hip.conv_igemm_ws_bytes(c.gd, dt) if (c.gd is not None and training) else 0
             max_igemm_ws = max(max_igemm_ws, c.ws_f, c.ws_d)
-            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ws(c.gf, dt, f, c.src.data, c.wf, c.biasf,
-                                                                       c.res.data if c.res is not None else None, None, c.dst.data,
-                                                                       self.igemm_ws if c.ws_f else None))
+            c.fwd_flags = flags
+            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
+                c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
+                c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits, self.igemm_ws if c.ws_f else None))
             self.labels["fwd"].append("fwd:" + node.name)
             if training and node.stem:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
@@ -270,6 +272,7 @@ class Engine(object):
         self.ws = torch.empty(max_ws // 4 + 64, dtype=torch.float32, device=dev)
         self.fin_ws = torch.empty(max_fin_ws // 4 + 64, dtype=torch.float32, device=dev)
         self._build_losses()
+        self._plan_relu_bitmasks()
         # gradient buckets (contiguous slices of the flat gradient buffer, in the order the backward pass completes them):
         # the split reduction + finalisation of all layers of a bucket is three batched launches issued once the last of
         # their weight-gradient partials is enqueued; ursonet_amd/dp.py starts the bucket's all-reduce right after.
@@ -357,15 +360,16 @@ class Engine(object):
                 X = c.src
                 add = X.grad if X.grad_written else X.pending
                 dstg = X.grad_buf()
-                mask = X.data if X.spec.relu else None
+                mask = (X.bits if X.bits is not None else X.data) if X.spec.relu else None
+                mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
                 if getattr(c, "gd_scatter", False):
                     if add is None:                       # first contribution: everything off the sampled grid is zero
                         self.bwd_ops.append((None, lambda t=dstg: t.zero_()))       # torch fill: no profiler record
                         self.labels["bwd"].append(None)
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
-                self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg:
-                                     hip.conv_igemm_ws(c.gd, dt, 0, G, c.wd, None, add, mask, dstg, self.igemm_ws if c.ws_d else None)))
+                self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg, mflag=mflag:
+                                     hip.conv_igemm_ex(c.gd, dt, mflag, G, c.wd, None, add, mask, dstg, None, self.igemm_ws if c.ws_d else None)))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
@@ -391,6 +395,27 @@ class Engine(object):
         self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
         self.labels["opt"] += ["sqnorm", "sgd"]
         self.flat_g.zero_()
+
+    def _plan_relu_bitmasks(self):
+        """A post-ReLU tensor gets a bit mask (1/16 of its bytes) for the backward pass when the conv that produces it can
+        emit one from its forward epilogue and every data-gradient pass into it can consume one (urso_conv_igemm_bits_ok);
+        otherwise the tensor itself serves as the mask, as before."""
+        dt = self.dt
+        import os
+        enabled = os.environ.get("URSO_RELU_BITS", "0") == "1"      # measured on MI355X (round 1): emitting costs the forward
+        for X in self.acts.values():                                # pass more than the data-gradient pass gains -> off by default
+            X.bits = None
+            if not enabled or not X.spec.relu or X.numel % 8:
+                continue
+            prod = [c for c in self.convs.values() if c.dst is X]
+            cons = [c for c in self.convs.values() if c.src is X and getattr(c, "gd", None) is not None]
+            if len(prod) != 1 or not cons or not prod[0].node.relu:
+                continue
+            P = prod[0]
+            if not hip.conv_igemm_bits_ok(P.gf, dt, P.fwd_flags, P.ws_f):
+                continue
+            if all(hip.conv_igemm_bits_ok(c.gd, dt, 0, c.ws_d) for c in cons):
+                X.bits = torch.empty(X.numel // 8, dtype=torch.uint8, device=self.device)
 
     def _upload_param_table(self):
         self.pbatch = hip.ParamBatch(self._descs, self.device) if self._descs else None

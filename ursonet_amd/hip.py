@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liburso_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-EPI_RELU, EPI_OUT_F32 = 1, 2
+EPI_RELU, EPI_OUT_F32, EPI_MASK_BITS, EPI_EMIT_BITS = 1, 2, 4, 8
 K_IGEMM, K_WGRAD, K_PREP, K_FINALIZE, K_POOL, K_LOSS, K_OPTIM, K_DECODE, K_MOLD = range(1, 10)
 KERNEL_NAMES = {K_IGEMM: "conv_igemm", K_WGRAD: "conv_wgrad", K_PREP: "weight_prep", K_FINALIZE: "param_grad_finalize",
                 K_POOL: "maxpool", K_LOSS: "loss", K_OPTIM: "optimizer", K_DECODE: "quat_decode", K_MOLD: "mold"}
@@ -64,6 +64,8 @@ _SIGS = {
     "urso_conv_igemm": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp]),
     "urso_conv_igemm_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "urso_conv_igemm_bits_ok": (_i, [_gp, _i, _i, _sz]),
+    "urso_conv_igemm_ex": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_wgrad": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
     "urso_conv_wgrad_splits": (_i, [_gp, _i]),
@@ -141,6 +143,15 @@ def conv_igemm_ws(g, dt, flags, src, wgt, bias, add, mask, dst, ws, stream=None)
     _chk(_lib.urso_conv_igemm_ws(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
                                  ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, stream_ptr(stream)),
          "urso_conv_igemm_ws")
+
+
+def conv_igemm_bits_ok(g, dt, flags, ws_bytes=0):
+    return bool(_lib.urso_conv_igemm_bits_ok(C.byref(g), dt, flags, ws_bytes))
+
+
+def conv_igemm_ex(g, dt, flags, src, wgt, bias, add, mask, dst, bits_out=None, ws=None, stream=None):
+    _chk(_lib.urso_conv_igemm_ex(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst), ptr(bits_out),
+                                 ptr(ws), (ws.numel() * ws.element_size()) if ws is not None else 0, stream_ptr(stream)), "urso_conv_igemm_ex")
 
 
 def conv_wgrad_ws_bytes(g, dt):
