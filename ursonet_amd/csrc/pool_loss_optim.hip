@@ -8,10 +8,10 @@ template <typename T>
 __global__ void maxpool_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ am) {
     constexpr int VE = Elem<T>::VE;
     const int OH = H / 2, OW = W / 2, Cv = C / VE;
-    const size_t total = (size_t)B * OH * OW * Cv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % Cv); size_t p = i / Cv;
-        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int b = (int)(p / OH);
+    const uint32_t total = (uint32_t)B * OH * OW * Cv;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (uint32_t)Cv); uint32_t p = i / (uint32_t)Cv;
+        const int ox = (int)(p % (uint32_t)OW); p /= (uint32_t)OW; const int oy = (int)(p % (uint32_t)OH); const int b = (int)(p / (uint32_t)OH);
         float best[VE]; int arg[VE];
 #pragma unroll
         for (int q = 0; q < VE; ++q) { best[q] = -INFINITY; arg[q] = 0; }
@@ -37,48 +37,56 @@ __global__ void maxpool_fwd_kernel(int B, int H, int W, int C, const T* __restri
     }
 }
 
+// One thread = one 16-byte channel vector of a 2x2 block of input pixels (2oy..2oy+1, 2ox..2ox+1): the four pooling
+// windows that can touch the block -- (oy,ox), (oy-1,ox), (oy,ox-1), (oy-1,ox-1) -- are loaded once and routed to the
+// four pixels (window (oy',ox') covers input rows 2oy'..2oy'+2), instead of every input pixel re-reading its windows.
 template <typename T>
 __global__ void maxpool_bwd_kernel(int B, int H, int W, int C, const T* __restrict__ y, const T* __restrict__ dy,
                                    const uint8_t* __restrict__ am, int relu_mask, T* __restrict__ dx) {
     constexpr int VE = Elem<T>::VE;
     const int OH = H / 2, OW = W / 2, Cv = C / VE;
-    const size_t total = (size_t)B * H * W * Cv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % Cv); size_t p = i / Cv;
-        const int ix = (int)(p % W); p /= W; const int iy = (int)(p % H); const int b = (int)(p / H);
-        float g[VE];
+    const uint32_t total = (uint32_t)B * OH * OW * Cv;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (uint32_t)Cv); uint32_t p = i / (uint32_t)Cv;
+        const int ox = (int)(p % (uint32_t)OW); p /= (uint32_t)OW; const int oy = (int)(p % (uint32_t)OH); const int b = (int)(p / (uint32_t)OH);
+        float g[4][VE];                                   // [2*dy + dx] of the 2x2 block
 #pragma unroll
-        for (int q = 0; q < VE; ++q) g[q] = 0.f;
-        // windows containing (iy, ix): oy = iy/2 with ky = iy&1, and (iy even) oy = iy/2 - 1 with ky = 2
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < VE; ++q) g[k][q] = 0.f;
 #pragma unroll
         for (int wy = 0; wy < 2; ++wy) {
-            int oy, ky;
-            if (wy == 0) { oy = iy >> 1; ky = iy & 1; } else { if (iy & 1) continue; oy = (iy >> 1) - 1; ky = 2; }
-            if (oy < 0 || oy >= OH) continue;
+            const int woy = oy - wy;
+            if (woy < 0) continue;
 #pragma unroll
             for (int wx = 0; wx < 2; ++wx) {
-                int ox, kx;
-                if (wx == 0) { ox = ix >> 1; kx = ix & 1; } else { if (ix & 1) continue; ox = (ix >> 1) - 1; kx = 2; }
-                if (ox < 0 || ox >= OW) continue;
-                const size_t ob = (((size_t)b * OH + oy) * OW + ox) * C + cv * VE;
+                const int wox = ox - wx;
+                if (wox < 0) continue;
+                const size_t ob = (((size_t)b * OH + woy) * OW + wox) * C + cv * VE;
                 uint8_t ab[VE]; __builtin_memcpy(ab, am + ob, VE);
                 i32x4_t rd = *(const i32x4_t*)(dy + ob); T ed[VE]; __builtin_memcpy(ed, &rd, 16);
                 T ey[VE];
                 if (relu_mask) { i32x4_t ry = *(const i32x4_t*)(y + ob); __builtin_memcpy(ey, &ry, 16); }
-                const int tap = ky * 3 + kx;
+                // window row ky lands on block row r when 2*woy + ky == 2*oy + r: this window (wy) sees block rows
+                // r = ky - 2*wy, i.e. wy = 0: ky = 0,1 -> r = 0,1;  wy = 1: ky = 2 -> r = 0.  Same for columns.
 #pragma unroll
                 for (int q = 0; q < VE; ++q) {
-                    bool hit = (ab[q] == tap);
-                    if (relu_mask) hit = hit && (Elem<T>::to_f(ey[q]) > 0.f);
-                    if (hit) g[q] += Elem<T>::to_f(ed[q]);
+                    const float d = (!relu_mask || Elem<T>::to_f(ey[q]) > 0.f) ? Elem<T>::to_f(ed[q]) : 0.f;
+                    const int ky = ab[q] / 3, kx = ab[q] - ky * 3;
+                    const int r = ky - 2 * wy, c = kx - 2 * wx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k][q] += (r == (k >> 1) && c == (k & 1)) ? d : 0.f;
                 }
             }
         }
-        T o[VE];
 #pragma unroll
-        for (int q = 0; q < VE; ++q) o[q] = Elem<T>::from_f(g[q]);
-        i32x4_t ov; __builtin_memcpy(&ov, o, 16);
-        *(i32x4_t*)(dx + (((size_t)b * H + iy) * W + ix) * C + cv * VE) = ov;
+        for (int k = 0; k < 4; ++k) {
+            T o[VE];
+#pragma unroll
+            for (int q = 0; q < VE; ++q) o[q] = Elem<T>::from_f(g[k][q]);
+            i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+            *(i32x4_t*)(dx + (((size_t)b * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * C + cv * VE) = ov;
+        }
     }
 }
 
@@ -89,6 +97,7 @@ extern "C" int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const v
     if (!x_d || !y_d || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_fwd: bad argument (H,W even; C multiple of %d)", VE); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
+    if (total >= 0x7FFFFFFFull) { urso_set_error("urso_maxpool3x3s2_fwd: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.25 + (double)B * H * W * C / 4);
     if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)x_d, (float*)y_d, argmax_d);
     else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)x_d, (__bf16*)y_d, argmax_d);
@@ -101,7 +110,8 @@ extern "C" int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const v
     const int VE = 16 / (int)dt_size(dt);
     if (!dy_d || !argmax_d || !dx_d || (relu_mask && !y_d) || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    const size_t total = (size_t)B * H * W * (C / VE);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
+    if (total >= 0x7FFFFFFFull) { urso_set_error("urso_maxpool3x3s2_bwd: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.5 + (double)B * H * W * C / 4);
     if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)y_d, (const float*)dy_d, argmax_d, relu_mask, (float*)dx_d);
     else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)y_d, (const __bf16*)dy_d, argmax_d, relu_mask, (__bf16*)dx_d);
