@@ -247,6 +247,12 @@ size_t urso_sqnorm_ws_bytes(size_t n);
 int urso_sqnorm(size_t n, const float* g_d, void* ws_d, size_t ws_bytes, float* out_d, void* stream);
 int urso_sgd_momentum_clip(size_t n, float* w_d, const float* g_d, float* v_d,
                            const float* hyper_d, const float* normsq_d, void* stream);
+/* keras.optimizers.Adam(lr, amsgrad=True, clipnorm) (the reference's non-SGD branch, net.py:982-983): global-norm clip,
+ * t += 1, lr_t = lr sqrt(1-b2^t)/(1-b1^t), m/v moments, vhat = max(vhat, v), w -= lr_t m / (sqrt(vhat) + eps).
+ * hyper_d = device fp32 {lr, beta_1, beta_2, epsilon, clipnorm, t, 1-beta_1, 1-beta_2}; t is advanced on the device by
+ * every call (a captured hipGraph keeps counting). */
+int urso_adam_amsgrad_clip(size_t n, float* w_d, const float* g_d, float* m_d, float* v_d, float* vhat_d,
+                           float* hyper_d, const float* normsq_d, void* stream);
 int urso_scale_f32(size_t n, float* x_d, float s, void* stream);
 
 /*

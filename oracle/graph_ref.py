@@ -404,10 +404,33 @@ def sgd_step(P, grads, velocity, lr, momentum, clipnorm):
     return norm
 
 
+def adam_step(P, grads, state, lr, clipnorm, epsilon=1e-7, beta_1=0.9, beta_2=0.999):
+    """keras.optimizers.Adam(lr, amsgrad=True, clipnorm) as net.py:982-983 builds it [Keras 2.x Adam.get_updates]:
+    global-norm clip; t = iterations + 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+    vhat = max(vhat, v); p -= lr_t * m / (sqrt(vhat) + eps).  In place; `state` carries t, m, v, vhat."""
+    norm = global_norm(grads)
+    scale = clipnorm / norm if (clipnorm and clipnorm > 0 and norm >= clipnorm) else 1.0
+    t = state["t"] = state.get("t", 0) + 1
+    lr_t = lr * (math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t))
+    with torch.no_grad():
+        for ln, ws in grads.items():
+            for wn, g in ws.items():
+                g = g * scale
+                st = state.setdefault((ln, wn), {"m": torch.zeros_like(g), "v": torch.zeros_like(g), "vhat": torch.zeros_like(g)})
+                st["m"] = beta_1 * st["m"] + (1.0 - beta_1) * g
+                st["v"] = beta_2 * st["v"] + (1.0 - beta_2) * g * g
+                st["vhat"] = torch.maximum(st["vhat"], st["v"])
+                P[ln][wn].sub_(lr_t * st["m"] / (torch.sqrt(st["vhat"]) + epsilon))
+    return norm
+
+
 def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*", relu_hook=None):
     """One fit_generator step [A13]: fwd, loss, bwd, clip, update.  Returns dict of scalars/outputs."""
     grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook)
-    norm = sgd_step(P, grads, velocity, lr, config.LEARNING_MOMENTUM, config.GRADIENT_CLIP_NORM)
+    if str(getattr(config, "OPTIMIZER", "SGD")).upper() == "SGD":
+        norm = sgd_step(P, grads, velocity, lr, config.LEARNING_MOMENTUM, config.GRADIENT_CLIP_NORM)
+    else:
+        norm = adam_step(P, grads, velocity, lr, config.GRADIENT_CLIP_NORM, 1e-4 if getattr(config, "F16", False) else 1e-7)
     return {"loc": loc, "ori": ori, "loc_loss": float(ll), "ori_loss": float(ol), "total": float(tot),
             "grad_norm": norm, "grads": grads}
 

@@ -540,3 +540,31 @@ def test_bit_masks_refused_where_unsupported():
     bits = torch.zeros(2 * 8 * 8 * 2, dtype=torch.uint8, device="cuda")
     with pytest.raises(hip.UrsoHipError):
         hip.conv_igemm_ex(g, 0, hip.EPI_RELU | hip.EPI_EMIT_BITS, x, w, None, None, None, y, bits)
+
+
+def test_adam_amsgrad_clip_against_numpy():
+    """urso_adam_amsgrad_clip over three steps (device-side step counter) vs a float64 NumPy restatement of
+    Keras' Adam(amsgrad=True, clipnorm) update (net.py:982-983)."""
+    hip = _hip()
+    rng = np.random.default_rng(5)
+    n = 10007
+    w = rng.normal(size=n).astype(np.float32)
+    lr, b1, b2, eps, clip = 1e-3, 0.9, 0.999, 1e-7, 5.0
+    W = dev(torch.tensor(w)); M = torch.zeros(n, device="cuda"); V = torch.zeros(n, device="cuda"); VH = torch.zeros(n, device="cuda")
+    hyper = torch.tensor([lr, b1, b2, eps, clip, 0.0, 1.0 - b1, 1.0 - b2], device="cuda")
+    ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4 + 4, device="cuda"); nsq = torch.zeros(1, device="cuda")
+    wr = w.astype(np.float64); m = np.zeros(n); v = np.zeros(n); vh = np.zeros(n)
+    for t in range(1, 4):
+        g = (rng.normal(size=n) * (3.0 if t == 2 else 0.01)).astype(np.float32)     # step 2 is clipped
+        G = dev(torch.tensor(g))
+        hip.sqnorm(n, G, ws, nsq)
+        hip.adam_amsgrad_clip(n, W, G, M, V, VH, hyper, nsq)
+        norm = np.sqrt((g.astype(np.float64) ** 2).sum())
+        gc = g.astype(np.float64) * (clip / norm if norm >= clip else 1.0)
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        m = b1 * m + (1 - b1) * gc; v = b2 * v + (1 - b2) * gc * gc; vh = np.maximum(vh, v)
+        wr = wr - lr_t * m / (np.sqrt(vh) + eps)
+        torch.cuda.synchronize()
+        assert float(hyper[5]) == t
+        assert np.abs(W.cpu().numpy() - wr).max() < 2e-6
+        assert np.abs(VH.cpu().numpy() - vh).max() <= 2e-6 * vh.max()

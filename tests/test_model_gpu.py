@@ -184,3 +184,36 @@ def test_inference_forward_matches_oracle_r101():
     loc, ori = G.forward(P, torch.tensor(img), cfg)
     gl, go = eng.outputs()
     assert _rel(gl.cpu().numpy(), loc.numpy()) < 1e-3 and _rel(go.cpu().numpy(), ori.numpy()) < 1e-3
+
+
+def test_adam_training_steps_match_oracle():
+    """OPTIMIZER != 'SGD' -> Adam(amsgrad, clipnorm) (net.py:982-983): two hipGraph replays vs two oracle steps.
+    Adam's first updates are ~lr*sign(g), so weights whose gradient is ~0 are excluded from the comparison."""
+    from ursonet_amd.engine import Engine
+    cfg = make_config(dtype="float32", backbone="resnet18", h=64, w=64, batch=2, regress_ori=True)
+    cfg.OPTIMIZER = "ADAM"
+    img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=4)
+    eng = Engine(cfg, "training", seed=5, randomize_bn=True)
+    assert eng.adam
+    w0 = eng.get_weights()
+    eng.load_batch(img, loc, ori)
+    eng.step(); eng.step()
+    torch.cuda.synchronize()
+    assert float(eng.hyper[5]) == 2.0
+    from oracle import graph_ref as G
+    P = G.to_torch(w0); st = {}
+    r1 = G.train_step(P, st, torch.tensor(img), torch.tensor(loc), torch.tensor(ori), cfg, cfg.LEARNING_RATE)
+    G.train_step(P, st, torch.tensor(img), torch.tensor(loc), torch.tensor(ori), cfg, cfg.LEARNING_RATE)
+    w2 = eng.get_weights()
+    worst = 0.0
+    for ln, ws in P.items():
+        for wn, wref in ws.items():
+            if wn in ("moving_mean", "moving_variance"):
+                continue
+            g1 = r1["grads"][ln][wn].numpy()
+            sel = np.abs(g1) > 1e-4 * np.abs(g1).max()
+            d_ref = (wref.detach().numpy() - w0[ln][wn])[sel]
+            d_gpu = (w2[ln][wn] - w0[ln][wn])[sel]
+            if sel.any():
+                worst = max(worst, float(np.abs(d_gpu - d_ref).max() / (np.abs(d_ref).max() + 1e-30)))
+    assert worst < 2e-2, worst

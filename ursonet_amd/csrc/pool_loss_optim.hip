@@ -329,6 +329,37 @@ extern "C" int urso_sgd_momentum_clip(size_t n, float* w_d, const float* g_d, fl
     return urso_check_launch("urso_sgd_momentum_clip");
 }
 
+// keras.optimizers.Adam(lr, amsgrad=True, clipnorm) (net.py:982-983; Keras 2.x get_updates): global-norm clip, then
+//   t += 1; lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; vhat = max(vhat, v);
+//   w -= lr_t m / (sqrt(vhat) + eps).       hyper = {lr, b1, b2, eps, clipnorm, t}: t lives on the device so that a
+// captured hipGraph advances it on every replay (adam_tick_kernel runs first, alone, so no block reads a half-written t).
+__global__ void adam_tick_kernel(float* hyper) { if (threadIdx.x == 0 && blockIdx.x == 0) hyper[5] += 1.0f; }
+__global__ void adam_kernel(size_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vhat, const float* __restrict__ hyper, const float* __restrict__ normsq) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], clip = hyper[4], t = hyper[5], c1 = hyper[6], c2 = hyper[7];
+    const float norm = sqrtf(normsq[0]);
+    const float c = (clip > 0.f && norm >= clip) ? clip / norm : 1.f;
+    const float lr_t = lr * (sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * c;
+        const float mi = b1 * m[i] + c1 * gi;
+        const float vi = b2 * v[i] + c2 * (gi * gi);
+        const float vh = fmaxf(vhat[i], vi);
+        m[i] = mi; v[i] = vi; vhat[i] = vh;
+        w[i] = w[i] - lr_t * mi / (sqrtf(vh) + eps);
+    }
+}
+extern "C" int urso_adam_amsgrad_clip(size_t n, float* w_d, const float* g_d, float* m_d, float* v_d, float* vhat_d,
+                                      float* hyper_d, const float* normsq_d, void* stream) {
+    if (!w_d || !g_d || !m_d || !v_d || !vhat_d || !hyper_d || !normsq_d) { urso_set_error("urso_adam_amsgrad_clip: null argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 36);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, hyper_d);
+    size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, m_d, v_d, vhat_d, (const float*)hyper_d, normsq_d);
+    return urso_check_launch("urso_adam_amsgrad_clip");
+}
+
 __global__ void scale_kernel(size_t n, float* __restrict__ x, float s) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
 }

@@ -117,9 +117,9 @@ class DataParallelEngine(object):
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(torch.cuda.current_stream(eng.device))
         with torch.cuda.stream(side):
-            saved = (eng.flat_w.clone(), eng.flat_v.clone())
+            saved = eng.save_train_state()
             eng.step_eager()
-            eng.flat_w.copy_(saved[0]); eng.flat_v.copy_(saved[1])
+            eng.restore_train_state(saved)
         torch.cuda.current_stream(eng.device).wait_stream(side)
         torch.cuda.synchronize(eng.device)
         graphs = []

@@ -387,13 +387,25 @@ class Engine(object):
         self.bwd_ops, self.labels["bwd"] = resolved, labels
         # ---------------------------------------------------------------- optimizer
         n = self.n_flat
-        self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), float(cfg.GRADIENT_CLIP_NORM or 0.0)],
-                                  dtype=torch.float32, device=dev)
+        self.adam = str(getattr(cfg, "OPTIMIZER", "SGD")).upper() != "SGD"          # net.py:979-983: anything else is Adam(amsgrad)
+        clip = float(cfg.GRADIENT_CLIP_NORM or 0.0)
+        if self.adam:
+            eps = 1e-4 if getattr(cfg, "F16", False) else 1e-7                      # K.epsilon(); net.py:590-593 sets 1e-4 in F16 mode
+            self.hyper = torch.tensor([float(cfg.LEARNING_RATE), 0.9, 0.999, eps, clip, 0.0, 1.0 - 0.9, 1.0 - 0.999],
+                                      dtype=torch.float32, device=dev)
+            if not hasattr(self, "flat_v2") or self.flat_v2.numel() != self.flat_w.numel():
+                self.flat_v2, self.flat_vhat = torch.zeros_like(self.flat_w), torch.zeros_like(self.flat_w)
+        else:
+            self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), clip], dtype=torch.float32, device=dev)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sq_ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, dtype=torch.float32, device=dev)
         self.opt_ops.append(lambda: hip.sqnorm(n, self.flat_g, self.sq_ws, self.normsq))
-        self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
-        self.labels["opt"] += ["sqnorm", "sgd"]
+        if self.adam:
+            self.opt_ops.append(lambda: hip.adam_amsgrad_clip(n, self.flat_w, self.flat_g, self.flat_v, self.flat_v2, self.flat_vhat,
+                                                              self.hyper, self.normsq))
+        else:
+            self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
+        self.labels["opt"] += ["sqnorm", "adam" if self.adam else "sgd"]
         self.flat_g.zero_()
 
     def _plan_relu_bitmasks(self):
@@ -525,9 +537,9 @@ class Engine(object):
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):                     # warm-up launch outside capture (module load etc.)
             if self.mode == "training":
-                saved = (self.flat_w.clone(), self.flat_v.clone())
+                saved = self.save_train_state()
                 self.step_eager()
-                self.flat_w.copy_(saved[0]); self.flat_v.copy_(saved[1])
+                self.restore_train_state(saved)
             else:
                 self.run_prep(); self.run_forward()
         torch.cuda.current_stream(self.device).wait_stream(s)
@@ -582,8 +594,22 @@ class Engine(object):
     def set_lr(self, lr):
         self.hyper[0] = float(lr)
 
+    def save_train_state(self):
+        """Weights + optimizer state (incl. Adam's device-side step counter), for the warm-up step before graph capture."""
+        st = [self.flat_w.clone(), self.flat_v.clone()]
+        if getattr(self, "adam", False):
+            st += [self.flat_v2.clone(), self.flat_vhat.clone(), self.hyper.clone()]
+        return st
+
+    def restore_train_state(self, st):
+        self.flat_w.copy_(st[0]); self.flat_v.copy_(st[1])
+        if getattr(self, "adam", False):
+            self.flat_v2.copy_(st[2]); self.flat_vhat.copy_(st[3]); self.hyper.copy_(st[4])
+
     def reset_optimizer(self):
         self.flat_v.zero_()
+        if getattr(self, "adam", False):
+            self.flat_v2.zero_(); self.flat_vhat.zero_(); self.hyper[5] = 0.0
 
     def flops(self):
         return conv_flops(self.graph, self.B)

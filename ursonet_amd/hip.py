@@ -89,6 +89,7 @@ _SIGS = {
     "urso_sqnorm_ws_bytes": (_sz, [_sz]),
     "urso_sqnorm": (_i, [_sz, _fp, _vp, _sz, _fp, _vp]),
     "urso_sgd_momentum_clip": (_i, [_sz, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "urso_adam_amsgrad_clip": (_i, [_sz, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "urso_scale_f32": (_i, [_sz, _fp, _f, _vp]),
     "urso_quat_wavg_decode": (_i, [_i, _i, _fp, _fp, _fp, _fp, _vp]),
     "urso_warp_perspective": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -276,6 +277,11 @@ def sqnorm(n, g, ws, out, stream=None):
 def sgd_momentum_clip(n, w, g, v, hyper, normsq, stream=None):
     _chk(_lib.urso_sgd_momentum_clip(n, ptr(w), ptr(g), ptr(v), ptr(hyper), ptr(normsq), stream_ptr(stream)),
          "urso_sgd_momentum_clip")
+
+
+def adam_amsgrad_clip(n, w, g, m, v, vhat, hyper, normsq, stream=None):
+    _chk(_lib.urso_adam_amsgrad_clip(n, ptr(w), ptr(g), ptr(m), ptr(v), ptr(vhat), ptr(hyper), ptr(normsq), stream_ptr(stream)),
+         "urso_adam_amsgrad_clip")
 
 
 def scale_f32(n, x, s, stream=None):

@@ -347,12 +347,13 @@ class UrsoNet(object):
     def compile(self, learning_rate, momentum):
         """net.py:973-1028: (re)creates the optimizer state (momentum buffers reset, as a new Keras
         optimizer would), sets lr/momentum/clipnorm.  Loss assembly and the L2 term live in the engine."""
-        if self.config.OPTIMIZER != 'SGD':
-            raise NotImplementedError("only OPTIMIZER='SGD' (the CLI's hard-coded choice, pose_estimator.py:830)")
         eng = self._engine
         eng.hyper[0] = float(learning_rate)
-        eng.hyper[1] = float(momentum)
-        eng.hyper[2] = float(self.config.GRADIENT_CLIP_NORM or 0.0)
+        if eng.adam:                                   # OPTIMIZER != 'SGD': Adam(learning_rate, amsgrad=True, clipnorm), net.py:982-983
+            eng.hyper[4] = float(self.config.GRADIENT_CLIP_NORM or 0.0)
+        else:
+            eng.hyper[1] = float(momentum)
+            eng.hyper[2] = float(self.config.GRADIENT_CLIP_NORM or 0.0)
         eng.reset_optimizer()
 
     def set_trainable(self, layer_regex, keras_model=None, indent=0, verbose=1):
