@@ -70,6 +70,9 @@ class DataParallelEngine(object):
 
     def __init__(self, engine, bucket_bytes=32 << 20, group=None):
         self.eng, self.group = engine, group
+        if getattr(engine.config, "DP_EXACT_REL_LOSS", False):
+            raise NotImplementedError("DP_EXACT_REL_LOSS (all-reduce of the two batch norms of rel_loss_graph before its gradient) is not "
+                                      "built yet: data-parallel steps use the per-rank loss, as a tower-parallel Keras model would")
         self.world = dist.get_world_size(group)
         eng = engine
         dist.broadcast(eng.flat_w, src=0, group=group)
