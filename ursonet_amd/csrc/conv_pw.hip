@@ -1,0 +1,249 @@
+// Pointwise (1x1, stride 1) convolution / Dense-as-conv GEMM on MFMA for gfx950, 16-bit dtypes: the forward and
+// data-gradient passes of every branch2a / branch2c / shortcut conv of the bottleneck blocks (net.py:101-157), i.e. 35 of
+// the 54 convs of ResNet-50 and most of its HBM traffic.  Same math, tile shapes, weight layout and register-direct
+// epilogue as conv_igemm.hip (which remains the general kernel), but built around what bounds these layers -- bytes in
+// flight, not MFMA rate:
+//   * both operand tiles go HBM/L2 -> LDS by DMA (buffer_load ... lds): no staging registers, no ds_write pass; the LDS
+//     swizzle is applied on the source side (the lane that lands in slot s of row r loads logical chunk s ^ swz(r));
+//   * the DMAs are issued from inline asm and ordered by hand (s_waitcnt vmcnt(N) with N = the number of younger
+//     operations): through the builtin the compiler waits vmcnt(0) before ANY later LDS read, which serialises the copy
+//     of K-tile k+1 with the MFMAs of K-tile k.  Every compiler-visible load (bias, residual, mask) is consumed only
+//     after one of those hand-placed waits has already covered it, so the compiler's own (weaker) counts are harmless;
+//   * the residual / mask vectors of tile t+1 are requested slot by slot while the epilogue of tile t consumes the
+//     registers ("rolling" prefetch): their latency hides behind a whole tile instead of one K-tile of MFMAs.
+#include "common.h"
+
+struct PwArgs {
+    const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
+    uint32_t src_bytes, wgt_bytes, dst_bytes;
+    int M, C, N, Cc, nkt, tilesN, ntiles;
+    int OH, OW, FH, FW, OSH, OSW;      // destination scatter (FH == 0: dense)
+    float rcp_ohw, rcp_ow;
+    int relu;
+};
+
+__device__ __forceinline__ void pw_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <typename T, int BN, bool HAS_ADD, bool HAS_MASK>
+__global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int BM = 128, VE = 8;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int RA = BM / 32, RB = BN / 32;                 // DMA instructions per thread per K-tile
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr int CH = TN * 4, JPV = VE / 4, NV = CH / VE;    // channels / sub-tiles per vector / vectors per lane per pixel row
+    constexpr int NEPI = TM * NV * (1 + (HAS_ADD ? 1 : 0) + (HAS_MASK ? 1 : 0));   // vm operations an epilogue issues when a next tile exists
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto sA = [&](int buf) -> const char* { return smem + buf * BUF; };
+    auto sB = [&](int buf) -> const char* { return smem + buf * BUF + BM * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = pw_rsrc(a.src, a.src_bytes), rw = pw_rsrc(a.wgt, a.wgt_bytes);
+    const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
+
+    // ---- DMA roles: LDS row r0 + 32 i (pixel tile, then weight tile), physical 16-byte slot c8
+    const int c8 = tid & 7, r0 = tid >> 3;
+    int chA[RA], chB[RB], nrow[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) chA[i] = c8 ^ lds_swz(r0 + 32 * i);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int R = r0 + 32 * i;                     // LDS row of the weight tile -> which filter it must hold (conv_igemm.hip wperm)
+        chB[i] = c8 ^ lds_swz(R);
+        const int w = R / WN, rr = R % WN, j = rr >> 4, q = (rr & 15) >> 2, t = rr & 3;
+        nrow[i] = w * WN + (j / JPV) * 4 * VE + q * VE + (j % JPV) * 4 + t;
+    }
+    auto dma = [&](int ts, int kt, int buf) {
+        const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
+        const uint32_t la = lds0 + buf * BUF + wave * 1024, lb_ = la + BM * 128;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + r0 + 32 * i, kc = kt * 8 + chA[i];
+            const uint32_t off = (uint32_t)m * (uint32_t)a.C * 2u + (uint32_t)kc * 16u;
+            pw_dma16(rs, la + i * 32 * 128, (m < a.M && kc < a.Cc) ? off : URSO_OOB_SHIFT);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + nrow[i], kc = kt * 8 + chB[i];
+            const uint32_t off = ((uint32_t)n * (uint32_t)a.Cc + (uint32_t)kc) * 16u;
+            pw_dma16(rw, lb_ + i * 32 * 128, (n < a.N && kc < a.Cc) ? off : URSO_OOB_SHIFT);
+        }
+    };
+
+    // ---- epilogue geometry of a tile: byte offset of vector v of pixel sub-tile i (OOB when outside the tensor)
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    auto tile_offs = [&](int ts, uint32_t (&eo)[TM]) {          // row base offsets (channel nb + 0); vector v adds v*4*VE*2 bytes
+        const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
+        const int nb = n0 + wn * WN + fg * VE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + fr;
+            int dp = m;
+            if (a.FH != 0 && m < a.M) { int b, rem, oy, ox; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
+                                        dp = (b * a.FH + oy * a.OSH) * a.FW + ox * a.OSW; }
+            eo[i] = (m < a.M && nb < a.N) ? (uint32_t)(((size_t)dp * a.N + nb) * 2) : URSO_OOB_SHIFT;
+        }
+    };
+    // N % 8 == 0 and a lane's vectors are 4*VE channels apart: vector v is inside the tensor iff nb + v*32 < N
+    auto voff = [&](uint32_t base, int ts, int v) -> uint32_t {
+        const int nb = (ts % a.tilesN) * BN + wn * WN + fg * VE + v * 4 * VE;
+        return (nb < a.N) ? base + (uint32_t)(v * 4 * VE * 2) : URSO_OOB_SHIFT;     // OOB base stays out of range
+    };
+
+    i32x4_t radd[HAS_ADD ? TM * NV : 1], rmsk[HAS_MASK ? TM * NV : 1];
+    uint32_t eo_cur[TM], eo_nxt[TM];
+    tile_offs(tile, eo_cur);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const uint32_t o = voff(eo_cur[i], tile, v);
+            if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+            if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+        }
+    dma(tile, 0, 0);
+    pw_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    while (true) {
+        const int n0 = (tile % a.tilesN) * BN;
+        const int next = tile + bpx;
+        const bool has_next = next < t_end;
+        f32x4_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int nb = n0 + wn * WN + fg * VE;
+        i32x4_t rbias[CH / 4];
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            const int nq = nb + (q / JPV) * 4 * VE + (q % JPV) * 4;
+            rbias[q] = buf_load16(rbi, (nq < a.N) ? (uint32_t)nq * 4u : URSO_OOB_SHIFT);
+        }
+        if (has_next) tile_offs(next, eo_nxt);
+
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            const bool last = (kt + 1 == a.nkt);
+            if (!last) dma(tile, kt + 1, cur ^ 1);
+            else if (has_next) dma(next, 0, cur ^ 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x4_t fa[TN], fb[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[j], fb[i], acc[i][j]);
+            }
+            if (!last) { pw_wait_vm<0>(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); cur ^= 1; }
+        }
+        // everything older than the DMAs of the next tile's first K-tile (bias, residual, mask of THIS tile) has landed
+        if (has_next) pw_wait_vm<RA + RB>(); else pw_wait_vm<0>();
+        float bv[CH];
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) { f32x4_t b = __builtin_bit_cast(f32x4_t, rbias[q]); bv[q * 4] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                T ea[VE], em[VE], eo[VE];
+                if constexpr (HAS_ADD) __builtin_memcpy(ea, &radd[i * NV + v], 16);
+                if constexpr (HAS_MASK) __builtin_memcpy(em, &rmsk[i * NV + v], 16);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int c = v * VE + e;
+                    float y = acc[i][c >> 2][c & 3] + bv[c];
+                    if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
+                    y = a.relu ? fmaxf(y, 0.f) : y;
+                    if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                    eo[e] = Elem<T>::from_f(y);
+                }
+                i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                buf_store16(rds, voff(eo_cur[i], tile, v), ov);
+                if (has_next) {                          // this slot's registers are free: request the next tile's vector
+                    const uint32_t o = voff(eo_nxt[i], next, v);
+                    if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+                    if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+                }
+            }
+        }
+        if (!has_next) break;
+        pw_wait_vm<NEPI>();                              // the next tile's first K-tile (issued before this epilogue's stores/loads) is in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+        tile = next;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) eo_cur[i] = eo_nxt[i];
+    }
+}
+
+static int pw_device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+// Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
+int urso_pw_launch(int dt, int M, int C, int N, int OH, int OW, int FH, int FW, int OSH, int OSW, int relu,
+                   const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
+                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
+    PwArgs a;
+    a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
+    a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
+    a.M = M; a.C = C; a.N = N; a.Cc = C / 8; a.nkt = ceil_div(a.Cc, 8);
+    a.OH = OH; a.OW = OW; a.FH = FH; a.FW = FW; a.OSH = OSH; a.OSW = OSW;
+    a.rcp_ohw = 1.0f / (float)(OH * OW); a.rcp_ow = 1.0f / (float)OW; a.relu = relu;
+    const bool small = N <= 64;
+    const int bn = small ? 64 : 128;
+    a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(M, 128) * a.tilesN;
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = (small ? 3 : 2) * pw_device_cus() / 8;
+    if (bpx > cap) bpx = cap;
+    const dim3 grid(8 * bpx), blk(256);
+    const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
+#define URSO_PW(TT, BN_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, false>), grid, blk, 0, st, a); break; \
+                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, false>), grid, blk, 0, st, a); break; \
+                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, true>), grid, blk, 0, st, a); break; \
+                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, true>), grid, blk, 0, st, a); }
+    if (dt == URSO_BF16) { if (small) { URSO_PW(__bf16, 64) } else { URSO_PW(__bf16, 128) } }
+    else { if (small) { URSO_PW(_Float16, 64) } else { URSO_PW(_Float16, 128) } }
+#undef URSO_PW
+    return urso_check_launch("urso_conv_igemm(pointwise)");
+}
