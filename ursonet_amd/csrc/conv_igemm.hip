@@ -394,7 +394,7 @@ static void plan_splitk(int ntiles, int nkt, int ncu, int& S, int& kps) {
     kps = ceil_div(nkt, S); S = ceil_div(nkt, kps);
 }
 
-int urso_pw_launch(int dt, int M, int C, int N, int OH, int OW, int FH, int FW, int OSH, int OSW, int relu,
+int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
                    uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);      // conv_pw.hip
 
@@ -534,16 +534,15 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
                    (add_d ? dst_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? dst_elems / 8 : dst_elems * es) : 0) +
                    ((flags & URSO_EPI_EMIT_BITS) ? dst_elems / 8 : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    // pointwise 16-bit layers with the vector epilogue and no split-K: the DMA-staged kernel of conv_pw.hip
+    // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
         static int use_pw = -1;
-        if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 1; }
-        const bool pw_geom = g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 &&
-                             g->H == g->OH && g->W == g->OW;
+        if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 2; }     // 0 off, 1 pointwise only, 2 all
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
-        if (use_pw && pw_geom && dt != URSO_F32 && !(flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) &&
-            (g->N % 8) == 0 && !split)
-            return urso_pw_launch(dt, a.M, g->C, g->N, g->OH, g->OW, a.FH, a.FW, a.OSH, a.OSW, (flags & URSO_EPI_RELU) ? 1 : 0,
+        const bool fits = dt != URSO_F32 && !(flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) && (g->N % 8) == 0 &&
+                          !split && (size_t)a.M < (1u << 24);
+        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && (a.Cc & 7) == 0)))
+            return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
     }
     if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, ws_d, ws_bytes, st);

@@ -1,8 +1,9 @@
-// Pointwise (1x1, stride 1) convolution / Dense-as-conv GEMM on MFMA for gfx950, 16-bit dtypes: the forward and
-// data-gradient passes of every branch2a / branch2c / shortcut conv of the bottleneck blocks (net.py:101-157), i.e. 35 of
-// the 54 convs of ResNet-50 and most of its HBM traffic.  Same math, tile shapes, weight layout and register-direct
-// epilogue as conv_igemm.hip (which remains the general kernel), but built around what bounds these layers -- bytes in
-// flight, not MFMA rate:
+// DMA-staged implicit-GEMM convolution on MFMA for gfx950, 16-bit dtypes: the forward and data-gradient passes of the
+// bottleneck-block convs of net.py:101-157 whose channel count is a multiple of 64 (every conv of ResNet-50/101 but the
+// stem).  CONV = false is the pointwise (1x1, stride 1) form -- 35 of the 54 convs of ResNet-50 and most of its HBM
+// traffic -- CONV = true adds conv_igemm.hip's source mapping (taps, stride, dilation) for the 3x3 and strided layers.
+// Same math, tile shapes, weight layout and register-direct epilogue as conv_igemm.hip (which remains the general
+// kernel: fp32, the stem, split-K, fp32 outputs), but built around what bounds these layers -- bytes in flight:
 //   * both operand tiles go HBM/L2 -> LDS by DMA (buffer_load ... lds): no staging registers, no ds_write pass; the LDS
 //     swizzle is applied on the source side (the lane that lands in slot s of row r loads logical chunk s ^ swz(r));
 //   * the DMAs are issued from inline asm and ordered by hand (s_waitcnt vmcnt(N) with N = the number of younger
@@ -16,10 +17,11 @@
 struct PwArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
     uint32_t src_bytes, wgt_bytes, dst_bytes;
-    int M, C, N, Cc, nkt, tilesN, ntiles;
+    int M, C, N, Cc, Kc, nkt, tilesN, ntiles;      // Cc = 16-byte chunks per tap, Kc = chunks per filter (KH*KW*Cc)
     int OH, OW, FH, FW, OSH, OSW;      // destination scatter (FH == 0: dense)
     float rcp_ohw, rcp_ow;
     int relu;
+    int H, W, KH, KW, SH, SW, PH, PW, DHs, DWs;   // CONV: general source mapping (conv_igemm.hip), Cc % 8 == 0 so a K-tile never straddles taps
 };
 
 __device__ __forceinline__ void pw_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
@@ -33,7 +35,7 @@ __device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
 }
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <typename T, int BN, bool HAS_ADD, bool HAS_MASK>
+template <typename T, int BN, bool HAS_ADD, bool HAS_MASK, bool CONV>
 __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = 128, VE = 8;
@@ -74,24 +76,6 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
         const int w = R / WN, rr = R % WN, j = rr >> 4, q = (rr & 15) >> 2, t = rr & 3;
         nrow[i] = w * WN + (j / JPV) * 4 * VE + q * VE + (j % JPV) * 4 + t;
     }
-    auto dma = [&](int ts, int kt, int buf) {
-        const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
-        const uint32_t la = lds0 + buf * BUF + wave * 1024, lb_ = la + BM * 128;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int m = m0 + r0 + 32 * i, kc = kt * 8 + chA[i];
-            const uint32_t off = (uint32_t)m * (uint32_t)a.C * 2u + (uint32_t)kc * 16u;
-            pw_dma16(rs, la + i * 32 * 128, (m < a.M && kc < a.Cc) ? off : URSO_OOB_SHIFT);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int n = n0 + nrow[i], kc = kt * 8 + chB[i];
-            const uint32_t off = ((uint32_t)n * (uint32_t)a.Cc + (uint32_t)kc) * 16u;
-            pw_dma16(rw, lb_ + i * 32 * 128, (n < a.N && kc < a.Cc) ? off : URSO_OOB_SHIFT);
-        }
-    };
-
-    // ---- epilogue geometry of a tile: byte offset of vector v of pixel sub-tile i (OOB when outside the tensor)
     const int ohw = a.OH * a.OW;
     auto divmod = [](int n, int d, float rcp, int& q, int& r) {
         q = (int)((float)n * rcp);
@@ -100,6 +84,61 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
         q += hi ? 1 : (lo ? -1 : 0);
         r += hi ? -d : (lo ? d : 0);
     };
+    // CONV: per-row source coordinates of the tile being fetched and the running filter tap of its next K-tile
+    int ty0[CONV ? RA : 1], tx0[CONV ? RA : 1], pb[CONV ? RA : 1];
+    uint32_t rowbase[CONV ? RA : 1];
+    int ft_cc = 0, ft_ky = 0, ft_kx = 0;
+    auto setup_src = [&](int ts) {
+        if constexpr (CONV) {
+            const int m0 = (ts / a.tilesN) * BM;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int m = m0 + r0 + 32 * i;
+                if (m >= a.M) { ty0[i] = -(1 << 24); tx0[i] = 0; pb[i] = 0; }
+                else {
+                    int b, rem, oy, ox;
+                    divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
+                    ty0[i] = oy * a.SH - a.PH; tx0[i] = ox * a.SW - a.PW; pb[i] = b * a.H * a.W;
+                }
+            }
+            ft_cc = 0; ft_ky = 0; ft_kx = 0;
+        }
+    };
+    auto dma = [&](int ts, int kt, int buf) {
+        const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
+        const uint32_t la = lds0 + buf * BUF + wave * 1024, lb_ = la + BM * 128;
+        if constexpr (CONV) {
+            if (ft_cc == 0) {                      // a new filter tap: one coordinate check per row, reused for Cc/8 K-tiles
+                const int dmh = (1 << a.DHs) - 1, dmw = (1 << a.DWs) - 1;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int ty = ty0[i] + ft_ky, tx = tx0[i] + ft_kx;
+                    const int iy = ty >> a.DHs, ix = tx >> a.DWs;
+                    const bool ok = ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
+                    rowbase[i] = ok ? (uint32_t)((pb[i] + iy * a.W + ix) * a.C) * 2u : URSO_OOB_SHIFT;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                pw_dma16(rs, la + i * 32 * 128, rowbase[i] + (uint32_t)(ft_cc + chA[i]) * 16u);      // OOB_SHIFT + small stays out of range
+            ft_cc += 8; if (ft_cc >= a.Cc) { ft_cc = 0; if (++ft_kx == a.KW) { ft_kx = 0; ++ft_ky; } }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int m = m0 + r0 + 32 * i, kc = kt * 8 + chA[i];
+                const uint32_t off = (uint32_t)m * (uint32_t)a.C * 2u + (uint32_t)kc * 16u;
+                pw_dma16(rs, la + i * 32 * 128, (m < a.M && kc < a.Cc) ? off : URSO_OOB_SHIFT);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + nrow[i], kc = kt * 8 + chB[i];
+            const uint32_t off = ((uint32_t)n * (uint32_t)a.Kc + (uint32_t)kc) * 16u;
+            pw_dma16(rw, lb_ + i * 32 * 128, (n < a.N && kc < a.Kc) ? off : URSO_OOB_SHIFT);
+        }
+    };
+
+    // ---- epilogue geometry of a tile: byte offset of vector v of pixel sub-tile i (OOB when outside the tensor)
     auto tile_offs = [&](int ts, uint32_t (&eo)[TM]) {          // row base offsets (channel nb + 0); vector v adds v*4*VE*2 bytes
         const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
         const int nb = n0 + wn * WN + fg * VE;
@@ -129,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
             if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
         }
+    setup_src(tile);
     dma(tile, 0, 0);
     pw_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
@@ -154,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
         for (int kt = 0; kt < a.nkt; ++kt) {
             const bool last = (kt + 1 == a.nkt);
             if (!last) dma(tile, kt + 1, cur ^ 1);
-            else if (has_next) dma(next, 0, cur ^ 1);
+            else if (has_next) { setup_src(next); dma(next, 0, cur ^ 1); }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 i32x4_t fa[TN], fb[TM];
@@ -221,29 +261,33 @@ static int pw_device_cus() {
 }
 
 // Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
-int urso_pw_launch(int dt, int M, int C, int N, int OH, int OW, int FH, int FW, int OSH, int OSW, int relu,
+int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
                    uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
     PwArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
     a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
-    a.M = M; a.C = C; a.N = N; a.Cc = C / 8; a.nkt = ceil_div(a.Cc, 8);
-    a.OH = OH; a.OW = OW; a.FH = FH; a.FW = FW; a.OSH = OSH; a.OSW = OSW;
-    a.rcp_ohw = 1.0f / (float)(OH * OW); a.rcp_ow = 1.0f / (float)OW; a.relu = relu;
+    a.M = g->B * g->OH * g->OW; a.C = g->C; a.N = g->N; a.Cc = g->C / 8; a.Kc = g->KH * g->KW * a.Cc; a.nkt = ceil_div(a.Kc, 8);
+    a.OH = g->OH; a.OW = g->OW; a.FH = g->FH > 0 ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
+    a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu;
+    a.H = g->H; a.W = g->W; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
+    const int N = g->N;
     const bool small = N <= 64;
     const int bn = small ? 64 : 128;
-    a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(M, 128) * a.tilesN;
+    a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = (small ? 3 : 2) * pw_device_cus() / 8;
     if (bpx > cap) bpx = cap;
     const dim3 grid(8 * bpx), blk(256);
     const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
-#define URSO_PW(TT, BN_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, false>), grid, blk, 0, st, a); break; \
-                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, false>), grid, blk, 0, st, a); break; \
-                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, true>), grid, blk, 0, st, a); break; \
-                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, true>), grid, blk, 0, st, a); }
-    if (dt == URSO_BF16) { if (small) { URSO_PW(__bf16, 64) } else { URSO_PW(__bf16, 128) } }
-    else { if (small) { URSO_PW(_Float16, 64) } else { URSO_PW(_Float16, 128) } }
+#define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, false, CV_>), grid, blk, 0, st, a); break; \
+                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, false, CV_>), grid, blk, 0, st, a); break; \
+                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, true, CV_>), grid, blk, 0, st, a); break; \
+                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, true, CV_>), grid, blk, 0, st, a); }
+#define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, true) } else { URSO_PW2(TT, BN_, false) } } while (0)
+    if (dt == URSO_BF16) { if (small) URSO_PW(__bf16, 64); else URSO_PW(__bf16, 128); }
+    else { if (small) URSO_PW(_Float16, 64); else URSO_PW(_Float16, 128); }
 #undef URSO_PW
-    return urso_check_launch("urso_conv_igemm(pointwise)");
+#undef URSO_PW2
+    return urso_check_launch("urso_conv_igemm(dma)");
 }
