@@ -13,6 +13,7 @@
 //   * the residual / mask vectors of tile t+1 are requested slot by slot while the epilogue of tile t consumes the
 //     registers ("rolling" prefetch): their latency hides behind a whole tile instead of one K-tile of MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 struct PwArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
@@ -291,7 +292,10 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu;
     a.H = g->H; a.W = g->W; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     const int N = g->N;
-    const bool small = N <= 64;
+    static int force_small = -1;
+    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 0; }
+    // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU (more bytes in flight for the HBM-bound layers)
+    const bool small = N <= 64 || (force_small == 1) || (force_small == 2 && a.nkt <= 4) || (force_small == 3 && g->KH * g->KW > 1);
     const int bn = small ? 64 : 128;
     a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
     int bpx = ceil_div(a.ntiles, 8);
