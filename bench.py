@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--ori-bins", type=int, default=16)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
