@@ -195,6 +195,27 @@ int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32
                           int32_t* blockmap_h, int cap_blocks);
 int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream);
 
+/*
+ * Batch-statistics BatchNorm (TRAIN_BN = None, "Train BN layers": the BatchNorm wrapper net.py:60-76 forwards
+ * training=None, i.e. Keras' learning phase).  Secondary mode of the reference (config.py:146 defaults to frozen and the
+ * CLI never changes it): the BN cannot be folded into the filter, so the conv writes its raw output z [M pixels][N] and
+ *   urso_bn_batch_stats : mean/var (biased, over all M pixels) and moving = momentum*moving + (1-momentum)*batch (the
+ *                         moving variance is fed var*M/(M-(1+eps)), as Keras 2.x does); moving_* may be NULL
+ *   urso_bn_apply       : y = [relu](gamma (z - mean) rsqrt(var + eps) + beta + res)
+ *   urso_bn_backward    : dbeta = sum g, dgamma = sum g xhat, dz = gamma rstd (g - dbeta/M - xhat dgamma/M); g is the
+ *                         gradient w.r.t. (BN output + residual); gbeta/ggamma (gradient slices) receive the sums
+ *                         (zeros when !bn_trainable) and may be NULL
+ * N % (16/sizeof(dt)) == 0; fp64 slab partials in ws (urso_bn_ws_bytes), fixed summation order.
+ */
+size_t urso_bn_ws_bytes(int M, int N);
+int urso_bn_batch_stats(int M, int N, int dt, const void* z_d, void* ws_d, size_t ws_bytes, float* mean_d, float* var_d,
+                        float* moving_mean_d, float* moving_var_d, float momentum, float eps, void* stream);
+int urso_bn_apply(int M, int N, int dt, const void* z_d, const float* mean_d, const float* var_d, const float* gamma_d,
+                  const float* beta_d, float eps, const void* res_d, int relu, void* y_d, void* stream);
+int urso_bn_backward(int M, int N, int dt, const void* g_d, const void* z_d, const float* mean_d, const float* var_d,
+                     const float* gamma_d, float eps, void* ws_d, size_t ws_bytes, float* dbeta_d, float* dgamma_d,
+                     int bn_trainable, float* gbeta_d, float* ggamma_d, void* dz_d, void* stream);
+
 /* Input molding (mold_image, net.py:1337-1348): dst[b,h,w,0..3] = (src[b,h,w,c] - mean[c], 0) in dt.
  * src is uint8 (src_is_u8=1) or float32 [B,H,W,3]; mean may be NULL (already molded). */
 int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,

@@ -568,3 +568,49 @@ def test_adam_amsgrad_clip_against_numpy():
         assert float(hyper[5]) == t
         assert np.abs(W.cpu().numpy() - wr).max() < 2e-6
         assert np.abs(VH.cpu().numpy() - vh).max() <= 2e-6 * vh.max()
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("MN", [(600, 64), (130, 40), (96, 2048)])
+def test_batch_stat_bn_kernels_against_autograd(dt, MN):
+    """urso_bn_batch_stats / urso_bn_apply / urso_bn_backward (TRAIN_BN=None mode) vs torch autograd through a
+    training-mode batch norm + residual + ReLU; moving statistics follow Keras' update (momentum 0.99, variance fed
+    var*M/(M-(1+eps)))."""
+    hip = _hip()
+    M, N = MN
+    if dt == 0 and N % 4 or dt == 1 and N % 8:
+        pytest.skip("N not a vector multiple")
+    torch.manual_seed(M + N + dt)
+    tdt = hip.TORCH_DT[dt]
+    z = (torch.randn(M, N) * 2 + torch.randn(N)).to(tdt)
+    res = torch.randn(M, N).to(tdt)
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N)
+    mm, mv = torch.randn(N), torch.rand(N) + 0.5
+    eps, mom = 1e-3, 0.99
+    zf = z.float().clone().requires_grad_(True)
+    gam = gamma.clone().requires_grad_(True); bet = beta.clone().requires_grad_(True)
+    mu, var = zf.mean(0), zf.var(0, unbiased=False)
+    y = torch.relu((zf - mu) * torch.rsqrt(var + eps) * gam + bet + res.float())
+    gy = torch.randn(M, N).to(tdt).float()
+    g_masked = gy * (y > 0)                                   # what the consuming layer's dgrad epilogue hands over
+    (y * gy).sum().backward()
+    Z, R = dev(z), dev(res)
+    ws = torch.empty(hip.bn_ws_bytes(M, N) // 8 + 8, dtype=torch.float64, device="cuda")
+    mean_d, var_d = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    MMd, MVd = dev(mm.clone()), dev(mv.clone())
+    hip.bn_batch_stats(M, N, dt, Z, ws, mean_d, var_d, MMd, MVd, mom, eps)
+    Y = torch.empty(M, N, dtype=tdt, device="cuda")
+    hip.bn_apply(M, N, dt, Z, mean_d, var_d, dev(gamma), dev(beta), eps, R, 1, Y)
+    dbeta, dgamma = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    gbeta, ggamma = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    DZ = torch.empty(M, N, dtype=tdt, device="cuda")
+    hip.bn_backward(M, N, dt, dev(g_masked.to(tdt)), Z, mean_d, var_d, dev(gamma), eps, ws, dbeta, dgamma, 1, gbeta, ggamma, DZ)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dt == 0 else 1.5e-2
+    assert relerr(mean_d, mu) < 1e-5 and relerr(var_d, var) < 1e-5
+    assert relerr(MMd, mm * mom + mu.detach() * (1 - mom)) < 1e-5
+    assert relerr(MVd, mv * mom + var.detach() * (M / (M - (1 + eps))) * (1 - mom)) < 1e-5
+    assert relerr(Y, y) < tol
+    assert relerr(gbeta, bet.grad) < max(tol, 1e-4) and relerr(ggamma, gam.grad) < max(tol, 1e-4)
+    assert relerr(DZ, zf.grad) < (1e-4 if dt == 0 else 3e-2)
+    assert torch.equal(gbeta, dbeta) and torch.equal(ggamma, dgamma)

@@ -217,3 +217,49 @@ def test_adam_training_steps_match_oracle():
             if sel.any():
                 worst = max(worst, float(np.abs(d_gpu - d_ref).max() / (np.abs(d_ref).max() + 1e-30)))
     assert worst < 2e-2, worst
+
+
+@pytest.mark.parametrize("name,kw", [("r50", dict(backbone="resnet50", h=64, w=128, batch=4, regress_ori=False, ori_bins=4)),
+                                     ("r18", dict(backbone="resnet18", h=128, w=128, batch=3, regress_ori=True))])
+def test_batch_statistics_bn_mode_parity_fp32(name, kw):
+    """TRAIN_BN = None ("Train BN layers", net.py:60-76): batch statistics in the training graph -- forward outputs,
+    losses, every gradient and the moving-statistics update against the oracle (its batchnorm(training=None))."""
+    from ursonet_amd.engine import Engine
+    cfg = make_config(dtype="float32", **kw)
+    cfg.TRAIN_BN = None
+    img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=2)
+    eng = Engine(cfg, "training", seed=7, randomize_bn=True)
+    assert eng.train_bn
+    w0 = eng.get_weights()
+    eng.load_batch(img, loc, ori)
+    eng.step()
+    torch.cuda.synchronize()
+    ref0, _ = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE)
+    gl, go = eng.outputs()
+    assert _rel(gl.cpu().numpy(), ref0["loc"].numpy()) < 1e-3
+    assert _rel(go.cpu().numpy(), ref0["ori"].numpy()) < 1e-3
+    dec = ReluDecisions(eng, tol=1e-4)      # normalised activations: rounding differences are relative to sigma
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec)
+    assert dec.flips <= max(4, 1e-5 * dec.total)
+    ls = eng.losses()
+    assert abs(ls["loc_loss"] - ref["loc_loss"]) < 1e-3 * abs(ref["loc_loss"]) + 1e-6
+    assert abs(ls["ori_loss"] - ref["ori_loss"]) < 1e-3 * abs(ref["ori_loss"]) + 1e-6
+    grads = eng.get_grads()
+    worst = ("", 0.0)
+    bn_convs = {c.name for c in eng.convs.values() if c.batch_bn}
+    for ln, ws in ref["grads"].items():
+        for wn, gref in ws.items():
+            if wn == "bias" and ln in bn_convs:
+                # a bias in front of a batch-statistics BN has the exact gradient sum(dz) = 0 (+ the tiny L2 term): both sides
+                # hold rounding noise only, so the comparison is absolute
+                assert np.abs(grads[ln][wn] - gref.numpy()).max() < 2e-5, ln
+                continue
+            e = _rel(grads[ln][wn], gref.numpy())
+            if e > worst[1]:
+                worst = (ln + "/" + wn, e)
+    assert worst[1] < 2e-3, "worst gradient mismatch %s: %.3e" % worst
+    # moving statistics moved towards the batch statistics (momentum 0.99) and are no longer the initial ones
+    w1 = eng.get_weights()
+    bn = "bn_conv1" if name == "r50" else "bn_conv0"
+    assert not np.allclose(w1[bn]["moving_mean"], w0[bn]["moving_mean"])
+    assert np.abs(w1[bn]["moving_mean"] - w0[bn]["moving_mean"]).max() < 0.011 * (np.abs(w0[bn]["moving_mean"]).max() + 10 * np.abs(img).max())

@@ -13,8 +13,11 @@ CASES = {
     "cfg1_r18_quat_f32": dict(backbone="resnet18", h=128, w=128, batch=2, regress_ori=True, dtype="float32"),
     "cfg2_r50_f32": dict(backbone="resnet50", h=512, w=640, batch=32, regress_ori=False, ori_bins=16, dtype="float32"),
 }
+CASES["cfg2_r50_bf16_train_bn"] = dict(CASES["cfg2_r50_bf16"])        # secondary mode: batch-statistics BN (TRAIN_BN=None)
 for name in (sys.argv[1:] or CASES):
     cfg = make_config(**CASES[name])
+    if name.endswith("train_bn"):
+        cfg.TRAIN_BN = None
     eng = Engine(cfg, "training", seed=1, randomize_bn=True)
     img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=1)
     eng.load_batch(img, loc, ori)

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liburso_hip.so")
-SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_pw.hip", "conv_wgrad.hip", "prep.hip", "pool_loss_optim.hip", "augment.hip"]
+SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_pw.hip", "conv_wgrad.hip", "prep.hip", "pool_loss_optim.hip", "augment.hip", "bn_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 

@@ -23,6 +23,8 @@ from . import hip
 from .config import compute_dtype_name
 from .graph import BN_EPS, build_graph, conv_flops
 
+BN_MOMENTUM = 0.99          # Keras BatchNormalization default (net.py:60-76 passes none)
+
 _DT = {"float32": hip.F32, "bfloat16": hip.BF16, "float16": hip.F16}
 
 
@@ -146,6 +148,10 @@ class Engine(object):
     def _build_plan(self):
         cfg, g, B, dt, dev = self.config, self.graph, self.B, self.dt, self.device
         training = self.mode == "training"
+        # TRAIN_BN = None ("Train BN layers", net.py:60-76): batch statistics while training -- the BN is not folded, the conv
+        # writes its raw output and separate stats / apply / backward kernels run (csrc/bn_train.hip).  Inference and
+        # TRAIN_BN = False use the moving statistics folded into the filters.
+        self.train_bn = training and cfg.TRAIN_BN is None
         VE = 16 // (4 if dt == hip.F32 else 2)
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
@@ -167,6 +173,7 @@ class Engine(object):
         max_ws = 0
         max_fin_ws = 0
         max_igemm_ws = 0
+        max_bn_ws = 0
         descs = []                                 # hip.ParamDesc of every non-stem weight layer
         for node in g.nodes:
             if node.op == "pool":
@@ -224,6 +231,18 @@ class Engine(object):
             c.beta = self._ptr_or_none(node.bn, "beta") if node.bn else None
             c.mean = self._ptr_or_none(node.bn, "moving_mean") if node.bn else None
             c.var = self._ptr_or_none(node.bn, "moving_variance") if node.bn else None
+            c.batch_bn = bool(self.train_bn and node.bn)
+            if c.batch_bn:
+                # unfolded conv: the BN tensors move to the bn_* fields, the conv itself is a plain conv + bias
+                assert c.npad == c.N and not node.out_f32
+                c.bn_gamma, c.bn_beta, c.bn_mmean, c.bn_mvar = c.gamma, c.beta, c.mean, c.var
+                c.gamma = c.beta = c.mean = c.var = None
+                c.Mpix = B * node.dst.h * node.dst.w
+                c.z = torch.empty(c.Mpix * c.N, dtype=self.tdt, device=dev)
+                c.dz = torch.empty(c.Mpix * c.N, dtype=self.tdt, device=dev)
+                c.bmean, c.bvar = torch.empty(c.N, dtype=torch.float32, device=dev), torch.empty(c.N, dtype=torch.float32, device=dev)
+                c.dbeta, c.dgamma = torch.empty(c.N, dtype=torch.float32, device=dev), torch.empty(c.N, dtype=torch.float32, device=dev)
+                max_bn_ws = max(max_bn_ws, hip.bn_ws_bytes(c.Mpix, c.N))
             self.convs[node.name] = c
             # -- weight prep (per step in training; once in inference): the stem has its own packing kernel, every other
             #    layer gets a descriptor and ONE batched launch covers them all (urso_param_batch_run)
@@ -249,14 +268,26 @@ class Engine(object):
             c.ws_d = hip.conv_igemm_ws_bytes(c.gd, dt) if (c.gd is not None and training) else 0
             max_igemm_ws = max(max_igemm_ws, c.ws_f, c.ws_d)
             c.fwd_flags = flags
-            self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
-                c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
-                c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits, self.igemm_ws if c.ws_f else None))
-            self.labels["fwd"].append("fwd:" + node.name)
+            if c.batch_bn:
+                self.fwd_ops.append(lambda c=c: hip.conv_igemm_ex(c.gf, dt, 0, c.src.data, c.wf, c.biasf, None, None, c.z, None,
+                                                                  self.igemm_ws if c.ws_f else None))
+                self.labels["fwd"].append("fwd:" + node.name)
+                self.fwd_ops.append(lambda c=c: hip.bn_batch_stats(c.Mpix, c.N, dt, c.z, self.bn_ws, c.bmean, c.bvar, c.bn_mmean, c.bn_mvar,
+                                                                   BN_MOMENTUM, BN_EPS))
+                self.labels["fwd"].append("bn_stats:" + node.name)
+                self.fwd_ops.append(lambda c=c, n=node: hip.bn_apply(c.Mpix, c.N, dt, c.z, c.bmean, c.bvar, c.bn_gamma, c.bn_beta, BN_EPS,
+                                                                     c.res.data if c.res is not None else None, n.relu, c.dst.data))
+                self.labels["fwd"].append("bn_apply:" + node.name)
+            else:
+                self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
+                    c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
+                    c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits, self.igemm_ws if c.ws_f else None))
+                self.labels["fwd"].append("fwd:" + node.name)
             if training and node.stem:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(147, c.N))
         self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
+        self.bn_ws = torch.empty(max_bn_ws // 8 + 32, dtype=torch.float64, device=dev) if max_bn_ws else None
         self._descs = descs
         if descs:
             self.prep_ops.append(lambda: self.pbatch.run(hip.PB_PREP, "all", dt))
@@ -288,7 +319,8 @@ class Engine(object):
         for node in reversed(g.nodes):
             if node.op == "pool" or node.stem:
                 continue
-            if self.layer_trainable[node.name] or (node.bn and self.layer_trainable[node.bn]):
+            folded_bn = node.bn and not self.convs[node.name].batch_bn      # batch-statistics BN finalises its own gamma/beta
+            if self.layer_trainable[node.name] or (folded_bn and self.layer_trainable[node.bn]):
                 groups.setdefault(bucket_of[node.name], []).append(node.name)
         last_of_group = {names[-1]: k for k, names in groups.items()}
         for node in reversed(g.nodes):
@@ -307,6 +339,15 @@ class Engine(object):
             G = c.dst.grad
             tr = self.layer_trainable[node.name]
             bn_tr = self.layer_trainable[node.bn] if node.bn else False
+            Gsum = G                                   # gradient w.r.t. (BN output + residual): what a residual branch receives
+            if c.batch_bn:
+                ggam, gbet = self.gview(node.bn, "gamma").reshape(-1), self.gview(node.bn, "beta").reshape(-1)
+                self.bwd_ops.append((node.name, lambda c=c, G=G, bn_tr=bn_tr, ggam=ggam, gbet=gbet:
+                                     hip.bn_backward(c.Mpix, c.N, dt, G, c.z, c.bmean, c.bvar, c.bn_gamma, BN_EPS, self.bn_ws, c.dbeta, c.dgamma,
+                                                     bn_tr, gbet, ggam, c.dz)))
+                self.labels["bwd"].append("bn_bwd:" + node.name)
+                G = c.dz                               # the conv itself sees the gradient w.r.t. its raw output
+                bn_tr = False                          # gamma/beta gradients are done; the finalisation treats the layer as a plain conv
             # -- weight gradient + finalisation (skipped for fully frozen layers; their grads stay zero)
             if (tr or bn_tr) and node.stem:
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
@@ -318,8 +359,8 @@ class Engine(object):
                 self.labels["bwd"].append("unpack:" + node.name)
                 gw = self.gview(node.name, "kernel").reshape(-1)
                 gb = self.gview(node.name, "bias").reshape(-1) if node.bias else None
-                gg = self.gview(node.bn, "gamma").reshape(-1) if node.bn else None
-                gbe = self.gview(node.bn, "beta").reshape(-1) if node.bn else None
+                gg = self.gview(node.bn, "gamma").reshape(-1) if (node.bn and not c.batch_bn) else None
+                gbe = self.gview(node.bn, "beta").reshape(-1) if (node.bn and not c.batch_bn) else None
                 self.bwd_ops.append((node.name, lambda c=c, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr:
                                      hip.param_grad_finalize(147, c.N, c.N, c.dw_unp, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
                                                              float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
@@ -336,8 +377,8 @@ class Engine(object):
                 d.trainable, d.bn_trainable = int(tr), int(bn_tr)
                 d.gw = hip.ptr(self.gview(node.name, "kernel").reshape(-1))
                 d.gb = hip.ptr(self.gview(node.name, "bias").reshape(-1)) if node.bias else None
-                d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if node.bn else None
-                d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if node.bn else None
+                d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if (node.bn and not c.batch_bn) else None
+                d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad_partial(c.gf, dt, c.src.data, G, c.wg_ws)))
                 self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
@@ -352,9 +393,9 @@ class Engine(object):
                 if R.grad_written or R.pending is not None:
                     raise AssertionError("unexpected second residual consumer for %s" % node.name)
                 if R.spec.relu:
-                    R.pending = G
+                    R.pending = Gsum
                 else:
-                    R.grad, R.grad_written = G, True
+                    R.grad, R.grad_written = Gsum, True
             # -- data gradient into the conv input
             if not node.stem:
                 X = c.src
@@ -596,15 +637,15 @@ class Engine(object):
 
     def save_train_state(self):
         """Weights + optimizer state (incl. Adam's device-side step counter), for the warm-up step before graph capture."""
-        st = [self.flat_w.clone(), self.flat_v.clone()]
+        st = [self.flat_w.clone(), self.flat_v.clone(), self.flat_stats.clone()]
         if getattr(self, "adam", False):
             st += [self.flat_v2.clone(), self.flat_vhat.clone(), self.hyper.clone()]
         return st
 
     def restore_train_state(self, st):
-        self.flat_w.copy_(st[0]); self.flat_v.copy_(st[1])
+        self.flat_w.copy_(st[0]); self.flat_v.copy_(st[1]); self.flat_stats.copy_(st[2])
         if getattr(self, "adam", False):
-            self.flat_v2.copy_(st[2]); self.flat_vhat.copy_(st[3]); self.hyper.copy_(st[4])
+            self.flat_v2.copy_(st[3]); self.flat_vhat.copy_(st[4]); self.hyper.copy_(st[5])
 
     def reset_optimizer(self):
         self.flat_v.zero_()

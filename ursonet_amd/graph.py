@@ -91,9 +91,9 @@ def build_graph(config):
                         "For example, use 256, 320, 384, 448, 512, ... etc. ")
     if config.NR_IMAGE_CHANNELS != 3:
         raise NotImplementedError("only NR_IMAGE_CHANNELS == 3 is supported (config.py:78)")
-    if config.TRAIN_BN is not False:
-        raise NotImplementedError("TRAIN_BN=%r: only the frozen-BN mode (TRAIN_BN=False, config.py:146, never changed "
-                                  "by the reference CLI) is implemented" % (config.TRAIN_BN,))
+    if config.TRAIN_BN not in (False, None):
+        raise NotImplementedError("TRAIN_BN=%r: the frozen mode (False, config.py:146) and the batch-statistics mode (None) are "
+                                  "implemented; True (\"don't use\", net.py:73) adds BN layers to the heads and is not" % (config.TRAIN_BN,))
     g = Graph()
     img = g.tensor(H, W, 3, False)
     deep = config.BACKBONE in ("resnet50", "resnet101")

@@ -79,6 +79,10 @@ _SIGS = {
     "urso_param_grad_finalize": (_i, [_i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i,
                                       _fp, _fp, _fp, _fp, _fp, _sz, _vp]),
     "urso_param_grad_finalize_ws_bytes": (_sz, [_i, _i]),
+    "urso_bn_ws_bytes": (_sz, [_i, _i]),
+    "urso_bn_batch_stats": (_i, [_i, _i, _i, _vp, _vp, _sz, _fp, _fp, _fp, _fp, _f, _f, _vp]),
+    "urso_bn_apply": (_i, [_i, _i, _i, _vp, _fp, _fp, _fp, _fp, _f, _vp, _i, _vp, _vp]),
+    "urso_bn_backward": (_i, [_i, _i, _i, _vp, _vp, _fp, _fp, _fp, _f, _vp, _sz, _fp, _fp, _i, _fp, _fp, _vp, _vp]),
     "urso_mold_images": (_i, [_i, _i, _i, _i, _vp, _fp, _i, _vp, _vp]),
     "urso_maxpool3x3s2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "urso_maxpool3x3s2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -202,6 +206,25 @@ class ParamBatch(object):
         t, nb = self.maps[(phase, key)]
         if nb:
             _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
+
+
+def bn_ws_bytes(M, N):
+    return int(_lib.urso_bn_ws_bytes(M, N))
+
+
+def bn_batch_stats(M, N, dt, z, ws, mean, var, mmean, mvar, momentum, eps, stream=None):
+    _chk(_lib.urso_bn_batch_stats(M, N, dt, ptr(z), ptr(ws), ws.numel() * ws.element_size(), ptr(mean), ptr(var), ptr(mmean), ptr(mvar),
+                                  momentum, eps, stream_ptr(stream)), "urso_bn_batch_stats")
+
+
+def bn_apply(M, N, dt, z, mean, var, gamma, beta, eps, res, relu, y, stream=None):
+    _chk(_lib.urso_bn_apply(M, N, dt, ptr(z), ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, ptr(res), int(relu), ptr(y), stream_ptr(stream)),
+         "urso_bn_apply")
+
+
+def bn_backward(M, N, dt, g, z, mean, var, gamma, eps, ws, dbeta, dgamma, bn_trainable, gbeta, ggamma, dz, stream=None):
+    _chk(_lib.urso_bn_backward(M, N, dt, ptr(g), ptr(z), ptr(mean), ptr(var), ptr(gamma), eps, ptr(ws), ws.numel() * ws.element_size(),
+                               ptr(dbeta), ptr(dgamma), int(bn_trainable), ptr(gbeta), ptr(ggamma), ptr(dz), stream_ptr(stream)), "urso_bn_backward")
 
 
 def conv_weight_prep(KH, KW, Cin, N, npad, dt, w, b, gamma, beta, mean, var, eps, wf, wd, biasf, scale, stream=None):
