@@ -104,6 +104,7 @@ def main():
     from util import synthetic_batch
 
     cfg = bench_config(args.dtype, args.batch, args.height, args.width, args.backbone, args.ori_bins)
+    cfg.DP_EXACT_REL_LOSS = os.environ.get("URSO_DP_EXACT_REL_LOSS", "0") == "1"      # default: per-rank loss
     eng = Engine(cfg, "training", seed=1234, randomize_bn=True)
     img, loc, ori, _ = synthetic_batch(cfg, args.batch, seed=1234 + rank)
     eng.load_batch(img, loc, ori)                  # inputs resident in HBM before the timed region

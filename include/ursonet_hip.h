@@ -245,6 +245,13 @@ int urso_softmax_xent_fwd_bwd(int B, int K, const float* logits_d /* [B][K] */, 
 int urso_rel_l2_fwd_bwd(int B, int D, int ld /* row stride of pred and dpred (padded heads) */,
                         const float* gt_d /* [B][D] */, const float* pred_d, float weight,
                         int dt, float* loss_d, void* dpred_d, float* norms_d, void* stream);
+/* Two-phase form for data parallelism with the EXACT global loss (the ratio is over the whole global batch, so it is not
+ * a mean of per-rank losses): phase 1 writes norms_d = {sum (gt-pred)^2, sum gt^2} of this rank's samples, the caller
+ * sum-all-reduces the two floats, phase 2 computes loss = weight*sqrt(n0)/sqrt(n1) and
+ * dpred = -weight*gscale/(sqrt(n0) sqrt(n1)) (gt - pred) with gscale_d[0] = world size (undoes the gradient averaging). */
+int urso_rel_l2_norms(int B, int D, int ld, const float* gt_d, const float* pred_d, float* norms_d, void* stream);
+int urso_rel_l2_from_norms(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight, const float* gscale_d,
+                           int dt, const float* norms_d, float* loss_d, void* dpred_d, void* stream);
 /* K.l2_normalize (net.py:346) + one_minus_dot_prod_graph (net.py:724-733).
  * q = x * rsqrt(max(sum x^2, 1e-12)) when normalize=1 (else q = x); loss = mean_b(1 - |gt.q|).
  * gt_d may be NULL (inference: only q is produced). */

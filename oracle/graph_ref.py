@@ -335,11 +335,27 @@ def rel_loss(y_gt, y_pred):
     return torch.linalg.vector_norm((y_gt - y_pred) / torch.linalg.vector_norm(y_gt))
 
 
-def losses(P, images, gt_loc, gt_ori, config, relu_hook=None):
-    """net.py:656-669.  Returns (loc_pred, ori_pred, loc_loss, ori_loss)."""
+def rel_loss_sharded(y_gt, y_pred, global_norms, world):
+    """The data-parallel form of rel_loss for ONE shard of the global batch (exact mode): a surrogate whose
+    value is world * (this shard's share of the global loss) and whose gradient w.r.t. y_pred is
+    -world (gt - pred) / (||gt-pred||_global ||gt||_global); averaging the shards' gradients gives the global-batch gradient."""
+    nd, ng = float(global_norms[0]) ** 0.5, float(global_norms[1]) ** 0.5
+    return world * ((y_gt - y_pred) ** 2).sum() / (2.0 * nd * ng)
+
+
+def rel_norms(y_gt, y_pred):
+    return torch.stack([((y_gt - y_pred) ** 2).sum(), (y_gt ** 2).sum()]).detach()
+
+
+def losses(P, images, gt_loc, gt_ori, config, relu_hook=None, rel_global=None):
+    """net.py:656-669.  Returns (loc_pred, ori_pred, loc_loss, ori_loss).  rel_global = (global_norms, world) switches the
+    location loss to its exact data-parallel shard form (rel_loss_sharded)."""
     loc, ori = forward(P, images, config, relu_hook)
     assert not config.REGRESS_KEYPOINTS, "keypoint mode: use losses_keypoints"
-    loc_loss = rel_loss(gt_loc, loc) if config.REGRESS_LOC else softmax_loss(gt_loc, loc)
+    if config.REGRESS_LOC and rel_global is not None:
+        loc_loss = rel_loss_sharded(gt_loc, loc, rel_global[0], rel_global[1])
+    else:
+        loc_loss = rel_loss(gt_loc, loc) if config.REGRESS_LOC else softmax_loss(gt_loc, loc)
     ori_loss = one_minus_dot_prod(gt_ori, ori) if config.REGRESS_ORI else softmax_loss(gt_ori, ori)
     return loc, ori, loc_loss, ori_loss
 
@@ -362,18 +378,18 @@ def regularizer(P, config, layer_regex=".*"):
     return reg
 
 
-def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None):
+def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None):
     """net.py:993-1012: sum_name LOSS_WEIGHTS[name]*mean(loss) + regulariser."""
-    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config, relu_hook)
+    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config, relu_hook, rel_global)
     tot = config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("ori_loss", 1.) * ol
     return tot + regularizer(P, config, layer_regex), (loc, ori, ll, ol)
 
 
-def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None):
+def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None):
     """Returns (grads {layer:{weight: tensor}}, (loc, ori, loc_loss, ori_loss), total)."""
     leaves = [(ln, wn, w) for ln, ws in P.items() for wn, w in ws.items()
               if w.requires_grad and is_trainable(ln, layer_regex)]
-    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook)
+    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook, rel_global)
     gs = torch.autograd.grad(tot, [w for _, _, w in leaves], allow_unused=True)
     grads = OrderedDict()
     for (ln, wn, w), g in zip(leaves, gs):

@@ -37,7 +37,7 @@ def _flat(grads, order):
     return torch.cat([grads[ln][wn].reshape(-1) for ln, wn in order])
 
 
-def _worker(rank, world, port, regress_loc, out):
+def _worker(rank, world, port, regress_loc, out, exact=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -49,7 +49,15 @@ def _worker(rank, world, port, regress_loc, out):
     img, loc, ori, _ = synthetic_batch(cfg, 4, seed=11)              # the global batch; rank r takes samples [2r, 2r+2)
     sl = slice(2 * rank, 2 * rank + 2)
     P = G.to_torch(W)
-    grads, _, _ = G.gradients(P, torch.tensor(img[sl]), torch.tensor(loc[sl]), torch.tensor(ori[sl]), cfg)
+    rel_global = None
+    if exact:
+        # DP_EXACT_REL_LOSS: this rank's two squared norms, summed over the ranks by the product's helper
+        from ursonet_amd.dp import allreduce_rel_norms
+        with torch.no_grad():
+            pred_loc, _, _, _ = G.losses(P, torch.tensor(img[sl]), torch.tensor(loc[sl]), torch.tensor(ori[sl]), cfg)
+        norms = allreduce_rel_norms(G.rel_norms(torch.tensor(loc[sl]), pred_loc))
+        rel_global = (norms, world)
+    grads, _, _ = G.gradients(P, torch.tensor(img[sl]), torch.tensor(loc[sl]), torch.tensor(ori[sl]), cfg, rel_global=rel_global)
     order = [(ln, wn) for ln in grads for wn in grads[ln]]
     flat = _flat(grads, order).clone()
     sizes, off = [], 0
@@ -71,11 +79,11 @@ def _worker(rank, world, port, regress_loc, out):
     dist.destroy_process_group()
 
 
-def _run(regress_loc):
+def _run(regress_loc, exact=False):
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, regress_loc, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, regress_loc, out, exact), nprocs=2, join=True)
     return dict(out)
 
 
@@ -90,3 +98,10 @@ def test_dp_rel_loss_is_per_rank_not_global():
     big-batch gradient; the build documents and keeps per-rank semantics."""
     out = _run(regress_loc=True)
     assert out["err"] > 1e-3, out
+
+
+def test_dp_exact_rel_loss_equals_big_batch():
+    """DP_EXACT_REL_LOSS: with the two norms summed over the ranks (ursonet_amd.dp.allreduce_rel_norms) and the gradient
+    pre-scaled by the world size, the AVERAGED shard gradients equal the gradient of the one global-batch loss."""
+    out = _run(regress_loc=True, exact=True)
+    assert out["err"] < 2e-5, out

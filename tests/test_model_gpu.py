@@ -263,3 +263,23 @@ def test_batch_statistics_bn_mode_parity_fp32(name, kw):
     bn = "bn_conv1" if name == "r50" else "bn_conv0"
     assert not np.allclose(w1[bn]["moving_mean"], w0[bn]["moving_mean"])
     assert np.abs(w1[bn]["moving_mean"] - w0[bn]["moving_mean"]).max() < 0.011 * (np.abs(w0[bn]["moving_mean"]).max() + 10 * np.abs(img).max())
+
+
+def test_exact_rel_loss_mode_single_gpu_equals_default():
+    """DP_EXACT_REL_LOSS splits rel_loss into norms -> (all-reduce) -> loss+gradient; on one GPU (world size 1) the
+    two-phase kernels must reproduce the one-kernel loss and every gradient."""
+    from ursonet_amd.engine import Engine
+    res = []
+    for exact in (False, True):
+        cfg = make_config(dtype="float32", backbone="resnet18", h=64, w=64, batch=3, regress_ori=True)
+        cfg.DP_EXACT_REL_LOSS = exact
+        img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=6)
+        eng = Engine(cfg, "training", seed=9, randomize_bn=True)
+        assert bool(getattr(eng, "rel_exact", False)) == exact and (len(eng.loss_pre_ops) == 1) == exact
+        eng.load_batch(img, loc, ori)
+        eng.step()
+        torch.cuda.synchronize()
+        res.append((eng.losses(), eng.flat_g.clone(), eng.flat_w.clone()))
+    assert abs(res[0][0]["loc_loss"] - res[1][0]["loc_loss"]) < 1e-6 * abs(res[0][0]["loc_loss"])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-6 * float(res[0][1].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-6 * float(res[0][2].abs().max())

@@ -7,8 +7,8 @@ Additions (all optional, never required by a reference caller):
                  storage type of activations / MFMA inputs on the MI355X; accumulation,
                  master weights, gradients of parameters and the optimizer are fp32.
   DP_EXACT_REL_LOSS  False: per-rank `rel_loss_graph` (what a tower-parallel Keras model
-                 would compute); True (exact global loss via an all-reduce of the two norms)
-                 is not built yet and raises in ursonet_amd.dp.
+                 would compute); True: the two squared norms are summed over the ranks between
+                 forward and backward, i.e. the loss and its gradient are those of the one global batch.
 """
 import json
 import os

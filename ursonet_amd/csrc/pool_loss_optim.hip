@@ -212,6 +212,47 @@ extern "C" int urso_rel_l2_fwd_bwd(int B, int D, int ld, const float* gt_d, cons
     return urso_check_launch("urso_rel_l2_fwd_bwd");
 }
 
+// Two-phase form for the exact data-parallel loss: the two squared norms are summed over ALL ranks between the phases
+// (ursonet_amd/dp.py all-reduces norms[0..1]); gscale_d[0] = world size undoes the gradient averaging that follows, so
+// that the averaged gradient is the gradient of the ONE global batch-Frobenius ratio.
+__global__ void rel_l2_norms_kernel(int B, int D, int ld, const float* __restrict__ gt, const float* __restrict__ pred, float* __restrict__ norms) {
+    __shared__ float sh[8];
+    float sd = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < B * D; i += blockDim.x) {
+        const int b = i / D, d = i - b * D;
+        const float g = gt[i], e = g - pred[(size_t)b * ld + d];
+        sd += e * e; sg += g * g;
+    }
+    sd = block_sum(sd, sh); sg = block_sum(sg, sh);
+    if (threadIdx.x == 0) { norms[0] = sd; norms[1] = sg; }
+}
+__global__ void rel_l2_from_norms_kernel(int B, int D, int ld, const float* __restrict__ gt, const float* __restrict__ pred, float weight,
+                                         const float* __restrict__ gscale, int dt, const float* __restrict__ norms,
+                                         float* __restrict__ loss, void* __restrict__ dpred) {
+    const float nd = sqrtf(norms[0]), ng = sqrtf(norms[1]);
+    if (threadIdx.x == 0) loss[0] = weight * nd / ng;
+    const float c = -weight * gscale[0] / (nd * ng);
+    for (int i = threadIdx.x; i < B * ld; i += blockDim.x) {
+        const int b = i / ld, d = i - b * ld;
+        put_any(dt, dpred, i, d < D ? c * (gt[b * D + d] - pred[i]) : 0.f);
+    }
+}
+extern "C" int urso_rel_l2_norms(int B, int D, int ld, const float* gt_d, const float* pred_d, float* norms_d, void* stream) {
+    if (!gt_d || !pred_d || !norms_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_norms: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, 0);
+    hipLaunchKernelGGL(rel_l2_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, norms_d);
+    return urso_check_launch("urso_rel_l2_norms");
+}
+extern "C" int urso_rel_l2_from_norms(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight, const float* gscale_d,
+                                      int dt, const float* norms_d, float* loss_d, void* dpred_d, void* stream) {
+    if (!gt_d || !pred_d || !gscale_d || !norms_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_from_norms: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_LOSS, 0, 0);
+    hipLaunchKernelGGL(rel_l2_from_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, gscale_d, dt, norms_d, loss_d, dpred_d);
+    return urso_check_launch("urso_rel_l2_from_norms");
+}
+
 // =============================================================== l2-normalise + 1-|dot|
 __global__ void absdot_kernel(int B, int D, int ld, int normalize, const float* __restrict__ gt, const float* __restrict__ x,
                               float weight, int dt, float* __restrict__ q, float* __restrict__ loss, void* __restrict__ dx) {

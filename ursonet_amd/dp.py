@@ -33,6 +33,18 @@ def plan_buckets(layer_sizes, bucket_bytes=32 << 20):
     return buckets
 
 
+def allreduce_rel_norms(norms, group=None):
+    """Sum {sum (gt-pred)^2, sum gt^2} of rel_loss_graph over the ranks (DP_EXACT_REL_LOSS); synchronous w.r.t. the caller's stream."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1 or _force_collectives():
+        dist.all_reduce(norms, op=dist.ReduceOp.SUM, group=group)
+    return norms
+
+
+def _force_collectives():
+    import os
+    return dist.is_initialized() and os.environ.get("URSO_DP_FORCE_COLLECTIVES", "0") == "1"
+
+
 class GradReducer(object):
     """Averages slices of a flat gradient tensor across the process group, asynchronously."""
 
@@ -70,10 +82,12 @@ class DataParallelEngine(object):
 
     def __init__(self, engine, bucket_bytes=32 << 20, group=None):
         self.eng, self.group = engine, group
-        if getattr(engine.config, "DP_EXACT_REL_LOSS", False):
-            raise NotImplementedError("DP_EXACT_REL_LOSS (all-reduce of the two batch norms of rel_loss_graph before its gradient) is not "
-                                      "built yet: data-parallel steps use the per-rank loss, as a tower-parallel Keras model would")
         self.world = dist.get_world_size(group)
+        # DP_EXACT_REL_LOSS: the location loss is ONE ratio of norms over the global batch (net.py:750-762); its two squared norms are
+        # summed over the ranks between forward and backward and the gradient is pre-scaled by the world size (undone by the averaging)
+        self.rel_exact = bool(getattr(engine, "rel_exact", False)) and bool(engine.loss_pre_ops)
+        if self.rel_exact:
+            engine.rel_scale.fill_(float(self.world))
         eng = engine
         dist.broadcast(eng.flat_w, src=0, group=group)
         dist.broadcast(eng.flat_stats, src=0, group=group)
@@ -107,7 +121,7 @@ class DataParallelEngine(object):
         for k, c in enumerate(self.cuts):
             ops = [op for _, op in eng.bwd_ops[prev:c]]
             if k == 0:
-                ops = eng.prep_ops + eng.fwd_ops + eng.loss_ops + ops
+                ops = ([] if self.rel_exact else eng.prep_ops + eng.fwd_ops + eng.loss_pre_ops) + eng.loss_ops + ops
             segs.append(ops)
             prev = c
         tail = [op for _, op in eng.bwd_ops[prev:]]
@@ -127,6 +141,13 @@ class DataParallelEngine(object):
         torch.cuda.synchronize(eng.device)
         graphs = []
         pool = None
+        self._pre_graph = None
+        if self.rel_exact:                   # [prep + forward + norms]  -> all-reduce of 2 floats ->  [loss + backward ...]
+            self._pre_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._pre_graph):
+                for op in eng.prep_ops + eng.fwd_ops + eng.loss_pre_ops:
+                    op()
+            pool = self._pre_graph.pool()
         for ops in segs + [last]:
             if not ops:                      # e.g. a bucket made only of frozen layers
                 graphs.append(None)
@@ -142,6 +163,9 @@ class DataParallelEngine(object):
     def step(self):
         if self._graphs is None:
             self.capture()
+        if self._pre_graph is not None:
+            self._pre_graph.replay()
+            allreduce_rel_norms(self.eng.rel_norms, self.group)       # the compute stream waits for it before the next replay
         for k in range(len(self.buckets)):
             if self._graphs[k] is not None:
                 self._graphs[k].replay()

@@ -155,6 +155,7 @@ class Engine(object):
         VE = 16 // (4 if dt == hip.F32 else 2)
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
+        self.loss_pre_ops = []     # DP_EXACT_REL_LOSS: the part of the loss that precedes the cross-rank sum of the two norms
         self.labels = {"prep": [], "fwd": [], "loss": [], "bwd": [], "opt": []}
         self.convs = OrderedDict()
 
@@ -513,7 +514,17 @@ class Engine(object):
         wl = float(lw.get("loc_loss", 1.))
         if cfg.REGRESS_LOC:
             self.gt_loc = torch.zeros(B, 3, dtype=torch.float32, device=dev)
-            self.loss_ops.append(lambda: hip.rel_l2(B, 3, 8, self.gt_loc, loc.data, wl, dt, self.loss_buf[0:1], gz_loc, self.rel_norms))
+            self.rel_exact = bool(getattr(cfg, "DP_EXACT_REL_LOSS", False))
+            if self.rel_exact:
+                # exact global batch-Frobenius ratio under data parallelism: norms -> (dp.py sum-all-reduces them) -> loss + gradient;
+                # rel_scale = world size (1 on a single GPU, where the two phases reproduce the one-kernel loss)
+                if not hasattr(self, "rel_scale"):
+                    self.rel_scale = torch.ones(1, dtype=torch.float32, device=dev)
+                self.loss_pre_ops.append(lambda: hip.rel_l2_norms(B, 3, 8, self.gt_loc, loc.data, self.rel_norms))
+                self.loss_ops.append(lambda: hip.rel_l2_from_norms(B, 3, 8, self.gt_loc, loc.data, wl, self.rel_scale, dt, self.rel_norms,
+                                                                   self.loss_buf[0:1], gz_loc))
+            else:
+                self.loss_ops.append(lambda: hip.rel_l2(B, 3, 8, self.gt_loc, loc.data, wl, dt, self.loss_buf[0:1], gz_loc, self.rel_norms))
         else:
             self.gt_loc = torch.zeros(B, nloc, dtype=torch.float32, device=dev)
             self.loss_ops.append(lambda: hip.softmax_xent(B, nloc, loc.data, self.gt_loc, wl, 1, dt, self.loss_buf[0:1], gz_loc, self.row_ws))
@@ -541,7 +552,7 @@ class Engine(object):
             op()
 
     def run_backward(self):
-        for op in self.loss_ops:
+        for op in self.loss_pre_ops + self.loss_ops:
             op()
         for _, op in self.bwd_ops:
             op()
@@ -557,7 +568,7 @@ class Engine(object):
     def profile_step(self):
         """One eager training step with the library's HIP-event launch profiler on.
         Returns [(label, kernel_id, ms, flops, bytes)] in launch order."""
-        labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * len(self.loss_ops) +
+        labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * (len(self.loss_pre_ops) + len(self.loss_ops)) +
                   [l for l in self.labels["bwd"] if l is not None] + self.labels["opt"])
         torch.cuda.synchronize(self.device)
         hip.prof_collect()

@@ -88,6 +88,8 @@ _SIGS = {
     "urso_maxpool3x3s2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "urso_softmax_xent_fwd_bwd": (_i, [_i, _i, _fp, _fp, _f, _i, _i, _fp, _vp, _fp, _vp]),
     "urso_rel_l2_fwd_bwd": (_i, [_i, _i, _i, _fp, _fp, _f, _i, _fp, _vp, _fp, _vp]),
+    "urso_rel_l2_norms": (_i, [_i, _i, _i, _fp, _fp, _fp, _vp]),
+    "urso_rel_l2_from_norms": (_i, [_i, _i, _i, _fp, _fp, _f, _fp, _i, _fp, _fp, _vp, _vp]),
     "urso_absdot_fwd_bwd": (_i, [_i, _i, _i, _i, _fp, _fp, _f, _i, _fp, _fp, _vp, _vp]),
     "urso_mse_fwd_bwd": (_i, [_i, _i, _i, _fp, _fp, _f, _i, _fp, _vp, _vp]),
     "urso_sqnorm_ws_bytes": (_sz, [_sz]),
@@ -272,6 +274,15 @@ def maxpool_bwd(B, H, W, Cc, dt, y, dy, argmax, relu_mask, dx, stream=None):
 def softmax_xent(B, K, logits, labels, weight, relu_mask, dt, loss, dz, row_ws, stream=None):
     _chk(_lib.urso_softmax_xent_fwd_bwd(B, K, ptr(logits), ptr(labels), weight, int(relu_mask), dt, ptr(loss), ptr(dz),
                                         ptr(row_ws), stream_ptr(stream)), "urso_softmax_xent_fwd_bwd")
+
+
+def rel_l2_norms(B, D, ld, gt, pred, norms, stream=None):
+    _chk(_lib.urso_rel_l2_norms(B, D, ld, ptr(gt), ptr(pred), ptr(norms), stream_ptr(stream)), "urso_rel_l2_norms")
+
+
+def rel_l2_from_norms(B, D, ld, gt, pred, weight, gscale, dt, norms, loss, dpred, stream=None):
+    _chk(_lib.urso_rel_l2_from_norms(B, D, ld, ptr(gt), ptr(pred), weight, ptr(gscale), dt, ptr(norms), ptr(loss), ptr(dpred),
+                                     stream_ptr(stream)), "urso_rel_l2_from_norms")
 
 
 def rel_l2(B, D, ld, gt, pred, weight, dt, loss, dpred, norms=None, stream=None):
