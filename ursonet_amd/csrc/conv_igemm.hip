@@ -541,7 +541,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool fits = dt != URSO_F32 && !(flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
-        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && (a.Cc & 7) == 0)))
+        const bool taps_ok = (a.Cc & 7) == 0 && g->DH == 1 && g->DW == 1 && g->KH <= 3 && g->KW <= 3;     // whole-tap K-tiles, undilated, <= 3x3
+        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && taps_ok)))
             return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
     }

@@ -85,12 +85,10 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
         q += hi ? 1 : (lo ? -1 : 0);
         r += hi ? -d : (lo ? d : 0);
     };
-    // CONV: per-row source coordinates of the tile being fetched and the running filter tap of its next K-tile.
-    // Undilated filters of at most 3x3 taps (every such layer of the network) keep, per row, a bit mask of the taps that
-    // fall inside the image and the byte offset of tap (0,0): a new tap then costs a bit test, an add and a select per row.
-    const bool tapmask = CONV && a.DHs == 0 && a.DWs == 0 && a.KH <= 3 && a.KW <= 3;
-    int ty0[CONV ? RA : 1], tx0[CONV ? RA : 1], pb[CONV ? RA : 1];
-    uint32_t rowbase[CONV ? RA : 1];
+    // CONV (undilated filters of at most 3x3 taps -- every such layer of the network; anything else runs in conv_igemm.hip):
+    // per row of the tile being fetched, a bit mask of the taps that fall inside the image and the byte offset of tap (0,0);
+    // a new tap then costs a bit test, an add and a select per row.  ft_* = running filter tap of the next K-tile.
+    uint32_t vmask[CONV ? RA : 1], base0[CONV ? RA : 1], rowbase[CONV ? RA : 1];
     int ft_cc = 0, ft_ky = 0, ft_kx = 0;
     auto setup_src = [&](int ts) {
         if constexpr (CONV) {
@@ -98,23 +96,20 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const int m = m0 + r0 + 32 * i;
-                int b = 0, rem = 0, oy = 0, ox = 0;
+                int b, rem, oy, ox;
                 divmod(min(m, a.M - 1), ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
                 const int y0 = oy * a.SH - a.PH, x0 = ox * a.SW - a.PW;
-                if (tapmask) {
-                    uint32_t my = 0, mx = 0;
+                uint32_t my = 0, mx = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        my |= (k < a.KH && (unsigned)(y0 + k) < (unsigned)a.H) ? (1u << k) : 0u;
-                        mx |= (k < a.KW && (unsigned)(x0 + k) < (unsigned)a.W) ? (1u << k) : 0u;
-                    }
-                    uint32_t vm = 0;
+                for (int k = 0; k < 3; ++k) {
+                    my |= (k < a.KH && (unsigned)(y0 + k) < (unsigned)a.H) ? (1u << k) : 0u;
+                    mx |= (k < a.KW && (unsigned)(x0 + k) < (unsigned)a.W) ? (1u << k) : 0u;
+                }
+                uint32_t vm = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) vm |= ((my >> k) & 1u) ? (mx << (k * a.KW)) : 0u;
-                    ty0[i] = (int)((m < a.M) ? vm : 0u);                                   // reused as the tap mask
-                    tx0[i] = (int)((uint32_t)((b * a.H * a.W + y0 * a.W + x0) * a.C) * 2u);  // reused as the offset of tap (0,0)
-                } else if (m >= a.M) { ty0[i] = -(1 << 24); tx0[i] = 0; pb[i] = 0; }
-                else { ty0[i] = y0; tx0[i] = x0; pb[i] = b * a.H * a.W; }
+                for (int k = 0; k < 3; ++k) vm |= ((my >> k) & 1u) ? (mx << (k * a.KW)) : 0u;
+                vmask[i] = (m < a.M) ? vm : 0u;
+                base0[i] = (uint32_t)((b * a.H * a.W + y0 * a.W + x0) * a.C) * 2u;
             }
             ft_cc = 0; ft_ky = 0; ft_kx = 0;
         }
@@ -123,20 +118,11 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
         const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
         const uint32_t la = lds0 + buf * BUF + wave * 1024, lb_ = la + BM * 128;
         if constexpr (CONV) {
-            if (ft_cc == 0 && tapmask) {
+            if (ft_cc == 0) {
                 const int tapi = ft_ky * a.KW + ft_kx;
                 const uint32_t tapoff = (uint32_t)((ft_ky * a.W + ft_kx) * a.C) * 2u;
 #pragma unroll
-                for (int i = 0; i < RA; ++i) rowbase[i] = (((uint32_t)ty0[i] >> tapi) & 1u) ? (uint32_t)tx0[i] + tapoff : URSO_OOB_SHIFT;
-            } else if (ft_cc == 0) {               // a new filter tap: one coordinate check per row, reused for Cc/8 K-tiles
-                const int dmh = (1 << a.DHs) - 1, dmw = (1 << a.DWs) - 1;
-#pragma unroll
-                for (int i = 0; i < RA; ++i) {
-                    const int ty = ty0[i] + ft_ky, tx = tx0[i] + ft_kx;
-                    const int iy = ty >> a.DHs, ix = tx >> a.DWs;
-                    const bool ok = ty >= 0 && tx >= 0 && ((ty & dmh) == 0) && ((tx & dmw) == 0) && iy < a.H && ix < a.W;
-                    rowbase[i] = ok ? (uint32_t)((pb[i] + iy * a.W + ix) * a.C) * 2u : URSO_OOB_SHIFT;
-                }
+                for (int i = 0; i < RA; ++i) rowbase[i] = ((vmask[i] >> tapi) & 1u) ? base0[i] + tapoff : URSO_OOB_SHIFT;
             }
 #pragma unroll
             for (int i = 0; i < RA; ++i)
