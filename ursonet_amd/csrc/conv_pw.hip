@@ -201,17 +201,41 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
             const bool last = (kt + 1 == a.nkt);
             if (!last) dma(tile, kt + 1, cur ^ 1);
             else if (has_next) { setup_src(next); dma(next, 0, cur ^ 1); }
+            if constexpr (BN == 64) {
+                // narrow tile (3 blocks / CU, VGPRs to spare): all twelve fragment reads of the K-tile are issued ahead of its
+                // MFMAs, pinned with a scheduling barrier -- one exposed LDS latency per K-tile instead of several.  (For
+                // the 128-wide tile the same pinning costs more than it gains: measured, so it keeps the compiler's order.)
+                i32x4_t fa0[TN], fb0[TM], fa1[TN], fb1[TM];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                i32x4_t fa[TN], fb[TM];
+                for (int j = 0; j < TN; ++j) fa0[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, fg));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, ks * 4 + fg));
+                for (int i = 0; i < TM; ++i) fb0[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, fg));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, ks * 4 + fg));
+                for (int j = 0; j < TN; ++j) fa1[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fb1[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, 4 + fg));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[j], fb[i], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa0[j], fb0[i], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa1[j], fb1[i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    i32x4_t fa[TN], fb[TM];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[j], fb[i], acc[i][j]);
+                }
             }
             if (!last) { pw_wait_vm<0>(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); cur ^= 1; }
         }
