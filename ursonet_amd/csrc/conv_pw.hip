@@ -223,6 +223,33 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) Mma<T>::run(fa1[j], fb1[i], acc[i][j]);
+            } else if constexpr (!(HAS_ADD && HAS_MASK)) {
+                // wide tile with registers to spare: second-half fragments are read while the first half multiplies, in a
+                // fixed interleave (2 MFMA : 1 ds_read) requested from the scheduler
+                i32x4_t fa0[TN], fb0[TM], fa1[TN], fb1[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fa0[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fb0[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, fg));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fa1[j] = *(const i32x4_t*)(sB(cur) + lds_off(wn * WN + j * 16 + fr, 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fb1[i] = *(const i32x4_t*)(sA(cur) + lds_off(wm * WM + i * 16 + fr, 4 + fg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa0[j], fb0[i], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa1[j], fb1[i], acc[i][j]);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // first-half fragments
+#pragma unroll
+                for (int q = 0; q < TM + TN; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);            // 2 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 ds_read of the second half
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN - 2 * (TM + TN), 0);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
