@@ -537,11 +537,16 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
         static int use_pw = -1;
-        if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 2; }     // 0 off, 1 pointwise only, 2 all
+        if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 3; }     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool fits = dt != URSO_F32 && !(flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
         const bool taps_ok = (a.Cc & 7) == 0 && g->DH == 1 && g->DW == 1 && g->KH <= 3 && g->KW <= 3;     // whole-tap K-tiles, undilated, <= 3x3
+        // the 7x7/s2 stem as packed by urso_stem_weight_pack: 7 x 4 taps of 8-channel pixel pairs, one tap per 16-byte chunk
+        const bool stem_ok = a.Cc == 1 && g->KW == 4 && g->KH <= 8 && g->DH == 1 && g->DW == 1 && g->N <= 64 && !add_d && !mask_d;
+        if (fits && use_pw >= 3 && stem_ok)
+            return urso_pw_launch(g, dt, 2, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
+                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
         if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && taps_ok)))
             return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);

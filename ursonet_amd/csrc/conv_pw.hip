@@ -36,7 +36,7 @@ __device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
 }
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <typename T, int BN, bool HAS_ADD, bool HAS_MASK, bool CONV>
+template <typename T, int BN, bool HAS_ADD, bool HAS_MASK, int CONV>   // CONV: 0 pointwise, 1 whole-tap conv (<= 3x3), 2 stem (one tap per 16-byte chunk)
 __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = 128, VE = 8;
@@ -99,15 +99,15 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
                 int b, rem, oy, ox;
                 divmod(min(m, a.M - 1), ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
                 const int y0 = oy * a.SH - a.PH, x0 = ox * a.SW - a.PW;
+                constexpr int MKH = (CONV == 2) ? 8 : 3, MKW = (CONV == 2) ? 4 : 3;     // stem: 7 x 4 taps of pixel PAIRS (28 mask bits)
                 uint32_t my = 0, mx = 0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    my |= (k < a.KH && (unsigned)(y0 + k) < (unsigned)a.H) ? (1u << k) : 0u;
-                    mx |= (k < a.KW && (unsigned)(x0 + k) < (unsigned)a.W) ? (1u << k) : 0u;
-                }
+                for (int k = 0; k < MKH; ++k) my |= (k < a.KH && (unsigned)(y0 + k) < (unsigned)a.H) ? (1u << k) : 0u;
+#pragma unroll
+                for (int k = 0; k < MKW; ++k) mx |= (k < a.KW && (unsigned)(x0 + k) < (unsigned)a.W) ? (1u << k) : 0u;
                 uint32_t vm = 0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) vm |= ((my >> k) & 1u) ? (mx << (k * a.KW)) : 0u;
+                for (int k = 0; k < MKH; ++k) vm |= ((my >> k) & 1u) ? (mx << (k * a.KW)) : 0u;
                 vmask[i] = (m < a.M) ? vm : 0u;
                 base0[i] = (uint32_t)((b * a.H * a.W + y0 * a.W + x0) * a.C) * 2u;
             }
@@ -117,7 +117,16 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
     auto dma = [&](int ts, int kt, int buf) {
         const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
         const uint32_t la = lds0 + buf * BUF + wave * 1024, lb_ = la + BM * 128;
-        if constexpr (CONV) {
+        if constexpr (CONV == 2) {
+            // stem (C = 8: the image as pixel pairs x 4 channels): every 16-byte chunk of a K-tile is its own filter tap
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int tapi = kt * 8 + chA[i];
+                const int ky = tapi >> 2, kx = tapi & 3;                               // KW == 4 (checked on the host)
+                const bool ok = tapi < a.Kc && ((vmask[i] >> (tapi & 31)) & 1u);
+                pw_dma16(rs, la + i * 32 * 128, ok ? base0[i] + (uint32_t)((ky * a.W + kx) * 16) : URSO_OOB_SHIFT);
+            }
+        } else if constexpr (CONV == 1) {
             if (ft_cc == 0) {
                 const int tapi = ft_ky * a.KW + ft_kx;
                 const uint32_t tapoff = (uint32_t)((ft_ky * a.W + ft_kx) * a.C) * 2u;
@@ -344,8 +353,12 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
                                         case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, false, CV_>), grid, blk, 0, st, a); break; \
                                         case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, true, CV_>), grid, blk, 0, st, a); break; \
                                         default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, true, CV_>), grid, blk, 0, st, a); }
-#define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, true) } else { URSO_PW2(TT, BN_, false) } } while (0)
-    if (dt == URSO_BF16) { if (small) URSO_PW(__bf16, 64); else URSO_PW(__bf16, 128); }
+#define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, 1) } else { URSO_PW2(TT, BN_, 0) } } while (0)
+    if (conv == 2) {                     // the stem: N <= 64, no residual / mask (conv_igemm.hip checked)
+        if (dt == URSO_BF16) hipLaunchKernelGGL((pw_kernel<__bf16, 64, false, false, 2>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pw_kernel<_Float16, 64, false, false, 2>), grid, blk, 0, st, a);
+    }
+    else if (dt == URSO_BF16) { if (small) URSO_PW(__bf16, 64); else URSO_PW(__bf16, 128); }
     else { if (small) URSO_PW(_Float16, 64); else URSO_PW(_Float16, 128); }
 #undef URSO_PW
 #undef URSO_PW2
