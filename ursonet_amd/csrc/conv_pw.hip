@@ -339,8 +339,10 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     a.H = g->H; a.W = g->W; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     const int N = g->N;
     static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 0; }
-    // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU (more bytes in flight for the HBM-bound layers)
+    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 3; }
+    // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU.  Policy 3 (default, measured): N <= 64 and every
+    // filter with more than one tap (MFMA-bound: +0.7 % on the step); pointwise layers keep the wide tile (narrow = more
+    // re-reads of the pixel tile: -4 %).  URSO_PW_SMALL = 0 / 1 / 2 select never / always / short-K only.
     const bool small = N <= 64 || (force_small == 1) || (force_small == 2 && a.nkt <= 4) || (force_small == 3 && g->KH * g->KW > 1);
     const int bn = small ? 64 : 128;
     a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
