@@ -435,6 +435,174 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     }
 }
 
+// Narrow form for layers with at most 64 filters (the 3x3 convs of stage 2, the stem): 128(k) x 64(n) output tile, so no
+// MFMA work is spent on absent columns; the dz chunk is 64 pixels x 128 B (16-B slot s of row p at s ^ 2((p>>1)&3)), 48 KiB of
+// LDS per block.  Same structure as wgrad_tr_kernel otherwise.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int VE = 8, RM = 64, ITEMS = 4;          // 64 pixels x 128 channels per operand per step; 4 x 16 B per thread
+    constexpr int BUFB = RM * 256 + RM * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUFB];
+    auto sX = [&](int buf) -> char* { return smem + buf * BUFB; };
+    auto sZ = [&](int buf) -> char* { return smem + buf * BUFB + RM * 256; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a CONTIGUOUS run of the split-major work list, so
+    // that the tiles sharing a pixel range (same x / dz chunks) sit behind one L2 instead of being fetched by all eight
+    const int tiles = a.ktiles * a.ntiles;
+    const int wid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * a.splits);
+    const int sp = wid / tiles, tile = wid - sp * tiles;
+    const int kt = tile % a.ktiles, nt = tile / a.ktiles;
+    const int k0c = kt * 16, n0 = nt * 64;
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const i32x4_t rx = raw_rsrc(a.x, a.x_bytes), rz = raw_rsrc(a.dz, a.dz_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // staging role: the chunks go from HBM straight into LDS (buffer_load ... lds: the wave's 64 lanes fill 1 KiB = 4 pixel
+    // rows in lane order, out-of-range lanes write zeros), so the swizzle is applied on the SOURCE side: the lane that
+    // lands in physical slot tid&15 of row p loads logical 16-B chunk (tid&15) ^ 2(p&7).  Rows prow, +16, +32, +48.
+    const int prow = tid >> 4, ch = (tid & 15) ^ ((prow & 7) << 1);
+    const int kc = k0c + ch;
+    const bool kvalid = kc < a.Kc;
+    int ky = 0, kx = 0, cc = 0;
+    if (kvalid) { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
+    // dz staging role: physical slot tid&7 of rows zrow, zrow+32 (a wave fills 8 rows x 128 B = 1 KiB per instruction)
+    const int zrow = tid >> 3, zs = tid & 7;
+    const int zch = ((((zs >> 1) ^ ((zrow >> 1) & 3)) << 1) | (zs & 1));
+    const int ncol = n0 + zch * VE;
+    const bool nvalid = ncol < a.N;
+
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    int mcur = m_begin;
+    int pb[ITEMS], poy[ITEMS], pox[ITEMS];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            int rem;
+            divmod(m_begin + prow + 16 * e, ohw, a.rcp_ohw, pb[e], rem);
+            divmod(rem, a.OW, a.rcp_ow, poy[e], pox[e]);
+        }
+    }
+    const int dq = RM / a.OW, dr = RM - dq * a.OW;                          // MODE 1: a step advances dq rows + dr pixels
+    const uint32_t xc_off = (uint32_t)(cc * VE) * 2u, z_off0 = (uint32_t)ncol * 2u;
+
+    auto dma = [&](int buf) {
+        const uint32_t dx = lds0 + buf * BUFB + wave * 1024, dz = lds0 + buf * BUFB + RM * 256 + wave * 1024;
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int m = mcur + prow + 16 * e;
+            const bool mvalid = m < m_end;
+            uint32_t off; bool ok;
+            if constexpr (MODE == 0) { off = (uint32_t)(m * a.C) * 2u + xc_off; ok = mvalid && kvalid; }
+            else {
+                int b, oy, ox;
+                if constexpr (MODE == 1) {
+                    b = pb[e]; oy = poy[e]; ox = pox[e];
+                    int nx = ox + dr; const bool w1 = nx >= a.OW; nx -= w1 ? a.OW : 0;
+                    int ny = oy + dq + (w1 ? 1 : 0); const bool w2 = ny >= a.OH; ny -= w2 ? a.OH : 0;
+                    pox[e] = nx; poy[e] = ny; pb[e] = b + (w2 ? 1 : 0);
+                } else { int rem; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); }
+                const int iy = oy * a.SH - a.PH + ky, ix = ox * a.SW - a.PW + kx;
+                ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off;
+            }
+            lds_dma16(rx, dx + e * 16 * 256, ok ? off : URSO_OOB_SHIFT);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int mz = mcur + zrow + 32 * e;
+            const uint32_t zoff = (uint32_t)mz * (uint32_t)a.N * 2u + z_off0;
+            lds_dma16(rz, dz + e * 32 * 128, (mz < m_end && nvalid) ? zoff : URSO_OOB_SHIFT);
+        }
+        mcur += RM;
+    };
+
+    // fragment role: lane (c = lane&15, g = lane>>4); this lane's part of the address of channel block cb:
+    //   row (16r + 32ks) + 4g + (c>>2), 32-B block cb ^ (row&7), 8-B piece c&3
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frow = fg * 4 + (fr >> 2), fsw = frow & 7;
+    const int fbase = frow * 256 + (fr & 3) * 8;
+    int offx[4], offz[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offx[i] = fbase + (((wk * 4 + i) ^ fsw) << 5);
+    const int zbase = frow * 128 + (fr & 3) * 8, zsw = (frow >> 1) & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offz[j] = zbase + (((wn * 2 + j) ^ zsw) << 5);
+
+    f32x4_t acc[4][2], accc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    accc[0] = accc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_col = (kt == 0) && (wk == 0) && a.colpart;
+    const i32x4_t ones = {OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W};
+
+    const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
+    if (nsteps > 0) dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk has landed in LDS
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) dma(cur ^ 1);             // that buffer was released by the barrier that ended step s-1
+        const char* bx = sX(cur); const char* bz = sZ(cur);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i32x4_t fz[2], fx[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const i32x2_t lo = lds_read_tr16(bz + offz[j] + ks * 32 * 128), hi = lds_read_tr16(bz + offz[j] + ks * 32 * 128 + 16 * 128);
+                fz[j] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i32x2_t lo = lds_read_tr16(bx + offx[i] + ks * 32 * 256), hi = lds_read_tr16(bx + offx[i] + ks * 32 * 256 + 16 * 256);
+                fx[i] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(fz[j], fx[i], acc[i][j]);
+            if (do_col) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(fz[j], ones, accc[j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float* out = a.part + (size_t)sp * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kt * 128 + wk * 64 + i * 16 + fr;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = n0 + wn * 32 + j * 16 + fg * 4;
+            if (nb >= a.N) continue;
+            *(f32x4_t*)(out + (size_t)k * a.N + nb) = acc[i][j];                    // N % 8 == 0 on this path
+        }
+    }
+    if (do_col && fr == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = n0 + wn * 32 + j * 16 + fg * 4;
+            if (nb < a.N) *(f32x4_t*)(a.colpart + (size_t)sp * a.N + nb) = accc[j];
+        }
+    }
+}
+
 // Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
 // float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
 // sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
@@ -487,7 +655,7 @@ void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int
     hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
 }
 
-struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split; size_t part_elems, col_elems; };
+struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split, narrow; size_t part_elems, col_elems; };
 
 static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int es = (int)dt_size(dt);
@@ -495,7 +663,10 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     if (g->C % p.VE || g->N % p.VE) return URSO_EINVAL;
     p.Cc = g->C / p.VE; p.Kc = g->KH * g->KW * p.Cc; p.K = p.Kc * p.VE;
     p.M = g->B * g->OH * g->OW;
-    p.ktiles = ceil_div(p.K, 128); p.ntiles = ceil_div(g->N, 128);
+    static int narrow_ok = -1;
+    if (narrow_ok < 0) { const char* e = getenv("URSO_WGRAD_NARROW"); narrow_ok = e ? atoi(e) : 1; }
+    p.narrow = (es == 2 && narrow_ok && g->N <= 64) ? 1 : 0;      // 16-bit layers with <= 64 filters: 128 x 64 tiles (wgrad_tr64_kernel)
+    p.ktiles = ceil_div(p.K, 128); p.ntiles = ceil_div(g->N, p.narrow ? 64 : 128);
     const int tiles = p.ktiles * p.ntiles;
     const int steps = ceil_div(p.M, p.RM);
     // aim for ~2 resident blocks per CU (64 KiB LDS each) but keep >= 8 reduction steps per block;
@@ -568,6 +739,7 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
                          else if (MD == 1) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 1, true>), grid, dim3(256), 0, st, a); \
                          else hipLaunchKernelGGL((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)
     if (dt == URSO_F32) URSO_WG(wgrad_kernel, float, mode);
+    else if (p.narrow) { if (dt == URSO_BF16) URSO_WG(wgrad_tr64_kernel, __bf16, tmode); else URSO_WG(wgrad_tr64_kernel, _Float16, tmode); }
     else if (dt == URSO_BF16) { if (pipe) URSO_WGP(__bf16, tmode); else URSO_WG(wgrad_tr_kernel, __bf16, tmode); }
     else { if (pipe) URSO_WGP(_Float16, tmode); else URSO_WG(wgrad_tr_kernel, _Float16, tmode); }
 #undef URSO_WGP
