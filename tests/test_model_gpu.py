@@ -283,3 +283,67 @@ def test_exact_rel_loss_mode_single_gpu_equals_default():
     assert abs(res[0][0]["loc_loss"] - res[1][0]["loc_loss"]) < 1e-6 * abs(res[0][0]["loc_loss"])
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-6 * float(res[0][1].abs().max())
     assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-6 * float(res[0][2].abs().max())
+
+
+def test_full_size_cfg2_step_is_deterministic_and_descends():
+    """BASELINE.json configs[1] at its real size (ResNet-50, 32 x 512 x 640, bf16) through properties that do not need the
+    oracle: (a) two engines run from the same state produce bit-identical weights after 3 steps (fixed-order reductions,
+    no atomics), (b) the loss on a fixed batch goes down, (c) every gradient is finite, (d) frozen-BN statistics unchanged."""
+    from ursonet_amd.engine import Engine
+    cfg = make_config(backbone="resnet50", h=512, w=640, batch=32, regress_ori=False, ori_bins=16, dtype="bfloat16", lr=1e-3)
+    img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=12)
+    finals, first_losses, last_losses = [], [], []
+    for run in range(2):
+        eng = Engine(cfg, "training", seed=21, randomize_bn=True)
+        stats0 = eng.flat_stats.clone()
+        eng.load_batch(img, loc, ori)
+        eng.step(); torch.cuda.synchronize()
+        l0 = eng.losses()
+        assert bool(torch.isfinite(eng.flat_g).all())
+        for _ in range(5):
+            eng.step()
+        torch.cuda.synchronize()
+        l1 = eng.losses()
+        first_losses.append(l0); last_losses.append(l1)
+        finals.append(eng.flat_w.clone())
+        assert torch.equal(eng.flat_stats, stats0)
+        del eng
+        torch.cuda.empty_cache()
+    assert torch.equal(finals[0], finals[1]), "training is not deterministic"
+    assert first_losses[0] == first_losses[1] and last_losses[0] == last_losses[1]
+    tot0 = first_losses[0]["loc_loss"] + first_losses[0]["ori_loss"]
+    tot1 = last_losses[0]["loc_loss"] + last_losses[0]["ori_loss"]
+    assert np.isfinite(tot1) and tot1 < tot0, (tot0, tot1)
+
+
+def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch):
+    """The DP path (bucketed hipGraph segments + RCCL all-reduce between them) with ONE rank and the collectives forced on
+    must reproduce the single-graph engine bit for bit (AVG over one rank is the identity); also with DP_EXACT_REL_LOSS."""
+    import socket
+    import torch.distributed as dist
+    from ursonet_amd.engine import Engine
+    from ursonet_amd.dp import DataParallelEngine
+    monkeypatch.setenv("URSO_DP_FORCE_COLLECTIVES", "1")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        for exact in (False, True):
+            cfg = make_config(backbone="resnet50", h=64, w=128, batch=4, regress_ori=False, ori_bins=4, dtype="bfloat16")
+            cfg.DP_EXACT_REL_LOSS = exact
+            img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=3)
+            plain = Engine(cfg, "training", seed=8, randomize_bn=True)
+            plain.load_batch(img, loc, ori)
+            for _ in range(3):
+                plain.step()
+            eng = Engine(cfg, "training", seed=8, randomize_bn=True, grad_bucket_bytes=8 << 20)
+            dp = DataParallelEngine(eng, bucket_bytes=8 << 20)
+            assert len(dp.buckets) >= 3
+            eng.load_batch(img, loc, ori)
+            for _ in range(3):
+                dp.step()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.flat_w, plain.flat_w), "DP (1 rank) differs from the plain engine (exact=%s)" % exact
+            assert eng.losses() == plain.losses()
+    finally:
+        dist.destroy_process_group()
