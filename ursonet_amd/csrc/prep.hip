@@ -47,6 +47,54 @@ __device__ __forceinline__ void weight_prep_body(int bx, int by, int tap, int KH
     }
 }
 
+// 64 x 64 form for C % 4 == 0, N % 4 == 0: 16-byte reads of W along n, 8-byte (16-bit T) / 16-byte (fp32) stores of wd along n and
+// of wf along c through a 64 x 64 LDS transpose.  One block = one (tap, 64 channels, 64 filters) tile.
+template <typename T>
+__device__ __forceinline__ void weight_prep_body64(int bx, int by, int tap, int KH, int KW, int C, int N, int npad,
+                                   const float* __restrict__ w, const float* __restrict__ b,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                   void* wf, void* wd, float* biasf, float* scale) {
+    __shared__ float tile[64][65];
+    const int c0 = bx * 64, n0 = by * 64;
+    const int tq = threadIdx.x & 15, tr = threadIdx.x >> 4;        // 16 quads x 16 rows
+    const int taps = KH * KW, ftap = taps - 1 - tap;
+    const int n = n0 + tq * 4;
+    float s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = (n + q < N) ? bn_scale(gamma, var, eps, n + q) : 1.0f;
+    for (int cy = tr; cy < 64; cy += 16) {
+        const int c = c0 + cy;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (c < C && n < N) { v = *(const f32x4_t*)(w + ((size_t)tap * C + c) * N + n); v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3]; }
+        tile[cy][tq * 4] = v.x; tile[cy][tq * 4 + 1] = v.y; tile[cy][tq * 4 + 2] = v.z; tile[cy][tq * 4 + 3] = v.w;
+        if (wd && c < C && n < npad) {
+            T o[4] = {Elem<T>::from_f(v.x), Elem<T>::from_f(v.y), Elem<T>::from_f(v.z), Elem<T>::from_f(v.w)};
+            __builtin_memcpy((T*)wd + ((size_t)c * taps + ftap) * npad + n, o, sizeof(o));
+        }
+    }
+    __syncthreads();
+    for (int ny = tr; ny < 64; ny += 16) {
+        const int nn = n0 + ny, c = c0 + tq * 4;
+        if (nn < npad && c < C) {
+            T o[4] = {Elem<T>::from_f(tile[tq * 4][ny]), Elem<T>::from_f(tile[tq * 4 + 1][ny]), Elem<T>::from_f(tile[tq * 4 + 2][ny]),
+                      Elem<T>::from_f(tile[tq * 4 + 3][ny])};
+            __builtin_memcpy((T*)wf + ((size_t)nn * taps + tap) * C + c, o, sizeof(o));
+        }
+    }
+    if (tap == 0 && bx == 0 && tr == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nq = n + q;
+            if (nq < npad) {
+                float bf = 0.f, sc = 1.f;
+                if (nq < N) { sc = s[q]; bf = (b ? b[nq] * s[q] : 0.f); if (gamma) bf += beta[nq] - mean[nq] * s[q]; }
+                biasf[nq] = bf; scale[nq] = sc;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void weight_prep_kernel(int KH, int KW, int C, int N, int npad,
                                    const float* __restrict__ w, const float* __restrict__ b,
@@ -61,6 +109,13 @@ template <typename T>
 __global__ void weight_prep_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
+    if (((d.C | d.N | d.npad) & 3) == 0) {                          // aligned layers: 64 x 64 vector form
+        const int gx = ceil_div(d.C, 64), gy = ceil_div(d.npad, 64);
+        const int bx = local % gx, by = (local / gx) % gy, tap = local / (gx * gy);
+        weight_prep_body64<T>(bx, by, tap, d.KH, d.KW, d.C, d.N, d.npad, d.w, d.b, d.gamma, d.beta, d.mean, d.var, d.eps,
+                              d.wf, d.wd, d.biasf, d.scale);
+        return;
+    }
     const int gx = ceil_div(d.C, 32), gy = ceil_div(d.npad, 32);
     const int bx = local % gx, by = (local / gx) % gy, tap = local / (gx * gy);
     weight_prep_body<T>(bx, by, tap, d.KH, d.KW, d.C, d.N, d.npad, d.w, d.b, d.gamma, d.beta, d.mean, d.var, d.eps,
@@ -143,10 +198,38 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
 __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
                                     const float* __restrict__ gamma, const float* __restrict__ var, float eps,
                                     float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
+    const int kbeg = by * kb, kend = min(K, kbeg + kb);
+    if (((N | ldn) & 3) == 0) {
+        // 16 column quads (64 columns) x 16 row lanes, 16-byte loads/stores; the 16 row lanes are combined in lane order
+        __shared__ f32x4_t red4[16][17];
+        const int tq = threadIdx.x & 15, tk = threadIdx.x >> 4;
+        const int n = bx * 64 + tq * 4;
+        f32x4_t dot = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) {
+            f32x4_t s;
+            s.x = bn_scale(gamma, var, eps, n); s.y = bn_scale(gamma, var, eps, n + 1);
+            s.z = bn_scale(gamma, var, eps, n + 2); s.w = bn_scale(gamma, var, eps, n + 3);
+            for (int k = kbeg + tk; k < kend; k += 16) {
+                const f32x4_t d = *(const f32x4_t*)(dwr + (size_t)k * ldn + n), ww = *(const f32x4_t*)(w + (size_t)k * N + n);
+                dot += ww * d;
+                f32x4_t g = s * d + ww * regc;
+                if (!trainable) g = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                *(f32x4_t*)(gw + (size_t)k * N + n) = g;
+            }
+        }
+        red4[tk][tq] = dot;
+        __syncthreads();
+        if (tk == 0 && n < N) {
+            f32x4_t t = red4[0][tq];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) t += red4[i][tq];
+            *(f32x4_t*)(dotpart + (size_t)by * N + n) = t;
+        }
+        return;
+    }
     __shared__ float red[4][64];
     const int tn = threadIdx.x & 63, tk = threadIdx.x >> 6;
     const int n = bx * 64 + tn;
-    const int kbeg = by * kb, kend = min(K, kbeg + kb);
     float dot = 0.f;
     if (n < N) {
         const float s = bn_scale(gamma, var, eps, n);
@@ -250,7 +333,7 @@ void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int
 
 static int batch_layer_blocks(int phase, const urso_param_desc& d) {
     switch (phase) {
-    case URSO_PB_PREP: return ceil_div(d.C, 32) * ceil_div(d.npad, 32) * d.KH * d.KW;
+    case URSO_PB_PREP: return (((d.C | d.N | d.npad) & 3) == 0 ? ceil_div(d.C, 64) * ceil_div(d.npad, 64) : ceil_div(d.C, 32) * ceil_div(d.npad, 32)) * d.KH * d.KW;
     case URSO_PB_REDUCE: {
         if (d.splits <= 1) return 0;
         const size_t cnt = (size_t)d.K * d.npad;
