@@ -106,6 +106,8 @@ int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
  * `g` is the FORWARD geometry (src = x, dst = dz, D = 1).  Deterministic split over the
  * pixel dimension with fp32 partials in ws_d (no atomics).
  */
+#define URSO_WGRAD_PART_PAD 64   /* floats of padding between consecutive partial tensors: a power-of-two distance would put the
+                                   same element of every partial on the same HBM channel */
 size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt);
 int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
                     void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream);
@@ -166,8 +168,8 @@ size_t urso_param_grad_finalize_ws_bytes(int K, int N);
  * step in launch latency.  One urso_param_desc per layer (plain C, device pointers) lives in a device array; a host-built
  * block map (2 x int32 per block: layer index, local block id) lets ONE launch per phase cover any subset of layers,
  * e.g. all layers of one gradient bucket.  Arithmetic and summation order are those of the per-layer entry points.
- *   urso_conv_wgrad_partial  : urso_conv_wgrad without the split reduction; ws_d = part[splits][K][npad] fp32 followed by
- *                              colpart[splits][npad] (urso_conv_wgrad_ws_bytes).  urso_conv_wgrad_splits gives `splits`.
+ *   urso_conv_wgrad_partial  : urso_conv_wgrad without the split reduction; ws_d = `splits` partial tensors [K][npad] fp32, K*npad + URSO_WGRAD_PART_PAD floats apart,
+ *                              followed by colpart[splits][npad] (urso_conv_wgrad_ws_bytes).  urso_conv_wgrad_splits gives `splits`.
  *   urso_param_desc_init     : fills geometry, k-slab plan and L2 coefficients (regc = 2 wd/(K N), regb = 2 wd/N).
  *   urso_param_batch_plan    : host; writes the block map for `phase` over descs_h[layer_ids[0..n_ids)] and returns the
  *                              block count (call with blockmap_h = NULL to size it).

@@ -460,7 +460,7 @@ def test_batched_param_phases_equal_per_layer_entry_points(dt):
                      ("wd", t["wd"]), ("biasf", t["biasf"]), ("scale", t["scale"]), ("dw_raw", t["dw_raw"]), ("colsum", t["colsum"]),
                      ("dotpart", t["dotpart"]), ("gw", t["gw"]), ("gb", t["gb"]), ("ggamma", t["gg"]), ("gbeta", t["gbe"])):
             setattr(d, f, hip.ptr(v))
-        d.part = t["ws"].data_ptr(); d.colpart = t["ws"].data_ptr() + 4 * splits * K * NP
+        d.part = t["ws"].data_ptr(); d.colpart = t["ws"].data_ptr() + 4 * splits * (K * NP + hip.WGRAD_PART_PAD)
         d.trainable, d.bn_trainable = 1, 1
         descs.append(d)
     assert descs[0].splits > 1 and descs[2].splits == 1

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 
     // ---- store the fp32 partial tile: part[sp][k][n], lane holds n..n+3 for one k
-    float* out = a.part + (size_t)sp * a.K * a.N;
+    float* out = a.part + (size_t)sp * ((size_t)a.K * a.N + URSO_WGRAD_PART_PAD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = kt * 128 + wk * 64 + i * 16 + fr;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
         __syncthreads();
     }
 
-    float* out = a.part + (size_t)sp * a.K * a.N;
+    float* out = a.part + (size_t)sp * ((size_t)a.K * a.N + URSO_WGRAD_PART_PAD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = kt * 128 + wk * 64 + i * 16 + fr;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
         __syncthreads();
     }
 
-    float* out = a.part + (size_t)sp * a.K * a.N;
+    float* out = a.part + (size_t)sp * ((size_t)a.K * a.N + URSO_WGRAD_PART_PAD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = kt * 128 + wk * 64 + i * 16 + fr;
@@ -606,39 +606,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
 // Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
 // float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
 // sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
-__device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
-    __shared__ f32x4_t red[16][17];
+__device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ part, float* __restrict__ out, size_t count, int splits,
+                                                     size_t pstride /* floats between partial tensors, multiple of 4 */) {
+    // a block owns 64 consecutive float4 columns (1 KiB per partial row); thread (col 0..15, split-lane sl 0..15) owns columns
+    // col, col+16, col+32, col+48 and the splits sl, sl+16, ...: eight 16-byte loads in flight per thread
+    __shared__ f32x4_t red[4][16][17];
     const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const size_t q = (size_t)bid * 16 + col;          // float4 index
+    const size_t q0 = (size_t)bid * 64 + col;         // first float4 index of this thread
     const size_t nq = (count + 3) / 4;
-    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    const bool full = (q * 4 + 3 < count);
-    if (q < nq && full) {
-        const f32x4_t* p = (const f32x4_t*)part + q;
-        const size_t stride = count / 4;                      // count % 4 == 0 whenever `full` rows are used (host guarantees)
-        int k = sl;
-        for (; k + 48 < splits; k += 64) {
-            f32x4_t a = p[(size_t)k * stride], b = p[(size_t)(k + 16) * stride], c = p[(size_t)(k + 32) * stride], d = p[(size_t)(k + 48) * stride];
-            s0 += a; s1 += b; s2 += c; s3 += d;
-        }
-        for (; k < splits; k += 16) s0 += p[(size_t)k * stride];
-    }
-    red[sl][col] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (sl == 0 && q < nq) {
-        if (full) {
-            f32x4_t t = red[0][col];
+    const bool vec = (count & 3) == 0;                // otherwise (tiny odd-sized tensors) the scalar tail below does everything
+    f32x4_t s[4][2];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) t += red[i][col];
-            *((f32x4_t*)out + q) = t;
-        } else {
-            for (size_t e = q * 4; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * count + e]; out[e] = t; }
+    for (int c = 0; c < 4; ++c) s[c][0] = s[c][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        const size_t stride = pstride / 4;
+        const f32x4_t* p = (const f32x4_t*)part;
+        int k = sl;
+        for (; k + 16 < splits; k += 32) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const size_t q = q0 + 16 * c;
+                if (q < nq) { s[c][0] += p[(size_t)k * stride + q]; s[c][1] += p[(size_t)(k + 16) * stride + q]; }
+            }
+        }
+        if (k < splits) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const size_t q = q0 + 16 * c; if (q < nq) s[c][0] += p[(size_t)k * stride + q]; }
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][sl][col] = s[c][0] + s[c][1];
+    __syncthreads();
+    if (sl < 4) {                                      // split-lane c finishes column group c (fixed order over the 16 lanes)
+        const size_t q = q0 + 16 * sl;
+        if (vec && q < nq) {
+            f32x4_t t = red[sl][0][col];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) t += red[sl][i][col];
+            *((f32x4_t*)out + q) = t;
+        }
+    }
+    if (!vec && threadIdx.x == 0 && bid == 0)
+        for (size_t e = 0; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * pstride + e]; out[e] = t; }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits) {
-    reduce_partials_body(blockIdx.x, part, out, count, splits);
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits, size_t pstride) {
+    reduce_partials_body(blockIdx.x, part, out, count, splits, pstride);
 }
 
 // Batched over layers (see urso_param_batch_run): a layer's first blocks reduce its weight partials, the rest its column sums.
@@ -646,9 +659,9 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const urso_p
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     const size_t cnt = (size_t)d.K * d.npad;
-    const int nb_dw = (int)(((cnt + 3) / 4 + 15) / 16);
-    if (local < nb_dw) reduce_partials_body(local, d.part, d.dw_raw, cnt, d.splits);
-    else reduce_partials_body(local - nb_dw, d.colpart, d.colsum, (size_t)d.npad, d.splits);
+    const int nb_dw = (int)(((cnt + 3) / 4 + 63) / 64);
+    if (local < nb_dw) reduce_partials_body(local, d.part, d.dw_raw, cnt, d.splits, cnt + URSO_WGRAD_PART_PAD);
+    else reduce_partials_body(local - nb_dw, d.colpart, d.colsum, (size_t)d.npad, d.splits, (size_t)d.npad);
 }
 
 void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, hipStream_t st) {
@@ -680,7 +693,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     int steps_per = ceil_div(steps, splits);
     splits = ceil_div(steps, steps_per);
     p.splits = splits; p.m_per_split = steps_per * p.RM;
-    p.part_elems = (size_t)splits * p.K * g->N;
+    p.part_elems = (size_t)splits * ((size_t)p.K * g->N + URSO_WGRAD_PART_PAD);
     p.col_elems = (size_t)splits * g->N;
     return URSO_OK;
 }
@@ -748,9 +761,9 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     if (rc != URSO_OK) return rc;
     if (!direct && !keep_partials) {
         size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
-        int blocks = (int)(((cnt + 3) / 4 + 15) / 16);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + 15) / 16)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits);
+        int blocks = (int)(((cnt + 3) / 4 + 63) / 64);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits, cnt + URSO_WGRAD_PART_PAD);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + 63) / 64)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;

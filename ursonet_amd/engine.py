@@ -369,7 +369,7 @@ class Engine(object):
             elif tr or bn_tr:
                 d = c.desc
                 c.wg_ws = torch.empty(hip.conv_wgrad_ws_bytes(c.gf, dt) // 4 + 64, dtype=torch.float32, device=dev)
-                n_part = c.splits * c.K_raw * c.npad
+                n_part = c.splits * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
                 c.dotpart = torch.empty(d.ks * c.N + 16, dtype=torch.float32, device=dev)

@@ -57,6 +57,7 @@ class ParamDesc(C.Structure):
 
 
 PB_PREP, PB_REDUCE, PB_FINALIZE_MAT, PB_FINALIZE_VEC = 0, 1, 2, 3
+WGRAD_PART_PAD = 64            # URSO_WGRAD_PART_PAD: floats between consecutive wgrad partial tensors
 _dp = C.POINTER(ParamDesc)
 _SIGS = {
     "urso_last_error": (C.c_char_p, []),
