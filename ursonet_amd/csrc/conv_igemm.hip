@@ -396,7 +396,7 @@ static void plan_splitk(int ntiles, int nkt, int ncu, int& S, int& kps) {
 
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
-                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);      // conv_pw.hip
+                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st);      // conv_pw.hip
 
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
@@ -539,17 +539,22 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         static int use_pw = -1;
         if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 3; }     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
-        const bool fits = dt != URSO_F32 && !(flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) && (g->N % 8) == 0 &&
+        const bool wants_bits = (flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) != 0;
+        const bool bits_fit = !wants_bits || (a.pointwise && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&
+                                              !((flags & URSO_EPI_MASK_BITS) && !mask_d) && !((flags & URSO_EPI_EMIT_BITS) && !bits_out_d));
+        const bool fits = dt != URSO_F32 && !(flags & URSO_EPI_OUT_F32) && bits_fit && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
+        const int mbits = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;
+        void* bout = (flags & URSO_EPI_EMIT_BITS) ? bits_out_d : nullptr;
         const bool taps_ok = (a.Cc & 7) == 0 && g->DH == 1 && g->DW == 1 && g->KH <= 3 && g->KW <= 3;     // whole-tap K-tiles, undilated, <= 3x3
         // the 7x7/s2 stem as packed by urso_stem_weight_pack: 7 x 4 taps of 8-channel pixel pairs, one tap per 16-byte chunk
         const bool stem_ok = a.Cc == 1 && g->KW == 4 && g->KH <= 8 && g->DH == 1 && g->DW == 1 && g->N <= 64 && !add_d && !mask_d;
-        if (fits && use_pw >= 3 && stem_ok)
+        if (fits && !wants_bits && use_pw >= 3 && stem_ok)
             return urso_pw_launch(g, dt, 2, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
-                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
-        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && taps_ok)))
+                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, 0, nullptr, st);
+        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && taps_ok && !wants_bits)))
             return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
-                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
+                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, mbits, bout, st);
     }
     if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, ws_d, ws_bytes, st);
     if (dt == URSO_BF16) return launch_igemm<__bf16>(g, flags, a, ws_d, ws_bytes, st);

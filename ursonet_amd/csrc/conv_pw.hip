@@ -22,6 +22,7 @@ struct PwArgs {
     int OH, OW, FH, FW, OSH, OSW;      // destination scatter (FH == 0: dense)
     float rcp_ohw, rcp_ow;
     int relu;
+    void* bits_out;                    // EMIT: ReLU bit mask of the stored output (1 byte per 16-byte vector)
     int H, W, KH, KW, SH, SW, PH, PW, DHs, DWs;   // CONV: general source mapping (conv_igemm.hip), Cc % 8 == 0 so a K-tile never straddles taps
 };
 
@@ -36,15 +37,18 @@ __device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
 }
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <typename T, int BN, bool HAS_ADD, bool HAS_MASK, int CONV>   // CONV: 0 pointwise, 1 whole-tap conv (<= 3x3), 2 stem (one tap per 16-byte chunk)
+// MASKK: 0 none, 1 mask_d is a tensor like dst (keep where > 0), 2 mask_d is a ReLU BIT mask (1 byte per 16-byte vector of dst);
+// EMIT: also write such a bit mask of (stored dst > 0) to bits_out (include/ursonet_hip.h, urso_conv_igemm_ex).
+template <typename T, int BN, bool HAS_ADD, int MASKK, int CONV, bool EMIT = false>   // CONV: 0 pointwise, 1 whole-tap conv (<= 3x3), 2 stem (one tap per 16-byte chunk)
 __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
+    constexpr bool HAS_MASK = MASKK == 1;
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = 128, VE = 8;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int RA = BM / 32, RB = BN / 32;                 // DMA instructions per thread per K-tile
     constexpr int BUF = (BM + BN) * 128;
     constexpr int CH = TN * 4, JPV = VE / 4, NV = CH / VE;    // channels / sub-tiles per vector / vectors per lane per pixel row
-    constexpr int NEPI = TM * NV * (1 + (HAS_ADD ? 1 : 0) + (HAS_MASK ? 1 : 0));   // vm operations an epilogue issues when a next tile exists
+    constexpr int NEPI = TM * NV * (1 + (HAS_ADD ? 1 : 0) + (MASKK ? 1 : 0) + (EMIT ? 1 : 0));   // vm operations an epilogue issues when a next tile exists
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto sA = [&](int buf) -> const char* { return smem + buf * BUF; };
@@ -62,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
     const i32x4_t rs = pw_rsrc(a.src, a.src_bytes), rw = pw_rsrc(a.wgt, a.wgt_bytes);
     const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? (MASKK == 2 ? a.dst_bytes / 16u : a.dst_bytes) : 0u);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(EMIT ? a.bits_out : a.dst, EMIT ? a.dst_bytes / 16u : 0u);
     const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
 
     // ---- DMA roles: LDS row r0 + 32 i (pixel tile, then weight tile), physical 16-byte slot c8
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
     };
 
     i32x4_t radd[HAS_ADD ? TM * NV : 1], rmsk[HAS_MASK ? TM * NV : 1];
+    uint32_t rbit[MASKK == 2 ? TM * NV : 1];
     uint32_t eo_cur[TM], eo_nxt[TM];
     tile_offs(tile, eo_cur);
 #pragma unroll
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
             const uint32_t o = voff(eo_cur[i], tile, v);
             if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+            if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b8(rmk, o >> 4, 0, 0);   // OOB >> 4 is beyond any bit mask
         }
     setup_src(tile);
     dma(tile, 0, 0);
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
                 T ea[VE], em[VE], eo[VE];
                 if constexpr (HAS_ADD) __builtin_memcpy(ea, &radd[i * NV + v], 16);
                 if constexpr (HAS_MASK) __builtin_memcpy(em, &rmsk[i * NV + v], 16);
+                uint32_t mbits = 0;
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     const int c = v * VE + e;
@@ -294,14 +302,27 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
                     if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
                     y = a.relu ? fmaxf(y, 0.f) : y;
                     if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> e) & 1u) ? y : 0.f;
                     eo[e] = Elem<T>::from_f(y);
+                    if constexpr (EMIT) mbits |= (Elem<T>::to_f(eo[e]) > 0.f) ? (1u << e) : 0u;       // of the STORED value
                 }
                 i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
-                buf_store16(rds, voff(eo_cur[i], tile, v), ov);
+                const uint32_t so = voff(eo_cur[i], tile, v);
+                buf_store16(rds, so, ov);
+                if constexpr (EMIT) {
+                    // the four lanes of a pixel (fg = 0..3) hold four consecutive mask bytes: gather them into one dword and let
+                    // lane fg = 0 store it (64 single-byte lanes per store instruction cost the HBM-bound forward pass ~10 %)
+                    const uint32_t x = (uint32_t)__shfl_xor((int)mbits, 16, 64);
+                    const uint32_t pr = (fg & 1) ? (x | (mbits << 8)) : (mbits | (x << 8));
+                    const uint32_t y2 = (uint32_t)__shfl_xor((int)pr, 32, 64);
+                    const uint32_t dw = (fg & 2) ? (y2 | (pr << 16)) : (pr | (y2 << 16));
+                    __builtin_amdgcn_raw_buffer_store_b32(dw, rmo, (fg == 0) ? (so >> 4) : URSO_OOB_SHIFT, 0, 0);
+                }
                 if (has_next) {                          // this slot's registers are free: request the next tile's vector
                     const uint32_t o = voff(eo_nxt[i], next, v);
                     if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
                     if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+                    if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b8(rmk, o >> 4, 0, 0);
                 }
             }
         }
@@ -329,8 +350,9 @@ static int pw_device_cus() {
 // Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
-                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
+                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st) {
     PwArgs a;
+    a.bits_out = bits_out;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
     a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
     a.M = g->B * g->OH * g->OW; a.C = g->C; a.N = g->N; a.Cc = g->C / 8; a.Kc = g->KH * g->KW * a.Cc; a.nkt = ceil_div(a.Kc, 8);
@@ -351,14 +373,25 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     if (bpx > cap) bpx = cap;
     const dim3 grid(8 * bpx), blk(256);
     const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
-#define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, false, CV_>), grid, blk, 0, st, a); break; \
-                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, false, CV_>), grid, blk, 0, st, a); break; \
-                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, true, CV_>), grid, blk, 0, st, a); break; \
-                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, true, CV_>), grid, blk, 0, st, a); }
+#define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 0, CV_>), grid, blk, 0, st, a); break; \
+                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 0, CV_>), grid, blk, 0, st, a); break; \
+                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 1, CV_>), grid, blk, 0, st, a); break; \
+                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 1, CV_>), grid, blk, 0, st, a); }
 #define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, 1) } else { URSO_PW2(TT, BN_, 0) } } while (0)
+    if (mask_bits || bits_out) {         // ReLU bit masks: pointwise layers only (conv_igemm.hip checked): emit = forward with residual, consume = data gradient
+#define URSO_PWB(TT, BN_) do { \
+        if (bits_out) { if (add) hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 0, 0, true>), grid, blk, 0, st, a); \
+                        else hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 0, 0, true>), grid, blk, 0, st, a); } \
+        else { if (add) hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 2, 0, false>), grid, blk, 0, st, a); \
+               else hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 2, 0, false>), grid, blk, 0, st, a); } } while (0)
+        if (dt == URSO_BF16) { if (small) URSO_PWB(__bf16, 64); else URSO_PWB(__bf16, 128); }
+        else { if (small) URSO_PWB(_Float16, 64); else URSO_PWB(_Float16, 128); }
+#undef URSO_PWB
+        return urso_check_launch("urso_conv_igemm(dma, bits)");
+    }
     if (conv == 2) {                     // the stem: N <= 64, no residual / mask (conv_igemm.hip checked)
-        if (dt == URSO_BF16) hipLaunchKernelGGL((pw_kernel<__bf16, 64, false, false, 2>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pw_kernel<_Float16, 64, false, false, 2>), grid, blk, 0, st, a);
+        if (dt == URSO_BF16) hipLaunchKernelGGL((pw_kernel<__bf16, 64, false, 0, 2>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pw_kernel<_Float16, 64, false, 0, 2>), grid, blk, 0, st, a);
     }
     else if (dt == URSO_BF16) { if (small) URSO_PW(__bf16, 64); else URSO_PW(__bf16, 128); }
     else { if (small) URSO_PW(_Float16, 64); else URSO_PW(_Float16, 128); }
