@@ -541,7 +541,7 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool wants_bits = (flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) != 0;
         const bool bits_fit = !wants_bits || (a.pointwise && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&
-                                              !((flags & URSO_EPI_MASK_BITS) && !mask_d) && !((flags & URSO_EPI_EMIT_BITS) && !bits_out_d));
+                                              !((flags & URSO_EPI_MASK_BITS) && (!mask_d || (g->N % 32))) && !((flags & URSO_EPI_EMIT_BITS) && !bits_out_d));
         const bool fits = dt != URSO_F32 && !(flags & URSO_EPI_OUT_F32) && bits_fit && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
         const int mbits = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;

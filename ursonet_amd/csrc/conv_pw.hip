@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
             const uint32_t o = voff(eo_cur[i], tile, v);
             if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-            if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b8(rmk, o >> 4, 0, 0);   // OOB >> 4 is beyond any bit mask
+            if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;   // the pixel's 4 lanes read one dword; OOB >> 4 is beyond any bit mask
         }
     setup_src(tile);
     dma(tile, 0, 0);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
                     const uint32_t o = voff(eo_nxt[i], next, v);
                     if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
                     if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-                    if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b8(rmk, o >> 4, 0, 0);
+                    if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
                 }
             }
         }
