@@ -6,7 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "liburso_hip.so")
+# Kernel experiments: URSO_LIB_VARIANT=<name> builds / loads lib/liburso_hip_<name>.so compiled with URSO_VARIANT_FLAGS
+# (e.g. "-DURSO_PW_NT=1"), so that two compile-time variants can be compared inside ONE gpurun call on the same box.
+VARIANT = os.environ.get("URSO_LIB_VARIANT", "")
+LIB = os.path.join(LIBDIR, "liburso_hip%s.so" % (("_" + VARIANT) if VARIANT else ""))
 SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_pw.hip", "conv_wgrad.hip", "prep.hip", "pool_loss_optim.hip", "augment.hip", "bn_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
@@ -34,9 +37,9 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, s.replace(".hip", (("_" + VARIANT) if VARIANT else "") + ".o"))
         objs.append(o)
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc()] + FLAGS + os.environ.get("URSO_VARIANT_FLAGS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

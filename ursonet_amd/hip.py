@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liburso_hip.so")
+_VARIANT = os.environ.get("URSO_LIB_VARIANT", "")        # kernel experiments: see ursonet_amd/build.py
+LIB_PATH = os.path.join(_HERE, "lib", "liburso_hip%s.so" % (("_" + _VARIANT) if _VARIANT else ""))
 
 F32, BF16, F16 = 0, 1, 2
 EPI_RELU, EPI_OUT_F32, EPI_MASK_BITS, EPI_EMIT_BITS = 1, 2, 4, 8
