@@ -325,3 +325,10 @@ def rotate_cam_given(image, t, q, K, pyr_change):
     t_new = np.asarray(t, dtype=np.float64) @ R.T
     q_new = quat_mult(SO32quat(R), q)
     return warped, t_new, q_new
+
+
+def encode_as_keypoints(ori, centroid, scale=1.0):
+    """utils.py:220-227 (one pose): K = R [0,0,1]^T scale + c and R [0,1,0]^T scale + c, as 3x1 columns."""
+    R = quat2SO3(ori)
+    c = np.asarray(centroid, dtype=np.float64).reshape(3, 1)
+    return R @ (scale * np.array([[0.0], [0.0], [1.0]])) + c, R @ (scale * np.array([[0.0], [1.0], [0.0]])) + c

@@ -129,3 +129,27 @@ def test_load_image_gt_rotation_augmentation_matches_oracle(mode):
             ref = P.encode_ori_fast(qn, cfg.BETA, ds.ori_histogram_map, ds.ori_output_mask)
             assert np.abs(ori - ref).max() <= 1e-6 * ref.max() + 1e-7
     assert hit >= 2
+
+
+def test_load_image_gt_rotation_augmentation_keypoint_mode():
+    """REGRESS_KEYPOINTS + ROT_AUG (net.py:421-424): the two virtual keypoints follow the rotated pose."""
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    from oracle import pose_math as P
+    cfg = make_config("resnet18", 64, 128, batch=2, regress_ori=True, keypoints=True)
+    cfg.ROT_AUG = True
+    ds = SyntheticPoses(4, 64, 128, cfg, seed=5)
+    hit = 0
+    for seed in range(8):
+        np.random.seed(seed)
+        img, meta, loc, k1, k2 = net.load_image_gt(ds, cfg, 2)
+        np.random.seed(seed)
+        if not (np.random.rand(1) > 0.5):
+            continue
+        hit += 1
+        pyr = (np.random.rand(3) - 0.5) * 20
+        w, tn, qn = P.rotate_cam_given(ds.load_image(2), ds.load_location(2), ds.load_quaternion(2), ds.camera.K, pyr)
+        r1, r2 = P.encode_as_keypoints(qn, tn)
+        assert np.array_equal(img, w) and np.allclose(loc, tn, atol=1e-12)
+        assert np.asarray(k1).shape == (1, 3) and np.allclose(k1, r1.T, atol=1e-12) and np.allclose(k2, r2.T, atol=1e-12)
+    assert hit >= 2

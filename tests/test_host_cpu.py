@@ -202,6 +202,13 @@ def test_augment_host_math_matches_reference_goldens():
         tn, qn = A.rotate_pose(t, g["qs2"][i], R)
         assert np.allclose(tn, t @ g["e2R"][i].T) and abs(np.linalg.norm(tn) - np.linalg.norm(t)) < 1e-12
         assert np.allclose(qn, P.quat_mult(P.SO32quat(R), g["qs2"][i]), atol=1e-15)
+        assert np.array_equal(A.quat2SO3(g["qs"][i]), g["q2R"][i])            # the reference's own quat2SO3 outputs
+        k1, k2 = A.encode_as_keypoints(g["qs"][i], t)
+        r1, r2 = P.encode_as_keypoints(g["qs"][i], t)
+        assert k1.shape == (3, 1) and np.allclose(k1, r1, atol=1e-15) and np.allclose(k2, r2, atol=1e-15)
+        assert np.allclose(k1[:, 0] - t, g["q2R"][i][:, 2]) and np.allclose(k2[:, 0] - t, g["q2R"][i][:, 1])
+    K1, K2 = A.encode_as_keypoints(g["qs"][:5], np.tile(np.array([0.3, -0.2, 7.0]), (5, 1)))
+    assert K1.shape == (5, 3) and K1.dtype == np.float32 and np.allclose(K2[2] - [0.3, -0.2, 7.0], g["q2R"][2][:, 1], atol=1e-6)
     cam = Camera()                                                           # urso.py:12-22
     assert abs(cam.fx - 640.0) < 1e-9 and cam.fy < 0 and np.allclose(cam.K[:2, 2], [640, 480])
     M = A.rotation_homography(cam.K, np.eye(3))

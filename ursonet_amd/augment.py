@@ -58,6 +58,29 @@ def quat_mult(a, b):
     return res / np.linalg.norm(res)
 
 
+def quat2SO3(q):
+    """se3lib.py:134-144: [x, y, z, w] -> rotation matrix."""
+    x, y, z, w = (float(v) for v in q)
+    return np.array([[1 - 2 * y * y - 2 * z * z, 2 * (x * y + z * w), 2 * (x * z - y * w)],
+                     [2 * (x * y - z * w), 1 - 2 * x * x - 2 * z * z, 2 * (y * z + x * w)],
+                     [2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * x * x - 2 * y * y]])
+
+
+def encode_as_keypoints(oris, centroids, scale=1.0):
+    """utils.py:220-244: a pose as two virtual 3-D keypoints on the body z and y axes.  One pose -> two 3x1 columns (the caller
+    transposes them, net.py:456); a batch [N,4], [N,3] -> two float32 [N,3] arrays."""
+    if np.ndim(oris) == 1:
+        R = quat2SO3(oris)
+        c = np.asarray(centroids, dtype=np.float64).reshape(3, 1)
+        return R @ (scale * np.array([[0.0], [0.0], [1.0]])) + c, R @ (scale * np.array([[0.0], [1.0], [0.0]])) + c
+    oris, centroids = np.asarray(oris), np.asarray(centroids)
+    K1 = np.zeros((len(oris), 3), dtype=np.float32); K2 = np.zeros((len(oris), 3), dtype=np.float32)
+    for i in range(len(oris)):
+        k1, k2 = encode_as_keypoints(oris[i], centroids[i], scale)
+        K1[i], K2[i] = k1[:, 0], k2[:, 0]
+    return K1, K2
+
+
 def rotation_homography(K, R_change):
     K = np.asarray(K, dtype=np.float64)
     return K @ np.asarray(R_change, dtype=np.float64) @ np.linalg.inv(K)

@@ -120,19 +120,19 @@ def load_image_gt(dataset, config, image_id):
         # the target re-encode run on the GPU (ursonet_amd.augment), same NumPy global-RNG draws as the reference
         assert config.REGRESS_LOC
         assert config.ORIENTATION_PARAM == 'quaternion'
-        if config.REGRESS_KEYPOINTS:
-            raise NotImplementedError("rotation augmentation with REGRESS_KEYPOINTS (utils.encode_as_keypoints) is not implemented")
         from . import augment
         dice = np.random.rand(1)
         which = "cam" if (config.ROT_AUG and dice > 0.5) else ("image" if (config.ROT_IMAGE_AUG and dice <= 0.5) else None)
         if which is not None:
-            if not config.REGRESS_ORI:
+            if not (config.REGRESS_ORI or config.REGRESS_KEYPOINTS):
                 ori = dataset.load_quaternion(image_id)
             if which == "cam":
                 image, loc, ori = augment.rotate_cam(image, loc, ori, dataset.camera.K, 20)
             else:
                 image, loc, ori = augment.rotate_image(image, loc, ori, dataset.camera.K)
-            if not config.REGRESS_ORI:
+            if config.REGRESS_KEYPOINTS:
+                k1, k2 = augment.encode_as_keypoints(ori, loc)          # net.py:424, 433: keypoints follow the rotated pose
+            elif not config.REGRESS_ORI:
                 ori = augment.encode_orientations(ori, dataset.ori_histogram_map, dataset.ori_output_mask, config.BETA)[0].cpu().numpy()
     original_shape = image.shape
     image, window, scale, padding, crop = utils.resize_image(

@@ -8,6 +8,12 @@ from .pose import (encode_loc, encode_ori, encode_ori_fast, euler2quat, stable_s
                    OrientationCodec, decode_orientations, pose_errors)
 
 
+def encode_as_keypoints(oris, centroids, scale=1.0):
+    """Drop-in for utils.encode_as_keypoints (utils.py:220-244)."""
+    from .augment import encode_as_keypoints as f
+    return f(oris, centroids, scale)
+
+
 def clr_triangular(iteration, base_lr, max_lr, step_size):
     """CyclicLR(mode='triangular').clr() (clr_callback.py:104-111) at `iteration` batches since start;
     iteration 0 -> base_lr (on_train_begin, clr_callback.py:116-117)."""
