@@ -40,7 +40,10 @@ template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_
 // MASKK: 0 none, 1 mask_d is a tensor like dst (keep where > 0), 2 mask_d is a ReLU BIT mask (1 byte per 16-byte vector of dst);
 // EMIT: also write such a bit mask of (stored dst > 0) to bits_out (include/ursonet_hip.h, urso_conv_igemm_ex).
 template <typename T, int BN, bool HAS_ADD, int MASKK, int CONV, bool EMIT = false>   // CONV: 0 pointwise, 1 whole-tap conv (<= 3x3), 2 stem (one tap per 16-byte chunk)
-__global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs a) {
+#ifndef URSO_PW_OCC
+#define URSO_PW_OCC 2
+#endif
+__global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(const PwArgs a) {
     constexpr bool HAS_MASK = MASKK == 1;
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = 128, VE = 8;

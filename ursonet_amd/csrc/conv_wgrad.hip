@@ -678,7 +678,10 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     p.M = g->B * g->OH * g->OW;
     static int narrow_ok = -1;
     if (narrow_ok < 0) { const char* e = getenv("URSO_WGRAD_NARROW"); narrow_ok = e ? atoi(e) : 1; }
-    p.narrow = (es == 2 && narrow_ok && g->N <= 64) ? 1 : 0;      // 16-bit layers with <= 64 filters: 128 x 64 tiles (wgrad_tr64_kernel)
+#ifndef URSO_WGRAD_NARROW_MULTITAP
+#define URSO_WGRAD_NARROW_MULTITAP 0                  // experiment: narrow tiles for every multi-tap filter, whatever N
+#endif
+    p.narrow = (es == 2 && narrow_ok && (g->N <= 64 || (URSO_WGRAD_NARROW_MULTITAP && g->KH * g->KW > 1))) ? 1 : 0;      // 16-bit layers with <= 64 filters: 128 x 64 tiles (wgrad_tr64_kernel)
     p.ktiles = ceil_div(p.K, 128); p.ntiles = ceil_div(g->N, p.narrow ? 64 : 128);
     const int tiles = p.ktiles * p.ntiles;
     const int steps = ceil_div(p.M, p.RM);
@@ -686,7 +689,10 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     // every extra split costs a K*N fp32 partial written and re-read, so do not over-split
     static int target = 0;
     if (!target) { const char* e = getenv("URSO_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
-    int splits = target / tiles;                       // never more blocks than resident slots: no second wave
+#ifndef URSO_WGRAD_NARROW_PCT
+#define URSO_WGRAD_NARROW_PCT 150                     // narrow tiles use 48 KiB of LDS: 3 blocks fit a CU, so they get 1.5x the block target (+1 % on the step)
+#endif
+    int splits = (p.narrow ? target * URSO_WGRAD_NARROW_PCT / 100 : target) / tiles;     // never more blocks than resident slots: no second wave
     splits = splits < 1 ? 1 : splits;
     int max_splits = steps / 8; if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
