@@ -363,12 +363,15 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu;
     a.H = g->H; a.W = g->W; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
     const int N = g->N;
+    // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU.  Policy 5 (default, measured inside one gpurun call):
+    // N <= 64, every filter with more than one tap (MFMA-bound: +0.7 % on the step) and the pointwise layers of stages 4-5
+    // that have no residual operand (M <= 65536: neither HBM- nor MFMA-bound, latency-limited -- +0.5 %); the big HBM-bound
+    // pointwise layers keep the wide tile (narrow = more re-reads of the pixel tile: -4 %).
+    // URSO_PW_SMALL = 0 / 1 / 2 / 3 select never / always / short-K only / multi-tap only.
     static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 3; }
-    // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU.  Policy 3 (default, measured): N <= 64 and every
-    // filter with more than one tap (MFMA-bound: +0.7 % on the step); pointwise layers keep the wide tile (narrow = more
-    // re-reads of the pixel tile: -4 %).  URSO_PW_SMALL = 0 / 1 / 2 select never / always / short-K only.
-    const bool small = N <= 64 || (force_small == 1) || (force_small == 2 && a.nkt <= 4) || (force_small == 3 && g->KH * g->KW > 1);
+    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 5; }
+    const bool small = N <= 64 || (force_small == 1) || (force_small == 2 && a.nkt <= 4) || (force_small >= 3 && g->KH * g->KW > 1) ||
+                       (force_small == 5 && a.M <= 65536 && !add);
     const int bn = small ? 64 : 128;
     a.tilesN = ceil_div(N, bn); a.ntiles = ceil_div(a.M, 128) * a.tilesN;
     int bpx = ceil_div(a.ntiles, 8);
