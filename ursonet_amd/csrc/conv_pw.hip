@@ -27,9 +27,15 @@ struct PwArgs {
 };
 
 __device__ __forceinline__ void pw_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+#if defined(URSO_DMA_KEEP_M0)
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+#else
+    // m0 is not saved: nothing else in these kernels uses it (DS instructions need no m0 on gfx9+), and hipcc itself sets it
+    // afresh before every LDS-DMA it emits
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+#endif
 }
 __device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
     const uint64_t a = (uint64_t)p;
