@@ -552,7 +552,7 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         if (fits && !wants_bits && use_pw >= 3 && stem_ok)
             return urso_pw_launch(g, dt, 2, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, 0, nullptr, st);
-        if (fits && ((use_pw >= 1 && a.pointwise) || (use_pw >= 2 && taps_ok && !wants_bits)))
+        if (fits && ((use_pw >= 1 && a.pointwise && (a.Cc & 7) == 0) || (use_pw >= 2 && taps_ok && !wants_bits)))
             return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, mbits, bout, st);
     }

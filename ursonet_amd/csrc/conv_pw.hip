@@ -154,16 +154,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
         } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
+                // no select: Cc % 8 == 0 (host-checked) so a K-tile has no tail, and a row m >= M lies beyond the descriptor's
+                // num_records (= M*C*2 bytes), i.e. it is zero-filled by the hardware
                 const int m = m0 + r0 + 32 * i, kc = kt * 8 + chA[i];
-                const uint32_t off = (uint32_t)m * (uint32_t)a.C * 2u + (uint32_t)kc * 16u;
-                pw_dma16(rs, la + i * 32 * 128, (m < a.M && kc < a.Cc) ? off : URSO_OOB_SHIFT);
+                pw_dma16(rs, la + i * 32 * 128, (uint32_t)m * (uint32_t)a.C * 2u + (uint32_t)kc * 16u);
             }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int n = n0 + nrow[i], kc = kt * 8 + chB[i];
             const uint32_t off = ((uint32_t)n * (uint32_t)a.Kc + (uint32_t)kc) * 16u;
-            pw_dma16(rw, lb_ + i * 32 * 128, (n < a.N && kc < a.Kc) ? off : URSO_OOB_SHIFT);
+            if constexpr (CONV == 2) pw_dma16(rw, lb_ + i * 32 * 128, (n < a.N && kc < a.Kc) ? off : URSO_OOB_SHIFT);   // the stem's K = 28 chunks has a tail
+            else pw_dma16(rw, lb_ + i * 32 * 128, off);               // Kc % 8 == 0; a filter row n >= N lies beyond num_records
         }
     };
 
