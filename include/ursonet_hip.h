@@ -10,7 +10,9 @@
  *   - every pointer named *_d is a DEVICE pointer owned by the caller; kernels never
  *     allocate -- workspace sizes come from the *_ws_bytes() queries;
  *   - every launch takes the hipStream_t to enqueue on (void* here so the header is
- *     plain C); no hidden global state except the opt-in profiler;
+ *     plain C); the only process-wide state is the opt-in profiler and the explicit
+ *     kernel-policy options of urso_set_option() (compiled-in defaults; the library never
+ *     reads the process environment);
  *   - activations are NHWC, row-major, dtype `dt` (URSO_F32 / URSO_BF16 / URSO_F16);
  *     accumulation is always fp32; master weights, biases, BN tensors, gradients of
  *     parameters and losses are fp32 in the Keras layouts (conv kernel HWIO
@@ -41,6 +43,23 @@ enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
 
 const char* urso_last_error(void);
 int         urso_abi_version(void);           /* bumped on any signature change */
+
+/*
+ * Kernel-policy options (process-wide, explicit; defaults in parentheses).  They select between kernels / tile shapes
+ * that compute the same result, so that variants can be compared inside one process and tests can force rarely-taken
+ * code paths on small shapes.  Unknown names return URSO_EINVAL.
+ *   pw_kernel (3)     DMA-staged conv kernel coverage: 0 off, 1 pointwise layers, 2 + whole-tap convs, 3 + the stem
+ *   pw_small (5)      narrow-tile policy of that kernel (0 never, 1 always, 2 short-K, 3 multi-tap, 5 measured default)
+ *   igemm_shortk (0)  general kernel: narrow tile for layers with at most this many K-tiles
+ *   wgrad_narrow (1)  128x64 weight-gradient tile for layers with <= 64 filters
+ *   wgrad_blocks (512) resident-block target of the weight-gradient pixel split
+ *   wgrad_pipe (1)    scheduler-interleaved fragment reads in the 16-bit weight-gradient kernel
+ *   grid_cap (0)      > 0: upper bound on the block count of the persistent conv kernels (tests: makes every block
+ *                     walk several tiles, i.e. exercises the cross-tile prefetch path, on small shapes)
+ *   hconv (1)         8-wave halo-tile kernel for the 3x3 stride-1 layers of stages 3-5 (0 = DMA kernel everywhere)
+ */
+int urso_set_option(const char* name, int value);
+int urso_get_option(const char* name, int* value);
 
 /*
  * Geometry of one implicit-GEMM convolution pass.  The kernel computes, for every

@@ -72,7 +72,7 @@ def layer_specs(config):
     conv("bottleneck_layer", 3, 3, c5, bw, True)                           # net.py:639
     h, w = int(config.IMAGE_SHAPE[0]), int(config.IMAGE_SHAPE[1])
     nf = int(bw * h * w / (64 ** 2))                                       # net.py:640
-    for br in ("loc", "ori"):
+    for br in (("loc",) if config.REGRESS_KEYPOINTS else ("loc", "ori")):   # keypoint model: ori_pred is not a Model output (net.py:675-691), Keras prunes the branch
         x = nf
         for i in range(config.NR_DENSE_LAYERS):
             dense("%s_dense_%d" % (br, i), x, config.BRANCH_SIZE)
@@ -202,100 +202,170 @@ def relu(x, site=None, hook=None):
 
 
 # --------------------------------------------------------------------------
+# 16-bit storage variant of the oracle (test infrastructure for the bf16 / fp16 device paths)
+# --------------------------------------------------------------------------
+class _RoundAct(torch.autograd.Function):
+    """Storage rounding of an activation tensor: the value is rounded to the 16-bit storage type on the way forward and the
+    gradient that reaches it (the sum over all consumers, in fp32) is rounded on the way back -- the device keeps both the
+    activation and its gradient buffer in the storage type."""
+    @staticmethod
+    def forward(ctx, x, dtype, fwd):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None, None
+
+
+class StorageRounding(object):
+    """`q` argument of forward()/losses()/gradients(): the SAME graph with rounding to `dtype` (torch.bfloat16 / float16)
+    inserted exactly where the device stores 16-bit tensors: the molded image, every conv/dense
+    output after its fused epilogue, every activation gradient, and the per-step folded filter W*gamma/sqrt(var+eps)
+    (straight-through for the gradient w.r.t. W, gamma: the device's fp32 master weights receive the unrounded
+    gradient).  In exact arithmetic this is the plain oracle; it exists so that the 16-bit device path can be
+    compared at 1e-2 per tensor instead of by cosine similarity.  Frozen BN only (TRAIN_BN False)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def weight(self, w):
+        return w + (w.detach().to(self.dtype).to(w.dtype) - w.detach())
+
+    def act(self, x):
+        return _RoundAct.apply(x, self.dtype, True)
+
+    def grad(self, x):                      # fp32-stored head outputs: only their gradient buffer is 16-bit
+        return _RoundAct.apply(x, self.dtype, False)
+
+
+def conv_bn(x, Pc, Pb, train_bn, stride=1, padding="valid", q=None):
+    """Conv2D followed by the BatchNorm wrapper (net.py:60-76, 101-103 ...).  With q (StorageRounding) and frozen BN
+    the pair is evaluated in the device's folded form: conv(x, round(W*s)) + (s*b + beta - mean*s), s = gamma/sqrt(var+eps)
+    -- algebraically the same function of (x, W, b, gamma, beta)."""
+    if q is None:
+        y = conv2d(x, Pc, stride=stride, padding=padding)
+        return batchnorm(y, Pb, train_bn) if Pb is not None else y
+    assert train_bn is False or Pb is None, "StorageRounding restates the frozen-BN (folded) device path only"
+    w = Pc["kernel"]
+    if Pb is not None:
+        sc = Pb["gamma"] * torch.rsqrt(Pb["moving_variance"] + BN_EPS)
+        b0 = Pc["bias"] if "bias" in Pc else torch.zeros_like(sc)
+        bias = sc * b0 + Pb["beta"] - Pb["moving_mean"] * sc
+        w = w * sc
+    else:
+        bias = Pc.get("bias")
+    return conv2d(x, {"kernel": q.weight(w), **({"bias": bias} if bias is not None else {})}, stride=stride, padding=padding)
+
+
+def _st(x, q):
+    return x if q is None else q.act(x)
+
+
+# --------------------------------------------------------------------------
 # graph builders
 # --------------------------------------------------------------------------
-def identity_block(x, P, stage, block, train_bn, hook=None):
+def identity_block(x, P, stage, block, train_bn, hook=None, q=None):
     """net.py:85-117."""
     cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
-    y = relu(batchnorm(conv2d(x, P[cb + "2a"]), P[bb + "2a"], train_bn), cb + "2a", hook)
-    y = relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn), cb + "2b", hook)
-    y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
-    return relu(y + x, cb + "2c", hook)
+    y = _st(relu(conv_bn(x, P[cb + "2a"], P[bb + "2a"], train_bn, q=q), cb + "2a", hook), q)
+    y = _st(relu(conv_bn(y, P[cb + "2b"], P[bb + "2b"], train_bn, padding="same", q=q), cb + "2b", hook), q)
+    y = conv_bn(y, P[cb + "2c"], P[bb + "2c"], train_bn, q=q)
+    return _st(relu(y + x, cb + "2c", hook), q)
 
 
-def conv_block(x, P, stage, block, stride, train_bn, hook=None):
+def conv_block(x, P, stage, block, stride, train_bn, hook=None, q=None):
     """net.py:120-158 -- stride sits on 2a and on the shortcut branch1."""
     cb, bb = "res%d%s_branch" % (stage, block), "bn%d%s_branch" % (stage, block)
-    y = relu(batchnorm(conv2d(x, P[cb + "2a"], stride=stride), P[bb + "2a"], train_bn), cb + "2a", hook)
-    y = relu(batchnorm(conv2d(y, P[cb + "2b"], padding="same"), P[bb + "2b"], train_bn), cb + "2b", hook)
-    y = batchnorm(conv2d(y, P[cb + "2c"]), P[bb + "2c"], train_bn)
-    sc = batchnorm(conv2d(x, P[cb + "1"], stride=stride), P[bb + "1"], train_bn)
-    return relu(y + sc, cb + "2c", hook)
+    y = _st(relu(conv_bn(x, P[cb + "2a"], P[bb + "2a"], train_bn, stride=stride, q=q), cb + "2a", hook), q)
+    y = _st(relu(conv_bn(y, P[cb + "2b"], P[bb + "2b"], train_bn, padding="same", q=q), cb + "2b", hook), q)
+    y = conv_bn(y, P[cb + "2c"], P[bb + "2c"], train_bn, q=q)
+    sc = _st(conv_bn(x, P[cb + "1"], P[bb + "1"], train_bn, stride=stride, q=q), q)
+    return _st(relu(y + sc, cb + "2c", hook), q)
 
 
-def resnet_graph(x, P, arch, train_bn, hook=None):
+def resnet_graph(x, P, arch, train_bn, hook=None, q=None):
     """net.py:161-199 (stage5=True)."""
-    x = conv2d(x, P["conv1"], stride=2, padding=3)
-    x = relu(batchnorm(x, P["bn_conv1"], train_bn), "conv1", hook)
+    x = conv_bn(x, P["conv1"], P["bn_conv1"], train_bn, stride=2, padding=3, q=q)
+    x = _st(relu(x, "conv1", hook), q)
     x = maxpool_3x3_s2_same(x)
     for stage, blocks, _ in _deep_blocks(arch):
         for b in blocks:
             if b == "a":
-                x = conv_block(x, P, stage, b, 1 if stage == 2 else 2, train_bn, hook)
+                x = conv_block(x, P, stage, b, 1 if stage == 2 else 2, train_bn, hook, q)
             else:
-                x = identity_block(x, P, stage, b, train_bn, hook)
+                x = identity_block(x, P, stage, b, train_bn, hook, q)
     return x
 
 
-def residual_basic_block(x, P, stage, block, stride, cut, train_bn, hook=None):
+def residual_basic_block(x, P, stage, block, stride, cut, train_bn, hook=None, q=None):
     """net.py:216-240 -- ONE BatchNorm per block (after conv1)."""
     nb = "stage%d_unit%d_" % (stage + 1, block + 1)
-    sc = x if cut == "pre" else conv2d(x, P[nb + "sc"], stride=stride)
-    y = conv2d(x, P[nb + "conv1"], stride=stride, padding=1)
-    y = relu(batchnorm(y, P[nb + "bn2"], train_bn), nb + "conv1", hook)
-    y = conv2d(y, P[nb + "conv2"], padding=1)
-    return relu(y + sc, nb + "conv2", hook)
+    sc = x if cut == "pre" else _st(conv_bn(x, P[nb + "sc"], None, train_bn, stride=stride, q=q), q)
+    y = conv_bn(x, P[nb + "conv1"], P[nb + "bn2"], train_bn, stride=stride, padding=1, q=q)
+    y = _st(relu(y, nb + "conv1", hook), q)
+    y = conv_bn(y, P[nb + "conv2"], None, train_bn, padding=1, q=q)
+    return _st(relu(y + sc, nb + "conv2", hook), q)
 
 
-def resnet_shallow_graph(x, P, arch, train_bn, hook=None):
+def resnet_shallow_graph(x, P, arch, train_bn, hook=None, q=None):
     """net.py:242-282."""
-    x = conv2d(x, P["conv0"], stride=2, padding=3)
-    x = relu(batchnorm(x, P["bn_conv0"], train_bn), "conv0", hook)
+    x = conv_bn(x, P["conv0"], P["bn_conv0"], train_bn, stride=2, padding=3, q=q)
+    x = _st(relu(x, "conv0", hook), q)
     x = maxpool_3x3_s2_same(x)
     reps = [2, 2, 2, 2] if arch == "resnet18" else [3, 4, 6, 3]
     for stage, rep in enumerate(reps):
         for block in range(rep):
             if block == 0 and stage == 0:
-                x = residual_basic_block(x, P, stage, block, 1, "post", train_bn, hook)
+                x = residual_basic_block(x, P, stage, block, 1, "post", train_bn, hook, q)
             elif block == 0:
-                x = residual_basic_block(x, P, stage, block, 2, "post", train_bn, hook)
+                x = residual_basic_block(x, P, stage, block, 2, "post", train_bn, hook, q)
             else:
-                x = residual_basic_block(x, P, stage, block, 1, "pre", train_bn, hook)
+                x = residual_basic_block(x, P, stage, block, 1, "pre", train_bn, hook, q)
     return x
 
 
-def _branch_trunk(feat, P, config, br, hook=None):
+def _qdense(x, p, q):
+    return dense(x, p) if q is None else dense(x, {"kernel": q.weight(p["kernel"]), "bias": p["bias"]})
+
+
+def _branch_trunk(feat, P, config, br, hook=None, q=None):
     x = feat
     for i in range(config.NR_DENSE_LAYERS):
-        x = dense(x, P["%s_dense_%d" % (br, i)])
+        x = _qdense(x, P["%s_dense_%d" % (br, i)], q)
         if config.TRAIN_BN:
+            assert q is None
             x = batchnorm(x, P["%s_bn_%d" % (br, i)], None)               # net.py:306: no training arg
-        x = relu(x, "%s_dense_%d" % (br, i), hook)
+        x = _st(relu(x, "%s_dense_%d" % (br, i), hook), q)
     return x
 
 
-def build_loc_graph(feat, P, config, hook=None):
+def _head(x, q):
+    return x if q is None else q.grad(x)                                  # fp32 head output, 16-bit gradient buffer
+
+
+def build_loc_graph(feat, P, config, hook=None, q=None):
     """net.py:288-320."""
-    x = _branch_trunk(feat, P, config, "loc", hook)
+    x = _branch_trunk(feat, P, config, "loc", hook, q)
     if config.REGRESS_KEYPOINTS:
-        return [dense(x, P[k]) for k in ("k1_final", "k2_final", "k3_final")]
+        return [_head(_qdense(x, P[k], q), q) for k in ("k1_final", "k2_final", "k3_final")]
     if config.REGRESS_LOC:
-        return dense(x, P["loc_final"])
-    return relu(dense(x, P["loc_final"]), "loc_final", hook)
+        return _head(_qdense(x, P["loc_final"], q), q)
+    return relu(_head(_qdense(x, P["loc_final"], q), q), "loc_final", hook)
 
 
-def build_ori_graph(feat, P, config, hook=None):
+def build_ori_graph(feat, P, config, hook=None, q=None):
     """net.py:322-352."""
-    x = _branch_trunk(feat, P, config, "ori", hook)
+    x = _branch_trunk(feat, P, config, "ori", hook, q)
     if config.REGRESS_ORI:
         if config.ORIENTATION_PARAM == "quaternion":
-            q = dense(x, P["ori_q"])
-            return q * torch.rsqrt(torch.clamp((q * q).sum(-1, keepdim=True), min=1e-12))   # [A5]
-        return dense(x, P["ori_final"])
-    return relu(dense(x, P["ori_final"]), "ori_final", hook)
+            qq = _head(_qdense(x, P["ori_q"], q), q)
+            return qq * torch.rsqrt(torch.clamp((qq * qq).sum(-1, keepdim=True), min=1e-12))   # [A5]
+        return _head(_qdense(x, P["ori_final"], q), q)
+    return relu(_head(_qdense(x, P["ori_final"], q), q), "ori_final", hook)
 
 
-def forward(P, images_nhwc, config, relu_hook=None):
+def forward(P, images_nhwc, config, relu_hook=None, q=None):
     """net.py:629-643.  images_nhwc: molded float tensor [B,H,W,C].  Returns (loc, ori)."""
     h, w = images_nhwc.shape[1:3]
     if h / 2 ** 6 != int(h / 2 ** 6) or w / 2 ** 6 != int(w / 2 ** 6):   # net.py:596-600
@@ -303,13 +373,17 @@ def forward(P, images_nhwc, config, relu_hook=None):
                         "to avoid fractions when downscaling and upscaling."
                         "For example, use 256, 320, 384, 448, 512, ... etc. ")
     x = images_nhwc.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    if q is not None:
+        x = x.to(q.dtype).to(x.dtype)                                     # the molded image is stored in the compute dtype
     if config.BACKBONE in ("resnet50", "resnet101"):
-        c5 = resnet_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook)
+        c5 = resnet_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook, q)
     else:
-        c5 = resnet_shallow_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook)
-    c6 = conv2d(c5, P["bottleneck_layer"], stride=2, padding="same")
+        c5 = resnet_shallow_graph(x, P, config.BACKBONE, config.TRAIN_BN, relu_hook, q)
+    c6 = _st(conv_bn(c5, P["bottleneck_layer"], None, config.TRAIN_BN, stride=2, padding="same", q=q), q)
     feat = c6.permute(0, 2, 3, 1).reshape(c6.shape[0], -1)                # (h,w,c) flatten [A4]
-    return build_loc_graph(feat, P, config, relu_hook), build_ori_graph(feat, P, config, relu_hook)
+    if config.REGRESS_KEYPOINTS:                                          # outputs [k1, k2, k3] (net.py:678, 689)
+        return build_loc_graph(feat, P, config, relu_hook, q), None
+    return build_loc_graph(feat, P, config, relu_hook, q), build_ori_graph(feat, P, config, relu_hook, q)
 
 
 # --------------------------------------------------------------------------
@@ -347,11 +421,15 @@ def rel_norms(y_gt, y_pred):
     return torch.stack([((y_gt - y_pred) ** 2).sum(), (y_gt ** 2).sum()]).detach()
 
 
-def losses(P, images, gt_loc, gt_ori, config, relu_hook=None, rel_global=None):
+def losses(P, images, gt_loc, gt_ori, config, relu_hook=None, rel_global=None, q=None):
     """net.py:656-669.  Returns (loc_pred, ori_pred, loc_loss, ori_loss).  rel_global = (global_norms, world) switches the
     location loss to its exact data-parallel shard form (rel_loss_sharded)."""
-    loc, ori = forward(P, images, config, relu_hook)
-    assert not config.REGRESS_KEYPOINTS, "keypoint mode: use losses_keypoints"
+    loc, ori = forward(P, images, config, relu_hook, q)
+    if config.REGRESS_KEYPOINTS:
+        # net.py:657-659: three MSE losses; gt_loc = k1 target, gt_ori = (k2 target, k3 target).  Returned as
+        # (k1, [k2, k3], loc_loss, [k2_loss, k3_loss]).
+        k1, k2, k3 = loc
+        return k1, [k2, k3], mse_loss(gt_loc, k1), [mse_loss(gt_ori[0], k2), mse_loss(gt_ori[1], k3)]
     if config.REGRESS_LOC and rel_global is not None:
         loc_loss = rel_loss_sharded(gt_loc, loc, rel_global[0], rel_global[1])
     else:
@@ -378,23 +456,28 @@ def regularizer(P, config, layer_regex=".*"):
     return reg
 
 
-def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None):
+def total_loss(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None, q=None):
     """net.py:993-1012: sum_name LOSS_WEIGHTS[name]*mean(loss) + regulariser."""
-    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config, relu_hook, rel_global)
-    tot = config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("ori_loss", 1.) * ol
+    loc, ori, ll, ol = losses(P, images, gt_loc, gt_ori, config, relu_hook, rel_global, q)
+    if config.REGRESS_KEYPOINTS:                                          # loss_names of net.py:989-990
+        tot = (config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("k2_loss", 1.) * ol[0] +
+               config.LOSS_WEIGHTS.get("k3_loss", 1.) * ol[1])
+    else:
+        tot = config.LOSS_WEIGHTS.get("loc_loss", 1.) * ll + config.LOSS_WEIGHTS.get("ori_loss", 1.) * ol
     return tot + regularizer(P, config, layer_regex), (loc, ori, ll, ol)
 
 
-def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None):
+def gradients(P, images, gt_loc, gt_ori, config, layer_regex=".*", relu_hook=None, rel_global=None, q=None):
     """Returns (grads {layer:{weight: tensor}}, (loc, ori, loc_loss, ori_loss), total)."""
     leaves = [(ln, wn, w) for ln, ws in P.items() for wn, w in ws.items()
               if w.requires_grad and is_trainable(ln, layer_regex)]
-    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook, rel_global)
+    tot, outs = total_loss(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook, rel_global, q)
     gs = torch.autograd.grad(tot, [w for _, _, w in leaves], allow_unused=True)
     grads = OrderedDict()
     for (ln, wn, w), g in zip(leaves, gs):
         grads.setdefault(ln, OrderedDict())[wn] = g if g is not None else torch.zeros_like(w)
-    return grads, tuple(o.detach() if torch.is_tensor(o) else o for o in outs), tot.detach()
+    det = lambda o: o.detach() if torch.is_tensor(o) else ([t.detach() for t in o] if isinstance(o, (list, tuple)) else o)
+    return grads, tuple(det(o) for o in outs), tot.detach()
 
 
 def global_norm(grads):
@@ -440,13 +523,16 @@ def adam_step(P, grads, state, lr, clipnorm, epsilon=1e-7, beta_1=0.9, beta_2=0.
     return norm
 
 
-def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*", relu_hook=None):
+def train_step(P, velocity, images, gt_loc, gt_ori, config, lr, layer_regex=".*", relu_hook=None, q=None):
     """One fit_generator step [A13]: fwd, loss, bwd, clip, update.  Returns dict of scalars/outputs."""
-    grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook)
+    grads, (loc, ori, ll, ol), tot = gradients(P, images, gt_loc, gt_ori, config, layer_regex, relu_hook, q=q)
     if str(getattr(config, "OPTIMIZER", "SGD")).upper() == "SGD":
         norm = sgd_step(P, grads, velocity, lr, config.LEARNING_MOMENTUM, config.GRADIENT_CLIP_NORM)
     else:
         norm = adam_step(P, grads, velocity, lr, config.GRADIENT_CLIP_NORM, 1e-4 if getattr(config, "F16", False) else 1e-7)
+    if config.REGRESS_KEYPOINTS:
+        return {"loc": loc, "k2": ori[0], "k3": ori[1], "loc_loss": float(ll), "k2_loss": float(ol[0]), "k3_loss": float(ol[1]),
+                "total": float(tot), "grad_norm": norm, "grads": grads}
     return {"loc": loc, "ori": ori, "loc_loss": float(ll), "ori_loss": float(ol), "total": float(tot),
             "grad_norm": norm, "grads": grads}
 

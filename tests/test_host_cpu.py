@@ -230,7 +230,24 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "symbol %s declared in include/ursonet_hip.h is not exported" % s
     assert set(syms) == set(hip.EXPORTED_SYMBOLS), set(syms) ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip._lib.urso_abi_version() == 3
+    assert hip._lib.urso_abi_version() == 4
+
+
+def test_policy_options_are_explicit_and_never_read_the_environment():
+    """urso_set_option / urso_get_option (include/ursonet_hip.h): compiled-in defaults, unknown names refused, and no getenv
+    anywhere in the C sources (VERDICT r1 weak #9)."""
+    import ursonet_amd.hip as hip
+    assert hip.get_option("pw_small") == 5 and hip.get_option("grid_cap") == 0 and hip.get_option("wgrad_blocks") == 512
+    with hip.options(grid_cap=24, pw_small=1):
+        assert hip.get_option("grid_cap") == 24 and hip.get_option("pw_small") == 1
+    assert hip.get_option("grid_cap") == 0 and hip.get_option("pw_small") == 5
+    with pytest.raises(hip.UrsoHipError):
+        hip.set_option("no_such_option", 1)
+    with pytest.raises(hip.UrsoHipError):
+        hip.set_option("wgrad_blocks", 0)
+    csrc = os.path.join(ROOT, "ursonet_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f), errors="replace").read(), f
 
 
 def test_cabi_argument_validation_without_gpu():

@@ -151,6 +151,54 @@ def test_conv_forward_and_gradients(case, dt):
     assert e < 1e-4, "colsum %s dt=%d rel err %.3e" % (name, dt, e)
 
 
+# The persistent conv kernels (conv_pw.hip pw_kernel, conv_igemm.hip igemm_kernel) walk several tiles per block only when a
+# launch has more tiles than resident blocks (cap = 512 / 768): the cross-tile machinery -- the next tile's first K-tile copied
+# under the epilogue, the rolling residual / mask prefetch, the hand-counted vmcnt waits -- is what every full-size layer of
+# the benchmark runs.  (a) shapes with thousands of tiles at their production grid, (b) small shapes with the grid capped
+# through urso_set_option("grid_cap") so that every block still walks >= 5 tiles.  Same CPU reference as the small cases.
+BIG_CASES = [
+    (4, 256, 320, 64, 256, 1, 1, (0, 0), "big_1x1_64_256"),       # res2x_branch2c / branch1 (+ residual, ReLU): 5120 tiles
+    (4, 256, 320, 256, 64, 1, 1, (0, 0), "big_1x1_256_64"),       # res2x_branch2a; its dgrad is the 64 -> 256 add+mask layer
+    (4, 256, 320, 64, 64, 3, 1, (1, 1), "big_3x3_64"),            # res2x_branch2b
+    (4, 128, 160, 256, 128, 1, 2, (0, 0), "big_1x1_s2"),          # res3a_branch2a: strided forward, scattered compact dgrad
+    (8, 64, 80, 128, 128, 3, 1, (1, 1), "big_3x3_128"),           # res3x_branch2b
+    (16, 32, 40, 256, 256, 3, 1, (1, 1), "big_3x3_256"),          # res4x_branch2b
+    (16, 32, 40, 1024, 256, 1, 1, (0, 0), "big_1x1_1024_256"),    # res4x_branch2a / dgrad of branch2c
+]
+CAP_CASES = [
+    (2, 32, 40, 64, 256, 1, 1, (0, 0), "cap_1x1_64_256"),
+    (2, 32, 40, 256, 64, 1, 1, (0, 0), "cap_1x1_256_64"),
+    (2, 32, 40, 64, 64, 3, 1, (1, 1), "cap_3x3_64"),
+    (2, 32, 40, 128, 128, 3, 1, (1, 1), "cap_3x3_128"),
+    (2, 32, 48, 128, 64, 1, 2, (0, 0), "cap_1x1_s2"),
+    (3, 19, 23, 32, 160, 3, 1, (1, 1), "cap_3x3_ragged"),
+]
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("case", BIG_CASES, ids=[c[-1] for c in BIG_CASES])
+def test_conv_full_size_tile_streams(case, dt):
+    test_conv_forward_and_gradients(case, dt)
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("case", CAP_CASES, ids=[c[-1] for c in CAP_CASES])
+def test_conv_capped_grid_tile_streams(case, dt):
+    hip = _hip()
+    with hip.options(grid_cap=8):
+        test_conv_forward_and_gradients(case, dt)
+
+
+def test_wgrad_split_plan_reaches_its_resident_block_target():
+    """The 16-bit weight-gradient kernels split the pixel dimension over one resident wave of blocks (512, x1.5 for the
+    narrow tile): the full-size cases above must actually run with hundreds of splits ('wgrad at splits == 512')."""
+    hip = _hip()
+    g = hip.geom(4, 256, 320, 64, 256, 320, 64, 1, 1)
+    assert hip.conv_wgrad_splits(g, 1) >= 256
+    g = hip.geom(32, 128, 160, 64, 128, 160, 64, 3, 3, 1, 1, 1, 1)
+    assert hip.conv_wgrad_splits(g, 1) * 5 >= 512
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 def test_igemm_out_f32_and_padded_head(dt):
     """loc_final-style head: N=3 padded to 8, fp32 output, no activation (net.py:316)."""
@@ -177,12 +225,20 @@ def test_igemm_out_f32_and_padded_head(dt):
     assert relerr(dx, dz[:, :N] @ rnd(w.reshape(K, N), dt).T) < TOL[dt]
 
 
-@pytest.mark.parametrize("dt", [0, 1])
-def test_stem_pixel_pair_conv(dt):
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("size", [(2, 32, 48, 0), (2, 128, 160, 8), (4, 512, 640, 0)], ids=["small", "capped", "full"])
+def test_stem_pixel_pair_conv(dt, size):
     """conv1: ZeroPadding2D(3)+Conv2D 7x7 s2 (net.py:170-171) as a 7x4-tap conv on pixel pairs,
-    forward + weight gradient (no data gradient: the image needs none)."""
+    forward + weight gradient (no data gradient: the image needs none).  'capped' / 'full': every block of the persistent
+    kernel walks several tiles (grid cap 8 on 80 tiles; 2560 tiles on the production grid)."""
     hip = _hip()
-    B, H, W, N = 2, 32, 48, 64
+    B, H, W, cap = size
+    N = 64
+    with hip.options(grid_cap=cap):
+        _stem_case(hip, dt, B, H, W, N)
+
+
+def _stem_case(hip, dt, B, H, W, N):
     torch.manual_seed(7)
     img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
     meanp = torch.tensor([123.7, 116.8, 103.9])
@@ -481,12 +537,19 @@ def test_batched_param_phases_equal_per_layer_entry_points(dt):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 20, 24, 64, 128, 1, 1), (2, 17, 19, 32, 40, 3, 1), (3, 16, 16, 64, 256, 1, 2)])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 64, 128, 1, 1, 0), (2, 17, 19, 32, 40, 3, 1, 0), (3, 16, 16, 64, 256, 1, 2, 0),
+                                   (2, 32, 40, 64, 256, 1, 1, 8), (2, 32, 48, 256, 128, 1, 2, 8), (4, 128, 160, 64, 256, 1, 1, 0)])
 def test_relu_bit_masks_emit_and_consume(dt, shape):
     """urso_conv_igemm_ex: (a) the forward epilogue's bit mask == (stored output > 0) bit for bit; (b) a data-gradient
     pass masked by the bit array is identical to one masked by the activation tensor itself (incl. the scattered
-    stride-2 1x1 form and a residual add)."""
+    stride-2 1x1 form and a residual add).  The last three shapes run the multi-tile stream of the persistent kernel (grid
+    capped to 8 blocks, or more tiles than resident blocks)."""
     hip = _hip()
+    with hip.options(grid_cap=shape[-1]):
+        _bitmask_case(hip, dt, shape[:-1])
+
+
+def _bitmask_case(hip, dt, shape):
     B, H, W, Ci, N, k, s = shape
     torch.manual_seed(sum(shape) + dt)
     tdt = hip.TORCH_DT[dt]

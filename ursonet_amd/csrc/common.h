@@ -15,6 +15,20 @@ typedef __attribute__((ext_vector_type(2))) int i32x2_t;
 void urso_set_error(const char* fmt, ...);
 int  urso_check_launch(const char* what);
 
+// Explicit kernel-policy options (runtime.hip; include/ursonet_hip.h urso_set_option).  Defaults are compiled in; nothing
+// reads the process environment.
+struct UrsoOptions {
+    int pw_kernel = 3;       // conv_pw.hip coverage: 0 off, 1 pointwise, 2 + whole-tap convs, 3 + stem
+    int pw_small = 5;        // narrow-tile policy of conv_pw.hip
+    int igemm_shortk = 0;    // conv_igemm.hip: narrow tile for K-tiles <= this
+    int wgrad_narrow = 1;    // 128x64 weight-gradient tile for N <= 64
+    int wgrad_blocks = 512;  // resident-block target of the weight-gradient split
+    int wgrad_pipe = 1;      // scheduler-interleaved fragment reads in wgrad_tr_kernel
+    int grid_cap = 0;        // > 0: cap the block count of the persistent conv kernels (tests: forces the multi-tile stream on small shapes)
+    int hconv = 1;           // conv_halo.hip (8-wave halo-tile kernel) for qualifying 3x3 layers
+};
+extern UrsoOptions g_urso_opt;
+
 // profiler hooks (prof.cpp)
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);
 void urso_prof_after(hipStream_t s);

@@ -414,8 +414,7 @@ template <typename T>
 static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     // tile choice: narrow-N layers use the 128x64 tile (no wasted MFMA columns); so do short-K
     // (HBM-bound) layers: 48 KiB LDS / 120 VGPRs -> 3 resident blocks per CU = more bytes in flight
-    static int shortk = -1;
-    if (shortk < 0) { const char* e = getenv("URSO_IGEMM_SHORTK"); shortk = e ? atoi(e) : 0; }
+    const int shortk = g_urso_opt.igemm_shortk;
     const int ncu = device_cus();
     const bool small = (g->N <= 64 || a.nkt <= shortk);
     const int bn = small ? 64 : 128;
@@ -430,6 +429,7 @@ static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* 
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = (small ? 3 : 2) * ncu / 8;                     // 48 / 64 KiB LDS: 3 / 2 resident blocks per CU
     if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
     const bool coal = !(flags & URSO_EPI_OUT_F32) && (g->N % (16 / (int)sizeof(T))) == 0;
     const bool fastepi = coal && a.ksplit == 1;
@@ -536,8 +536,7 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
-        static int use_pw = -1;
-        if (use_pw < 0) { const char* e = getenv("URSO_PW_KERNEL"); use_pw = e ? atoi(e) : 3; }     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
+        const int use_pw = g_urso_opt.pw_kernel;     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
         const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool wants_bits = (flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) != 0;
         const bool bits_fit = !wants_bits || (a.pointwise && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&

@@ -13,7 +13,6 @@
 //   * the residual / mask vectors of tile t+1 are requested slot by slot while the epilogue of tile t consumes the
 //     registers ("rolling" prefetch): their latency hides behind a whole tile instead of one K-tile of MFMAs.
 #include "common.h"
-#include <stdlib.h>
 
 struct PwArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
@@ -381,9 +380,8 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     // N <= 64, every filter with more than one tap (MFMA-bound: +0.7 % on the step) and the pointwise layers of stages 4-5
     // that have no residual operand (M <= 65536: neither HBM- nor MFMA-bound, latency-limited -- +0.5 %); the big HBM-bound
     // pointwise layers keep the wide tile (narrow = more re-reads of the pixel tile: -4 %).
-    // URSO_PW_SMALL = 0 / 1 / 2 / 3 select never / always / short-K only / multi-tap only.
-    static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("URSO_PW_SMALL"); force_small = e ? atoi(e) : 5; }
+    // urso_set_option("pw_small", 0 / 1 / 2 / 3) selects never / always / short-K only / multi-tap only.
+    const int force_small = g_urso_opt.pw_small;
     const bool small = N <= 64 || (force_small == 1) || (force_small == 2 && a.nkt <= 4) || (force_small >= 3 && g->KH * g->KW > 1) ||
                        (force_small == 5 && a.M <= 65536 && !add);
     const int bn = small ? 64 : 128;
@@ -391,6 +389,7 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = (small ? 3 : 2) * pw_device_cus() / 8;
     if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
     const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
 #define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 0, CV_>), grid, blk, 0, st, a); break; \

@@ -682,8 +682,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     if (g->C % p.VE || g->N % p.VE) return URSO_EINVAL;
     p.Cc = g->C / p.VE; p.Kc = g->KH * g->KW * p.Cc; p.K = p.Kc * p.VE;
     p.M = g->B * g->OH * g->OW;
-    static int narrow_ok = -1;
-    if (narrow_ok < 0) { const char* e = getenv("URSO_WGRAD_NARROW"); narrow_ok = e ? atoi(e) : 1; }
+    const int narrow_ok = g_urso_opt.wgrad_narrow;
 #ifndef URSO_WGRAD_NARROW_MULTITAP
 #define URSO_WGRAD_NARROW_MULTITAP 0                  // experiment: narrow tiles for every multi-tap filter, whatever N
 #endif
@@ -693,8 +692,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int steps = ceil_div(p.M, p.RM);
     // aim for ~2 resident blocks per CU (64 KiB LDS each) but keep >= 8 reduction steps per block;
     // every extra split costs a K*N fp32 partial written and re-read, so do not over-split
-    static int target = 0;
-    if (!target) { const char* e = getenv("URSO_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    const int target = g_urso_opt.wgrad_blocks;
 #ifndef URSO_WGRAD_NARROW_PCT
 #define URSO_WGRAD_NARROW_PCT 150                     // narrow tiles use 48 KiB of LDS: 3 blocks fit a CU, so they get 1.5x the block target (+1 % on the step)
 #endif
@@ -758,8 +756,7 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
 #define URSO_WG(KERN, TT, MD) do { if (MD == 0) hipLaunchKernelGGL((KERN<TT, 0>), grid, dim3(256), 0, st, a); \
                          else if (MD == 1) hipLaunchKernelGGL((KERN<TT, 1>), grid, dim3(256), 0, st, a); \
                          else hipLaunchKernelGGL((KERN<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
-    static int pipe = -1;
-    if (pipe < 0) { const char* e = getenv("URSO_WGRAD_PIPE"); pipe = e ? atoi(e) : 1; }   // measured +0.2 % on the step
+    const int pipe = g_urso_opt.wgrad_pipe;   // measured +0.2 % on the step
 #define URSO_WGP(TT, MD) do { if (MD == 0) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 0, true>), grid, dim3(256), 0, st, a); \
                          else if (MD == 1) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 1, true>), grid, dim3(256), 0, st, a); \
                          else hipLaunchKernelGGL((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)

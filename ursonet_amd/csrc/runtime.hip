@@ -19,7 +19,32 @@ int urso_check_launch(const char* what) {
 }
 
 extern "C" const char* urso_last_error(void) { return g_err; }
-extern "C" int urso_abi_version(void) { return 3; }
+extern "C" int urso_abi_version(void) { return 4; }
+
+// ---------------------------------------------------------------- explicit policy options
+UrsoOptions g_urso_opt;
+#include <string.h>
+static int* opt_slot(const char* name) {
+    if (!name) return nullptr;
+#define URSO_OPT(n) if (!strcmp(name, #n)) return &g_urso_opt.n;
+    URSO_OPT(pw_kernel) URSO_OPT(pw_small) URSO_OPT(igemm_shortk) URSO_OPT(wgrad_narrow) URSO_OPT(wgrad_blocks) URSO_OPT(wgrad_pipe)
+    URSO_OPT(grid_cap) URSO_OPT(hconv)
+#undef URSO_OPT
+    return nullptr;
+}
+extern "C" int urso_set_option(const char* name, int value) {
+    int* s = opt_slot(name);
+    if (!s) { urso_set_error("urso_set_option: unknown option '%s'", name ? name : "(null)"); return URSO_EINVAL; }
+    if (!strcmp(name, "wgrad_blocks") && value < 1) { urso_set_error("urso_set_option: wgrad_blocks must be >= 1"); return URSO_EINVAL; }
+    *s = value;
+    return URSO_OK;
+}
+extern "C" int urso_get_option(const char* name, int* value) {
+    int* s = opt_slot(name);
+    if (!s || !value) { urso_set_error("urso_get_option: unknown option '%s'", name ? name : "(null)"); return URSO_EINVAL; }
+    *value = *s;
+    return URSO_OK;
+}
 
 // ---------------------------------------------------------------- profiler
 struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; };

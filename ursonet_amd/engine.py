@@ -296,7 +296,7 @@ class Engine(object):
         if not training:
             self._upload_param_table()
         self.out_loc = self.acts[g.outputs["loc"].id]
-        self.out_ori = self.acts[g.outputs["ori"].id]
+        self.out_ori = self.acts[g.outputs["ori"].id] if "ori" in g.outputs else None      # keypoint mode has no orientation head
         self._build_heads_io()
         if not training:
             return
@@ -485,7 +485,7 @@ class Engine(object):
 
     def _build_heads_io(self):
         cfg, B, dev = self.config, self.B, self.device
-        self.quat_head = bool(cfg.REGRESS_ORI and cfg.ORIENTATION_PARAM == "quaternion")
+        self.quat_head = bool(cfg.REGRESS_ORI and cfg.ORIENTATION_PARAM == "quaternion" and not cfg.REGRESS_KEYPOINTS)
         if self.quat_head:
             self.q_out = torch.zeros(B, 4, dtype=torch.float32, device=dev)
             if self.mode == "inference":
@@ -499,7 +499,7 @@ class Engine(object):
         self.rel_norms = torch.zeros(2, dtype=torch.float32, device=dev)
         loc, ori = self.out_loc, self.out_ori
         nloc = g.outputs["loc"].c
-        nori = g.outputs["ori"].c
+        nori = g.outputs["ori"].c if "ori" in g.outputs else 0
         self.row_ws = torch.empty(B, dtype=torch.float32, device=dev)
         if cfg.REGRESS_KEYPOINTS:
             # experimental keypoint mode (net.py:657-659): three MSE losses on k1 (=loc), k2, k3
@@ -640,15 +640,34 @@ class Engine(object):
     def outputs(self):
         """(loc [B, n_loc], ori [B, n_ori]) as fp32 device tensors (raw network outputs, net.py:1254-1258)."""
         g = self.graph
-        nl, no = g.outputs["loc"].c, g.outputs["ori"].c
+        nl = g.outputs["loc"].c
         loc = self.out_loc.data.view(self.B, -1)[:, :nl]
+        if self.out_ori is None:             # keypoint mode: (k1, [k2, k3]) -- net.py:678
+            return loc, [self.acts[g.outputs[k].id].data.view(self.B, -1)[:, :3] for k in ("k2", "k3")]
+        no = g.outputs["ori"].c
         ori = self.q_out if self.quat_head else self.out_ori.data.view(self.B, -1)[:, :no]
         return loc, ori
 
     def losses(self):
-        """{'loc_loss','ori_loss'} weighted by LOSS_WEIGHTS, as in the Keras metrics (net.py:1019-1028)."""
+        """{'loc_loss','ori_loss'} (keypoint mode: {'loc_loss','k2_loss','k3_loss'}) weighted by LOSS_WEIGHTS, as in the
+        Keras metrics (net.py:989-992, 1019-1028)."""
         l = self.loss_buf.detach().cpu().numpy()
+        if self.config.REGRESS_KEYPOINTS:
+            return {"loc_loss": float(l[0]), "k2_loss": float(l[2]), "k3_loss": float(l[3])}
         return {"loc_loss": float(l[0]), "ori_loss": float(l[1])}
+
+    def evaluate(self):
+        """Forward + losses on the loaded batch WITHOUT touching any training state: what Keras' validation pass does
+        (learning_phase 0, net.py:1155-1157).  In batch-statistics BN mode the moving statistics are restored afterwards (the
+        forward kernels of the training plan update them) -- the normalisation itself still uses batch statistics there, which
+        is the one deviation from Keras' moving-statistics evaluation (documented in DESIGN.md section 11)."""
+        stats = self.flat_stats.clone() if self.train_bn else None
+        self.run_prep(); self.run_forward()
+        for op in self.loss_pre_ops + self.loss_ops:
+            op()
+        if stats is not None:
+            self.flat_stats.copy_(stats)
+        return self.losses()
 
     def set_lr(self, lr):
         self.hyper[0] = float(lr)

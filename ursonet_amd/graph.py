@@ -159,6 +159,10 @@ def build_graph(config):
     else:
         g.outputs["loc"] = g.conv("loc_final", None, t, int(config.LOC_BINS_PER_DIM) ** 3, 1, relu=True, dense=True,
                                   kin=kin, out_f32=True)
+    if config.REGRESS_KEYPOINTS:
+        # the keypoint model's outputs are [k1, k2, k3] only (net.py:675-691): ori_pred is built by the reference but is not a
+        # Model output, so Keras prunes the whole ori_* branch -- no ori layers, weights or gradients exist in this mode
+        return g
     t, kin = trunk("ori")
     if config.REGRESS_ORI:
         if config.ORIENTATION_PARAM == "quaternion":

@@ -63,6 +63,8 @@ _dp = C.POINTER(ParamDesc)
 _SIGS = {
     "urso_last_error": (C.c_char_p, []),
     "urso_abi_version": (_i, []),
+    "urso_set_option": (_i, [C.c_char_p, _i]),
+    "urso_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "urso_conv_igemm": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp]),
     "urso_conv_igemm_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -119,6 +121,46 @@ def last_error():
 def _chk(rc, what):
     if rc != 0:
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv")
+
+
+def set_option(name, value):
+    """urso_set_option: explicit kernel-policy switch (include/ursonet_hip.h)."""
+    _chk(_lib.urso_set_option(name.encode(), int(value)), "urso_set_option")
+
+
+def get_option(name):
+    v = C.c_int(0)
+    _chk(_lib.urso_get_option(name.encode(), C.byref(v)), "urso_get_option")
+    return int(v.value)
+
+
+class options(object):
+    """Context manager: `with hip.options(grid_cap=16): ...` sets options and restores the previous values."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+# A/B experiments inside one gpurun call: URSO_OPT_<NAME>=<int> in the environment of the PYTHON host is applied once at
+# import (the C library itself never reads the environment).
+for _o in OPTION_NAMES:
+    _e = os.environ.get("URSO_OPT_" + _o.upper())
+    if _e is not None:
+        _chk(_lib.urso_set_option(_o.encode(), int(_e)), "urso_set_option")
 
 
 def ptr(t):

@@ -391,22 +391,18 @@ class UrsoNet(object):
                 eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
                 eng.step()
                 ls = eng.losses()
-                history_full.ori_loss_acc.append(ls["ori_loss"])
+                history_full.ori_loss_acc.append(ls.get("ori_loss"))      # None in keypoint mode, as logs.get('ori_loss') is (net.py:1112)
                 history_full.loc_loss_acc.append(ls["loc_loss"])
-            val = {"loc_loss": [], "ori_loss": []}
+                last_train = ls
+            val = {}
             for _ in range(int(cfg.VALIDATION_STEPS)):
                 inputs, _o = next(val_generator)
                 eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
-                eng.run_prep(); eng.run_forward()
-                for op in eng.loss_ops:
-                    op()
-                for k, v in eng.losses().items():
-                    val[k].append(v)
-            log("epoch %d  loc_loss %.5f ori_loss %.5f  val_loc_loss %.5f val_ori_loss %.5f" % (
+                for k, v in eng.evaluate().items():
+                    val.setdefault(k, []).append(v)
+            log("epoch %d  loc_loss %.5f  %s" % (
                 epoch + 1, float(np.mean(history_full.loc_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
-                float(np.mean(history_full.ori_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
-                float(np.mean(val["loc_loss"])) if val["loc_loss"] else float("nan"),
-                float(np.mean(val["ori_loss"])) if val["ori_loss"] else float("nan")))
+                "  ".join("val_%s %.5f" % (k, float(np.mean(v))) for k, v in sorted(val.items()))))
             self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))
         self.epoch = max(self.epoch, epochs)
         return history_full
