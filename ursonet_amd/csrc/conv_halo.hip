@@ -1,0 +1,287 @@
+// Halo-tile implicit-GEMM convolution for the 3x3 / stride-1 / pad-1 layers of the bottleneck blocks (net.py:106,143: res{3,4,5}x_branch2b
+// forward and -- with the flipped filter of urso_conv_weight_prep -- their data gradient), 16-bit dtypes, gfx950.
+//
+// Why a second conv kernel.  conv_pw.hip treats a 3x3 conv as nine shifted 1x1 GEMMs and copies the pixel tile of EVERY tap from
+// L2 into LDS: a 128x64 tile moves 24 KiB per 0.5 M MACs, i.e. ~96 B/clk/CU at full MFMA rate against the ~64 B/clk a CU's vector
+// memory path can deliver -- the kernel is bound by L2->LDS bytes (measured: doubling the copies costs +30 %), not by MFMA issue.
+// Here the pixel operand is fetched ONCE per 64-channel chunk as a halo tile and the nine taps read it at shifted LDS rows:
+//   * the layer is evaluated over a VIRTUAL pixel grid with one zero column per image row and one zero row per image
+//     (Vw = W+1, Vh = H+1, p = (b*Vh + y)*Vw + x).  In that space tap (ky,kx) of output pixel p is input pixel
+//     p + (ky-1)*Vw + (kx-1) for EVERY p: borders, image seams and batch ends need no masks because the neighbours that fall
+//     outside the image are the shared zero column/row (or lie outside the tensor and are zero-filled by the buffer descriptor).
+//     Outputs at virtual pad positions are computed and dropped ((H+1)(W+1)/(HW) - 1 = 3-12 % extra MFMA work);
+//   * tile = 256 consecutive virtual pixels x 128 filters, 8 waves (4 x 2, 64x64 each) on v_mfma_f32_32x32x16; per 64-channel chunk
+//     the halo tile (256 + 2(Vw+1) rows x 128 B) is copied once and each tap adds a 16 KiB filter tile: 190-200 KiB per 19 M MACs
+//     (~21 B/clk/CU at full MFMA rate, 4.5x less than before);
+//   * LDS rows are 128 B with the XOR swizzle slot = chunk ^ ((row >> 1) & 7): a ds_read_b128 lane group of the 32x32x16 operand
+//     layout reads ONE chunk of 16 rows out of 32 consecutive ones, which that swizzle spreads over all 16 slots of the 256-byte
+//     bank row for ANY start row -- so the tap shift costs no bank conflicts;
+//   * everything goes HBM/L2 -> LDS by DMA (buffer_load ... lds) issued from inline asm and ordered by hand-counted vmcnt
+//     (conv_pw.hip explains why); one barrier per (chunk, tap) step of 16 MFMAs per wave; filter tiles run in a 3-slot ring two
+//     steps ahead, the next chunk's halo tile is copied one instruction per tap step into the other halo buffer.
+// The filter rows are permuted on the DMA source side so that a lane's 16 accumulators are two runs of 8 consecutive output
+// channels: the epilogue (bias, residual, ReLU, mask) stores 16-byte vectors straight from registers.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct HcArgs {
+    const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
+    uint32_t src_bytes, wgt_bytes, dst_bytes;
+    int H, W, C, N;
+    int Vw, Vh, Mv;            // virtual grid: Vw = W + 1, Vh = H + 1, Mv = B * Vh * Vw
+    int nchunks;               // C / 64
+    int tilesN, ntiles;
+    int R, JA;                 // halo rows per tile (BM + 2 (Vw + 1)) and DMA instructions per thread that cover them
+    int krow;                  // bytes per filter row (9 * C * 2)
+    float rcp_vw, rcp_vh;
+    int relu;
+};
+
+template <typename T> struct Mma32;
+template <> struct Mma32<__bf16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma32<_Float16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void hc_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    // m0 = wave-uniform LDS destination; lane l lands at m0 + 16 l (conv_pw.hip pw_dma16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t hc_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void hc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void hc_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// byte offset of (row, 16-byte chunk 2*k16 + h) inside a [rows][128 B] tile is  hc_rd(row, h) ^ (k16 << 5)
+__device__ __forceinline__ uint32_t hc_rd(int row, int h) {
+    const int s = (row >> 1) & 7;
+    return (uint32_t)(row * 128 + ((s >> 1) << 5) + ((h ^ (s & 1)) << 4));
+}
+// MFMA row rho of a 32-filter sub-tile <-> filter offset: lane half h then holds filters 8h..8h+7 in accumulators 0..7 and 16+8h.. in 8..15
+__device__ __forceinline__ int hc_perm(int rho) {
+    const int g = rho >> 3, hh = (rho >> 2) & 1, e = rho & 3;
+    return 16 * (g >> 1) + 8 * hh + 4 * (g & 1) + e;
+}
+
+constexpr int HC_BM = 256, HC_BN = 128, HC_BSLOT = HC_BN * 128, HC_AROWS = 448, HC_ABUF = HC_AROWS * 128;
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int BM = HC_BM, BN = HC_BN, BSLOT = HC_BSLOT, ABUF = HC_ABUF, AOFF = 3 * BSLOT;
+    __shared__ __attribute__((aligned(1024))) char smem[3 * BSLOT + 2 * ABUF];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int l31 = lane & 31, h = lane >> 5, c8 = lane & 7, r8 = lane >> 3;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = hc_rsrc(a.src, a.src_bytes), rw = hc_rsrc(a.wgt, a.wgt_bytes);
+    const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
+
+    // ---- fragment read offsets (tile independent).  Filter operand: rows 64 wn + 32 j + l31 of the ring slot; pixel operand: halo row
+    //      64 wm + 32 i + l31 + ky Vw + kx of the halo buffer (halo row 0 = virtual pixel p0 - Vw - 1)
+    uint32_t boff[2], aoff[9][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) boff[j] = hc_rd(64 * wn + 32 * j + l31, h);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aoff[t][i] = hc_rd(64 * wm + 32 * i + l31 + (t / 3) * a.Vw + (t % 3), h);
+
+    // ---- filter-tile DMA roles: instruction q covers ring rows 8 (wave + 8 q) + r8
+    uint32_t bsrc0[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int Rr = 8 * (wave + 8 * q) + r8;
+        const int nl = (Rr & ~31) + hc_perm(Rr & 31);
+        bsrc0[q] = (uint32_t)nl * (uint32_t)a.krow + (uint32_t)((c8 ^ ((Rr >> 1) & 7)) << 4);
+    }
+
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    // virtual pixel -> real pixel index (or -1 for the zero column / row and everything outside the batch)
+    auto real_pixel = [&](int p) -> int {
+        if (p < 0 || p >= a.Mv) return -1;
+        int q1, x, b, y;
+        divmod(p, a.Vw, a.rcp_vw, q1, x);
+        divmod(q1, a.Vh, a.rcp_vh, b, y);
+        return (x < a.W && y < a.H) ? (b * a.H + y) * a.W + x : -1;
+    };
+
+    const int nsteps = a.nchunks * 9;
+    while (true) {
+        const int p0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+        // ---- halo-tile DMA roles of this tile: instruction j covers halo rows 8 (wave + 8 j) + r8
+        uint32_t arow[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            arow[j] = URSO_OOB_SHIFT;
+            if (j < a.JA) {
+                const int r = 8 * (wave + 8 * j) + r8;
+                const int pix = (r < a.R) ? real_pixel(p0 - (a.Vw + 1) + r) : -1;
+                arow[j] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.C * 2u + (uint32_t)((c8 ^ ((r >> 1) & 7)) << 4) : URSO_OOB_SHIFT;
+            }
+        }
+        const uint32_t bs0 = bsrc0[0] + (uint32_t)n0 * (uint32_t)a.krow, bs1 = bsrc0[1] + (uint32_t)n0 * (uint32_t)a.krow;
+        auto dma_b = [&](int s, int slot) {                    // filter tile of step s = chunk * 9 + tap
+            const int cc = s / 9, t = s - cc * 9;
+            const bool ok = s < nsteps;
+            const uint32_t koff = (uint32_t)(t * a.C + cc * 64) * 2u;
+            hc_dma16(rw, lds0 + slot * BSLOT + wave * 1024, ok ? bs0 + koff : URSO_OOB_SHIFT);
+            hc_dma16(rw, lds0 + slot * BSLOT + (wave + 8) * 1024, ok ? bs1 + koff : URSO_OOB_SHIFT);
+        };
+        auto dma_a = [&](uint32_t ar, int j, int cc, int buf) {
+            hc_dma16(rs, lds0 + AOFF + buf * ABUF + (wave + 8 * j) * 1024, ar + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
+        };
+
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // ---- prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
+#pragma unroll
+        for (int j = 0; j < 9; ++j) if (j < a.JA) dma_a(arow[j], j, 0, 0);
+        dma_b(0, 0);
+        dma_b(1, 1);
+        hc_wait_vm<2>();                                      // all but the two copies of step 1
+        hc_barrier();
+
+        for (int cc = 0; cc < a.nchunks; ++cc) {
+            const uint32_t abase = AOFF + (cc & 1) * ABUF;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                dma_b(cc * 9 + t + 2, (t + 2) % 3);            // ring slot of step s is s % 3 = t % 3 (9 % 3 == 0)
+                const bool more_a = t < a.JA;
+                if (more_a) dma_a(arow[t], t, cc + 1, (cc + 1) & 1);      // past the last chunk: harmless copy into the idle buffer
+                const uint32_t bbase = (t % 3) * BSLOT;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    i32x4_t fw[2], fp[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j] = *(const i32x4_t*)(smem + bbase + (boff[j] ^ (uint32_t)(k << 5)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fp[i] = *(const i32x4_t*)(smem + abase + (aoff[t][i] ^ (uint32_t)(k << 5)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) Mma32<T>::run(fw[j], fp[i], acc[i][j]);
+                }
+                // everything older than this step's own copies has landed: the filter tile of step s + 1 and, by tap JA, the next halo tile
+                if (more_a) hc_wait_vm<3>(); else hc_wait_vm<2>();
+                hc_barrier();
+            }
+        }
+        hc_wait_vm<0>();
+
+        // ---- epilogue: + bias (+ residual) -> ReLU -> mask -> 16-byte stores from registers
+        uint32_t po[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = real_pixel(p0 + 64 * wm + 32 * i + l31);
+            po[i] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.N * 2u : URSO_OOB_SHIFT;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int nb = n0 + 64 * wn + 32 * j + 16 * hf + 8 * h;
+                const f32x4_t b0 = __builtin_bit_cast(f32x4_t, buf_load16(rbi, (uint32_t)nb * 4u));
+                const f32x4_t b1 = __builtin_bit_cast(f32x4_t, buf_load16(rbi, (uint32_t)nb * 4u + 16u));
+                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t o = po[i] + (uint32_t)nb * 2u;           // OOB_SHIFT + small stays out of range
+                    T ea[8], em[8], eo[8];
+                    if (a.add) { const i32x4_t v = buf_load16(rad, o); __builtin_memcpy(ea, &v, 16); }
+                    if (a.mask) { const i32x4_t v = buf_load16(rmk, o); __builtin_memcpy(em, &v, 16); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float y = acc[i][j][8 * hf + e] + bv[e];
+                        if (a.add) y += Elem<T>::to_f(ea[e]);
+                        y = a.relu ? fmaxf(y, 0.f) : y;
+                        if (a.mask) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                        eo[e] = Elem<T>::from_f(y);
+                    }
+                    i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                    buf_store16(rds, o, ov);
+                }
+            }
+        tile += bpx;
+        if (tile >= t_end) break;
+        // the next prologue overwrites LDS: every wave has passed the last step's barrier after its final reads
+    }
+}
+
+static int hc_device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+// Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 64 == 0, N % 128 == 0, halo tile within the LDS budget.
+bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags) {
+    if (!g_urso_opt.hconv || dt == URSO_F32) return false;
+    if (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) return false;
+    if (g->KH != 3 || g->KW != 3 || g->SH != 1 || g->SW != 1 || g->PH != 1 || g->PW != 1 || g->DH != 1 || g->DW != 1) return false;
+    if (g->OH != g->H || g->OW != g->W || g->FH > 0) return false;
+    if (g->C % 64 || g->N % HC_BN) return false;
+    if (HC_BM + 2 * (g->W + 2) > HC_AROWS) return false;
+    if ((size_t)g->B * (g->H + 1) * (g->W + 1) >= (1u << 24)) return false;
+    return true;
+}
+
+int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
+    HcArgs a;
+    a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
+    a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
+    a.H = g->H; a.W = g->W; a.C = g->C; a.N = g->N;
+    a.Vw = g->W + 1; a.Vh = g->H + 1; a.Mv = g->B * a.Vh * a.Vw;
+    a.nchunks = g->C / 64;
+    a.tilesN = g->N / HC_BN; a.ntiles = ceil_div(a.Mv, HC_BM) * a.tilesN;
+    a.R = HC_BM + 2 * (a.Vw + 1); a.JA = ceil_div(a.R, 64);
+    a.krow = 9 * g->C * 2;
+    a.rcp_vw = 1.0f / (float)a.Vw; a.rcp_vh = 1.0f / (float)a.Vh;
+    a.relu = relu;
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = hc_device_cus() / 8;                   // 160 KiB of LDS: one block per CU
+    if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
+    const dim3 grid(8 * bpx), blk(512);
+    if (dt == URSO_BF16) hipLaunchKernelGGL((hconv_kernel<__bf16>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((hconv_kernel<_Float16>), grid, blk, 0, st, a);
+    return urso_check_launch("urso_conv_igemm(halo)");
+}
