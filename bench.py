@@ -47,9 +47,30 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
+def host_cpu_info():
+    """lscpu-style description of the host: model string, sockets, physical cores, hardware threads."""
+    model, phys, sockets = "unknown", set(), set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v; sockets.add(v)
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+    except Exception:
+        pass
+    return {"model": model, "sockets": max(len(sockets), 1), "physical_cores": len(phys) or physical_cores(), "threads": os.cpu_count()}
+
+
 def cpu_baseline(cfg_kw, sample_batch, steps):
     """The oracle's training step (fwd+loss+bwd+SGD, fp32, torch-CPU/oneDNN) on the host cores,
-    on a bounded sample: `sample_batch` images per step, `steps` timed steps after one warm-up."""
+    on a bounded sample: `sample_batch` images per step, `steps` timed steps after one warm-up; plus a forward-only figure."""
     from oracle import graph_ref as G
     from util import synthetic_batch
     cores = min(physical_cores(), 128)
@@ -64,16 +85,24 @@ def cpu_baseline(cfg_kw, sample_batch, steps):
     for _ in range(steps):
         G.train_step(P, vel, img, loc, ori, cfg, 1e-3)
     dt = time.time() - t0
+    with torch.no_grad():
+        Pn = G.to_torch({ln: {wn: w.detach().numpy() for wn, w in ws.items()} for ln, ws in P.items()}, requires_grad=False)
+        G.forward(Pn, img, cfg)
+        t1 = time.time()
+        for _ in range(steps):
+            G.forward(Pn, img, cfg)
+        dtf = time.time() - t1
     return {"value": round(sample_batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle/graph_ref.train_step fp32, %s %dx%d, batch %d, %d timed steps after 1 warm-up (%.1f s)"
-                      % (cfg_kw["backbone"], cfg_kw["h"], cfg_kw["w"], sample_batch, steps, dt)}
+            "forward_only_images_per_sec": round(sample_batch * steps / dtf, 3), "host": host_cpu_info(),
+            "sample": "oracle/graph_ref.train_step fp32, %s %dx%d, batch %d, %d timed steps after 1 warm-up (%.1f s; forward-only %.1f s)"
+                      % (cfg_kw["backbone"], cfg_kw["h"], cfg_kw["w"], sample_batch, steps, dt, dtf)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
@@ -81,8 +110,8 @@ def main():
     ap.add_argument("--ori-bins", type=int, default=16)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -166,7 +195,7 @@ def main():
     # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pm = json.load(f)
         if pm.get("workload") == [args.backbone, args.batch, args.height, args.width, args.dtype]:
             traffic = pm["igemm_hbm_bytes_per_launch"]

@@ -56,7 +56,9 @@ int         urso_abi_version(void);           /* bumped on any signature change 
  *   wgrad_pipe (1)    scheduler-interleaved fragment reads in the 16-bit weight-gradient kernel
  *   grid_cap (0)      > 0: upper bound on the block count of the persistent conv kernels (tests: makes every block
  *                     walk several tiles, i.e. exercises the cross-tile prefetch path, on small shapes)
- *   hconv (1)         8-wave halo-tile kernel for the 3x3 stride-1 layers of stages 3-5 (0 = DMA kernel everywhere)
+ *   hconv (1)         8-wave halo-tile kernel (conv_halo.hip) for 3x3 stride-1 layers with >= 128 channels and filters:
+ *                     0 never, 1 where its tile count fills the chip evenly (measured policy), 2 wherever it applies
+ *   hconv_dbg (0)     kernel-development switches of that kernel; leave 0
  */
 int urso_set_option(const char* name, int value);
 int urso_get_option(const char* name, int* value);

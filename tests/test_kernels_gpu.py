@@ -114,6 +114,11 @@ def test_conv_forward_and_gradients(case, dt):
     torch.cuda.synchronize()
     e = relerr(y, y_ref)
     assert e < TOL[dt], "forward %s dt=%d rel err %.3e" % (name, dt, e)
+    y2 = torch.empty_like(y)                               # conv + bias + relu (no residual): the form of every branch2a / branch2b layer
+    hip.conv_igemm(g, dt, hip.EPI_RELU, dev(x, dt), wf, biasf, None, None, y2)
+    torch.cuda.synchronize()
+    e = relerr(y2, F.relu(z - res))
+    assert e < TOL[dt], "forward (no residual) %s dt=%d rel err %.3e" % (name, dt, e)
     # ---- backward reference
     dy = rnd(torch.randn(B, OH, OW, N), dt)
     dz_ref = (dy * (y_ref > 0)).detach()
@@ -128,6 +133,11 @@ def test_conv_forward_and_gradients(case, dt):
     dx_ref = (x_r.grad + addt) * (x > 0)
     e = relerr(dx, dx_ref)
     assert e < TOL[dt], "dgrad %s dt=%d rel err %.3e" % (name, dt, e)
+    # the same pass as res{3,4,5}x_branch2b runs it: ReLU mask of x, no residual gradient (conv_halo.hip takes this form)
+    hip.conv_igemm(gd, dt, 0, dev(dz_ref, dt), wd, None, None, dev(x, dt), dx)
+    torch.cuda.synchronize()
+    e = relerr(dx, x_r.grad * (x > 0))
+    assert e < TOL[dt], "dgrad (mask only) %s dt=%d rel err %.3e" % (name, dt, e)
     if k == 1 and s == 2:
         # compact form used for res{3,4,5}a_branch{2a,1}: GEMM over the output pixels, scattered to every 2nd pixel
         gs = hip.geom(B, OH, OW, N, OH, OW, Ci, 1, 1, FH=H, FW=W, OSH=s, OSW=s)
@@ -186,6 +196,21 @@ def test_conv_full_size_tile_streams(case, dt):
 def test_conv_capped_grid_tile_streams(case, dt):
     hip = _hip()
     with hip.options(grid_cap=8):
+        test_conv_forward_and_gradients(case, dt)
+
+
+HALO_CASES = [c for c in BIG_CASES + CAP_CASES if c[5] == 3 and c[3] % 128 == 0 and c[4] % 128 == 0]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("cap", [0, 8, 24])
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[-1] for c in HALO_CASES])
+def test_halo_conv_kernel_forced(case, dt, cap):
+    """conv_halo.hip on every shape it accepts (urso_set_option hconv = 2 overrides the tile-count policy), with the grid at its
+    production size and capped to 8 / 24 blocks so that a block's contiguous run holds several tiles: continuous halo / filter
+    stream across tile seams, several filter tiles per pixel tile (N = 256), transposed epilogue, mask-only data gradient."""
+    hip = _hip()
+    with hip.options(hconv=2, grid_cap=cap):
         test_conv_forward_and_gradients(case, dt)
 
 

@@ -36,6 +36,7 @@ struct HcArgs {
     int krow;                  // bytes per filter row (9 * C * 2)
     float rcp_vw, rcp_vh;
     int relu;
+    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop
 };
 
 template <typename T> struct Mma32;
@@ -73,40 +74,48 @@ __device__ __forceinline__ int hc_perm(int rho) {
     return 16 * (g >> 1) + 8 * hh + 4 * (g & 1) + e;
 }
 
-constexpr int HC_BM = 256, HC_BN = 128, HC_BSLOT = HC_BN * 128, HC_AROWS = 448, HC_ABUF = HC_AROWS * 128;
+constexpr int HC_BM = 256, HC_BN = 128, HC_BSLOT = HC_BN * 128, HC_AROWS = 424, HC_ABUF = HC_AROWS * 128;
+constexpr int HC_AOFF = 3 * HC_BSLOT, HC_XOFF = HC_AOFF + 2 * HC_ABUF, HC_LDS = 163840, HC_MAXN = (HC_LDS - HC_XOFF) / 4;
+constexpr int HC_NST = 8;                                  // vector-memory stores per lane of one epilogue
+
+__device__ __forceinline__ void hc_sbarrier() { asm volatile("s_barrier" ::: "memory"); }
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    constexpr int BM = HC_BM, BN = HC_BN, BSLOT = HC_BSLOT, ABUF = HC_ABUF, AOFF = 3 * BSLOT;
-    __shared__ __attribute__((aligned(1024))) char smem[3 * BSLOT + 2 * ABUF];
+    constexpr int BM = HC_BM, BN = HC_BN, BSLOT = HC_BSLOT, ABUF = HC_ABUF, AOFF = HC_AOFF, XOFF = HC_XOFF;
+    __shared__ __attribute__((aligned(1024))) char smem[HC_LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
     const int l31 = lane & 31, h = lane >> 5, c8 = lane & 7, r8 = lane >> 3;
 
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int cpx = ceil_div(a.ntiles, 8);
-    const int t_end = min((xcd + 1) * cpx, a.ntiles);
-    int tile = xcd * cpx + lb;
-    if (tile >= t_end) return;
+    // ---- this block's contiguous run of tiles; logical ids are XCD-contiguous so that neighbouring runs (which share halo rows and,
+    //      with several filter tiles per pixel tile, the whole pixel tile) meet in one L2
+    const int G = gridDim.x, lid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int t_begin = (int)(((long long)lid * a.ntiles) / G), t_end = (int)(((long long)(lid + 1) * a.ntiles) / G);
+    if (t_begin >= t_end) return;
 
     const i32x4_t rs = hc_rsrc(a.src, a.src_bytes), rw = hc_rsrc(a.wgt, a.wgt_bytes);
-    const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
 
-    // ---- fragment read offsets (tile independent).  Filter operand: rows 64 wn + 32 j + l31 of the ring slot; pixel operand: halo row
-    //      64 wm + 32 i + l31 + ky Vw + kx of the halo buffer (halo row 0 = virtual pixel p0 - Vw - 1)
-    uint32_t boff[2], aoff[9][2];
+    // ---- bias of all N filters -> LDS (read back per tile by the epilogue)
+    if (tid * 4 < a.N) {
+        f32x4_t b = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b = *(const f32x4_t*)(a.bias + tid * 4);
+        *(f32x4_t*)(smem + XOFF + tid * 16) = b;
+    }
+
+    // ---- fragment read offsets.  Filter operand: rows 64 wn + 32 j + l31 of a ring slot; pixel operand: halo row
+    //      64 wm + 32 i + l31 + ky Vw + kx of a halo buffer (halo row 0 = virtual pixel p0 - Vw - 1)
+    uint32_t boff[2];
+    int rb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) boff[j] = hc_rd(64 * wn + 32 * j + l31, h);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) aoff[t][i] = hc_rd(64 * wm + 32 * i + l31 + (t / 3) * a.Vw + (t % 3), h);
+    for (int i = 0; i < 2; ++i) rb[i] = 64 * wm + 32 * i + l31;
 
     // ---- filter-tile DMA roles: instruction q covers ring rows 8 (wave + 8 q) + r8
     uint32_t bsrc0[2];
@@ -125,40 +134,61 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
         r += hi ? -d : (lo ? d : 0);
     };
     // virtual pixel -> real pixel index (or -1 for the zero column / row and everything outside the batch)
-    auto real_pixel = [&](int p) -> int {
-        if (p < 0 || p >= a.Mv) return -1;
+    auto real_pixel = [&](int p) -> int {                      // branch-free: no exec-mask regions around the DMA issue
+        const bool in = p >= 0 && p < a.Mv;
         int q1, x, b, y;
-        divmod(p, a.Vw, a.rcp_vw, q1, x);
+        divmod(in ? p : 0, a.Vw, a.rcp_vw, q1, x);
         divmod(q1, a.Vh, a.rcp_vh, b, y);
-        return (x < a.W && y < a.H) ? (b * a.H + y) * a.W + x : -1;
+        return (in && x < a.W && y < a.H) ? (b * a.H + y) * a.W + x : -1;
     };
 
-    const int nsteps = a.nchunks * 9;
-    while (true) {
-        const int p0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
-        // ---- halo-tile DMA roles of this tile: instruction j covers halo rows 8 (wave + 8 j) + r8
-        uint32_t arow[9];
+    // halo-tile DMA roles of a tile: instruction j covers halo rows 8 (wave + 8 j) + r8 (JA <= 7 instructions; a wave skips the
+    // instructions whose rows lie beyond the halo, so the waits below are all vmcnt(0)-style, never counted per wave)
+    uint32_t arow[7];
+    auto set_arow = [&](int tile_) {
+        const int p0_ = (tile_ / a.tilesN) * BM;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            arow[j] = URSO_OOB_SHIFT;
-            if (j < a.JA) {
-                const int r = 8 * (wave + 8 * j) + r8;
-                const int pix = (r < a.R) ? real_pixel(p0 - (a.Vw + 1) + r) : -1;
-                arow[j] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.C * 2u + (uint32_t)((c8 ^ ((r >> 1) & 7)) << 4) : URSO_OOB_SHIFT;
-            }
+        for (int j = 0; j < 7; ++j) {
+            const int r = 8 * (wave + 8 * j) + r8;
+            const int pix = (r < a.R) ? real_pixel(p0_ - (a.Vw + 1) + r) : -1;
+            arow[j] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.C * 2u + (uint32_t)((c8 ^ ((r >> 1) & 7)) << 4) : URSO_OOB_SHIFT;
         }
-        const uint32_t bs0 = bsrc0[0] + (uint32_t)n0 * (uint32_t)a.krow, bs1 = bsrc0[1] + (uint32_t)n0 * (uint32_t)a.krow;
-        auto dma_b = [&](int s, int slot) {                    // filter tile of step s = chunk * 9 + tap
-            const int cc = s / 9, t = s - cc * 9;
-            const bool ok = s < nsteps;
-            const uint32_t koff = (uint32_t)(t * a.C + cc * 64) * 2u;
-            hc_dma16(rw, lds0 + slot * BSLOT + wave * 1024, ok ? bs0 + koff : URSO_OOB_SHIFT);
-            hc_dma16(rw, lds0 + slot * BSLOT + (wave + 8) * 1024, ok ? bs1 + koff : URSO_OOB_SHIFT);
-        };
-        auto dma_a = [&](uint32_t ar, int j, int cc, int buf) {
-            hc_dma16(rs, lds0 + AOFF + buf * ABUF + (wave + 8 * j) * 1024, ar + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
-        };
+    };
+    auto dma_a = [&](int j, int cc, int buf) {                 // static j
+        if (8 * (wave + 8 * j) < a.R)
+            hc_dma16(rs, lds0 + AOFF + buf * ABUF + (wave + 8 * j) * 1024, arow[j] + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
+    };
+    auto dma_b = [&](int n0_, int cc, int t, int slot) {       // filter tile (chunk cc, tap t) of the filter block starting at n0_
+        const uint32_t koff = (uint32_t)n0_ * (uint32_t)a.krow + (uint32_t)(t * a.C + cc * 64) * 2u;
+        hc_dma16(rw, lds0 + slot * BSLOT + wave * 1024, bsrc0[0] + koff);
+        hc_dma16(rw, lds0 + slot * BSLOT + (wave + 8) * 1024, bsrc0[1] + koff);
+    };
 
+    int tile = t_begin;
+    set_arow(tile);
+    {   // ---- block prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
+        const int n0 = (tile % a.tilesN) * BN;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dma_a(j, 0, 0);
+        dma_b(n0, 0, 0, 0);
+        dma_b(n0, 0, 1, 1);
+        hc_wait_vm<0>();
+        hc_barrier();                                         // also publishes the bias written above
+    }
+    int buf = 0;
+    i32x4_t fw0[2], fp0[2], fw1[2], fp1[2];                  // fragment sets of two consecutive 16-deep k sub-steps
+    auto rd = [&](i32x4_t (&fw)[2], i32x4_t (&fp)[2], uint32_t bbase, uint32_t abase, int shift, int k) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[j] = *(const i32x4_t*)(smem + bbase + (boff[j] ^ (uint32_t)(k << 5)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fp[i] = *(const i32x4_t*)(smem + abase + (hc_rd(rb[i] + shift, h) ^ (uint32_t)(k << 5)));
+    };
+    rd(fw0, fp0, 0, AOFF, 0, 0);                              // step 0, k = 0
+
+    while (true) {
+        const bool has_next = tile + 1 < t_end;
+        const int p0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+        const int n0n = ((tile + 1) % a.tilesN) * BN;
         f32x16_t acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -167,77 +197,126 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        // ---- prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
-#pragma unroll
-        for (int j = 0; j < 9; ++j) if (j < a.JA) dma_a(arow[j], j, 0, 0);
-        dma_b(0, 0);
-        dma_b(1, 1);
-        hc_wait_vm<2>();                                      // all but the two copies of step 1
-        hc_barrier();
-
-        for (int cc = 0; cc < a.nchunks; ++cc) {
-            const uint32_t abase = AOFF + (cc & 1) * ABUF;
+        for (int cc = 0; cc < ((a.dbg & 2) ? 0 : a.nchunks); ++cc) {
+            const bool last = cc + 1 == a.nchunks;
+            if (last && has_next) set_arow(tile + 1);          // from here on the halo copies target the next tile's chunk 0
+            const bool more_a = !last || has_next;
+            const int cca = last ? 0 : cc + 1;
+            const uint32_t abase = AOFF + buf * ABUF, abase_n = AOFF + (buf ^ 1) * ABUF;
+            const bool first_wait_after_epilogue = cc == 0 && tile != t_begin && !(a.dbg & 1);
+            // the read addresses are functions of (lane, tap) only: keep the compiler from hoisting all 9 x 2 x 4 of them out of the
+            // chunk loop into registers (it then spills the accumulators)
+            asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(boff[0]), "+v"(boff[1]));
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                dma_b(cc * 9 + t + 2, (t + 2) % 3);            // ring slot of step s is s % 3 = t % 3 (9 % 3 == 0)
-                const bool more_a = t < a.JA;
-                if (more_a) dma_a(arow[t], t, cc + 1, (cc + 1) & 1);      // past the last chunk: harmless copy into the idle buffer
                 const uint32_t bbase = (t % 3) * BSLOT;
+                const int shift = (t / 3) * a.Vw + (t % 3);
+                // k = 0 fragments are in fw0 / fp0 (read during the previous step)
+                rd(fw1, fp1, bbase, abase, shift, 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    i32x4_t fw[2], fp[2];
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fw[j] = *(const i32x4_t*)(smem + bbase + (boff[j] ^ (uint32_t)(k << 5)));
+                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(fw0, fp0, bbase, abase, shift, 2);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) fp[i] = *(const i32x4_t*)(smem + abase + (aoff[t][i] ^ (uint32_t)(k << 5)));
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) Mma32<T>::run(fw[j], fp[i], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(fw1, fp1, bbase, abase, shift, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- mid-step: this wave's copies issued one step ago have landed -> barrier -> every wave's have, and every wave has
+                //      finished reading the previous step's ring slot and (at t = 0) the previous chunk's halo buffer
+                if (t == 0 && first_wait_after_epilogue) hc_wait_vm<HC_NST>(); else hc_wait_vm<0>();
+                hc_sbarrier();
+                {   // filter tile two steps ahead -> ring slot (t + 2) % 3; one piece of the next halo tile -> the other halo buffer
+                    const int t2 = (t + 2) % 9;
+                    const bool wrap = t + 2 >= 9;
+                    const bool okb = !wrap || more_a;
+                    if (okb) dma_b((wrap && last) ? n0n : n0, wrap ? cca : cc, t2, (t + 2) % 3);
+                    if (t < 7 && t < a.JA && more_a) dma_a(t, cca, buf ^ 1);
                 }
-                // everything older than this step's own copies has landed: the filter tile of step s + 1 and, by tap JA, the next halo tile
-                if (more_a) hc_wait_vm<3>(); else hc_wait_vm<2>();
-                hc_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                // next step's k = 0 fragments (its filter tile and -- across a chunk seam -- its halo tile became visible at this or an
+                // earlier mid-step barrier)
+                if (t < 8) rd(fw0, fp0, ((t + 1) % 3) * BSLOT, abase, ((t + 1) / 3) * a.Vw + ((t + 1) % 3), 0);
+                else rd(fw0, fp0, 0, abase_n, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            buf ^= 1;
         }
-        hc_wait_vm<0>();
 
-        // ---- epilogue: + bias (+ residual) -> ReLU -> mask -> 16-byte stores from registers
-        uint32_t po[2];
+        // ---- epilogue: + bias -> ReLU -> 16-bit, transposed through LDS (this wave's 4 KiB of the halo buffer that has just been
+        //      retired: nothing is copied into it before the next mid-step barrier) so that every store instruction writes whole
+        //      128-byte lines; the mask is applied after the transposition, read with the same coalesced addresses
+        if (!(a.dbg & 1)) {
+            const uint32_t sbase = AOFF + (buf ^ 1) * ABUF + wave * 4096;
+            int vx, vy, vb;                                   // virtual coordinates of this lane's first store pixel
+            {
+                int q1;
+                divmod(p0 + 64 * wm + r8, a.Vw, a.rcp_vw, q1, vx);
+                divmod(q1, a.Vh, a.rcp_vh, vb, vy);
+            }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pix = real_pixel(p0 + 64 * wm + 32 * i + l31);
-            po[i] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.N * 2u : URSO_OOB_SHIFT;
-        }
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int nb = n0 + 64 * wn + 32 * j + 16 * hf + 8 * h;
-                const f32x4_t b0 = __builtin_bit_cast(f32x4_t, buf_load16(rbi, (uint32_t)nb * 4u));
-                const f32x4_t b1 = __builtin_bit_cast(f32x4_t, buf_load16(rbi, (uint32_t)nb * 4u + 16u));
-                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int nb = n0 + 64 * wn + 32 * j + 16 * hf + 8 * h;
+                        const f32x4_t b0 = *(const f32x4_t*)(smem + XOFF + nb * 4), b1 = *(const f32x4_t*)(smem + XOFF + nb * 4 + 16);
+                        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                        T eo[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t o = po[i] + (uint32_t)nb * 2u;           // OOB_SHIFT + small stays out of range
-                    T ea[8], em[8], eo[8];
-                    if (a.add) { const i32x4_t v = buf_load16(rad, o); __builtin_memcpy(ea, &v, 16); }
-                    if (a.mask) { const i32x4_t v = buf_load16(rmk, o); __builtin_memcpy(em, &v, 16); }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float y = acc[i][j][8 * hf + e] + bv[e];
-                        if (a.add) y += Elem<T>::to_f(ea[e]);
-                        y = a.relu ? fmaxf(y, 0.f) : y;
-                        if (a.mask) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
-                        eo[e] = Elem<T>::from_f(y);
+                        for (int e = 0; e < 8; ++e) {
+                            float y = acc[i][j][8 * hf + e] + bv[e];
+                            y = a.relu ? fmaxf(y, 0.f) : y;
+                            eo[e] = Elem<T>::from_f(y);
+                        }
+                        i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                        *(i32x4_t*)(smem + sbase + l31 * 128 + (((4 * j + 2 * hf + h) ^ ((l31 >> 1) & 7)) << 4)) = ov;
                     }
-                    i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
-                    buf_store16(rds, o, ov);
+                i32x4_t ov[4], mv[4];
+                uint32_t so[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 8 * q + r8;
+                    ov[q] = *(const i32x4_t*)(smem + sbase + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
+                    // pixel p0 + 64 wm + 32 i + 8 q + r8 = (vb, vy, vx) advanced by 8 (32 i + 8 q)/8 steps
+                    const bool ok = vb * a.Vh * a.Vw + vy * a.Vw + vx < a.Mv && vx < a.W && vy < a.H;
+                    so[q] = ok ? (uint32_t)((vb * a.H + vy) * a.W + vx) * (uint32_t)a.N * 2u + (uint32_t)(n0 + 64 * wn + 8 * c8) * 2u : URSO_OOB_SHIFT;
+                    if (a.mask) mv[q] = buf_load16(rmk, so[q]);
+                    vx += 8;
+                    if (vx >= a.Vw) { vx -= a.Vw; if (++vy == a.Vh) { vy = 0; ++vb; } }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (a.mask) {
+                        T ev[8], em[8];
+                        __builtin_memcpy(ev, &ov[q], 16); __builtin_memcpy(em, &mv[q], 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ev[e] = (Elem<T>::to_f(em[e]) > 0.f) ? ev[e] : Elem<T>::from_f(0.f);
+                        __builtin_memcpy(&ov[q], ev, 16);
+                    }
+                    buf_store16(rds, so[q], ov[q]);
                 }
             }
-        tile += bpx;
-        if (tile >= t_end) break;
-        // the next prologue overwrites LDS: every wave has passed the last step's barrier after its final reads
+        }
+        if (!has_next) break;
+        ++tile;
     }
 }
 
@@ -251,15 +330,23 @@ static int hc_device_cus() {
     return ncu;
 }
 
-// Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 64 == 0, N % 128 == 0, halo tile within the LDS budget.
-bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags) {
-    if (!g_urso_opt.hconv || dt == URSO_F32) return false;
+// Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 128 == 0, N % 128 == 0, halo tile within the LDS
+// budget -- and a tile count that fills the 256 one-block-per-CU slots evenly: every block walks ceil(tiles / blocks) tiles, so e.g. 340
+// tiles cost as much as 512.  hconv = 1 (default) takes the layer only when that rounding loses < 25 % (measured on cfg2: stage 3 659
+// tiles 58.8 vs 62.6 us, stage 5 180 tiles 52.6 vs 55.6 us in favour; stage 4 340 tiles 59.7 vs 56.5 us against); hconv = 2 always.
+bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
+    if (!g_urso_opt.hconv || dt == URSO_F32 || add) return false;          // a residual operand never occurs on these layers: left to conv_pw.hip
     if (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) return false;
     if (g->KH != 3 || g->KW != 3 || g->SH != 1 || g->SW != 1 || g->PH != 1 || g->PW != 1 || g->DH != 1 || g->DW != 1) return false;
     if (g->OH != g->H || g->OW != g->W || g->FH > 0) return false;
-    if (g->C % 64 || g->N % HC_BN) return false;
-    if (HC_BM + 2 * (g->W + 2) > HC_AROWS) return false;
+    if (g->C % 128 || g->N % HC_BN || g->N > HC_MAXN) return false;        // >= 2 channel chunks (the halo double buffer assumes it)
+    if (HC_BM + 2 * (g->W + 2) > HC_AROWS || g->W + 1 < 8) return false;
     if ((size_t)g->B * (g->H + 1) * (g->W + 1) >= (1u << 24)) return false;
+    if (g_urso_opt.hconv == 1) {
+        const int ntiles = ceil_div(g->B * (g->H + 1) * (g->W + 1), HC_BM) * (g->N / HC_BN), ncu = hc_device_cus();
+        const int blocks = ntiles < ncu ? ntiles : ncu, rounds = ceil_div(ntiles, blocks);
+        if (ntiles * 4 < blocks * rounds * 3 && !(ntiles <= ncu && ntiles * 3 >= ncu * 2)) return false;   // < 75 % of the slots busy (one-round launches: 2/3)
+    }
     return true;
 }
 
@@ -275,9 +362,9 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     a.R = HC_BM + 2 * (a.Vw + 1); a.JA = ceil_div(a.R, 64);
     a.krow = 9 * g->C * 2;
     a.rcp_vw = 1.0f / (float)a.Vw; a.rcp_vh = 1.0f / (float)a.Vh;
-    a.relu = relu;
+    a.relu = relu; a.dbg = g_urso_opt.hconv_dbg;
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = hc_device_cus() / 8;                   // 160 KiB of LDS: one block per CU
+    const int cap = hc_device_cus() / 8;                   // 160 KiB of LDS: one block per CU; each block walks a contiguous run of tiles
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);

@@ -398,7 +398,7 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
                    uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st);      // conv_pw.hip
 
-bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags);                                                   // conv_halo.hip
+bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add);                                                   // conv_halo.hip
 int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);
 
@@ -534,7 +534,10 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     // algorithmic work: 2*M*N*K flops; bytes = src + weights + dst (+ add/mask reads)
     double flops = 2.0 * a.M * (double)g->N * g->KH * g->KW * g->C;
     if (g->DH > 1 || g->DW > 1) flops /= (double)(g->DH * g->DW);     // gather-form dgrad: only 1/(DH*DW) taps are real
-    double bytes = (double)src_bytes + (double)wgt_bytes + (double)dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
+    if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem: 7x7x3 real taps of the 7x4x8 padded ones
+    // a strided pointwise layer reads only the sampled pixels
+    const double src_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? (double)a.M * g->C * es : (double)src_bytes;
+    double bytes = src_alg + (double)wgt_bytes + (double)dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
                    (add_d ? dst_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? dst_elems / 8 : dst_elems * es) : 0) +
                    ((flags & URSO_EPI_EMIT_BITS) ? dst_elems / 8 : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
@@ -548,7 +551,7 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool fits = dt != URSO_F32 && !(flags & URSO_EPI_OUT_F32) && bits_fit && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
         // 3x3 / stride-1 layers with >= 128 filters: the 8-wave halo-tile kernel (conv_halo.hip)
-        if (fits && urso_hconv_fits(g, dt, flags))
+        if (fits && urso_hconv_fits(g, dt, flags, add_d))
             return urso_hconv_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, add_d, mask_d, dst_d,
                                      a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
         const int mbits = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;

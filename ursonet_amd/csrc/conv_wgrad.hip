@@ -747,7 +747,9 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     a.M = p.M; a.Cc = p.Cc; a.Kc = p.Kc; a.K = p.K; a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
     hipStream_t st = (hipStream_t)stream;
     double flops = 2.0 * p.M * (double)g->N * g->KH * g->KW * g->C;
-    double bytes = (double)x_bytes + (double)dz_bytes + (double)p.K * g->N * 4;
+    if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem (see urso_conv_igemm_ex)
+    const double x_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? (double)p.M * g->C * es : (double)x_bytes;
+    double bytes = x_alg + (double)dz_bytes + (double)p.K * g->N * 4;
     ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
     dim3 grid(p.ktiles * p.ntiles, p.splits);
     const int rm = 128 / (int)dt_size(dt);
