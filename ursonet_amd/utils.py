@@ -22,84 +22,105 @@ def clr_triangular(iteration, base_lr, max_lr, step_size):
     return float(base_lr + (max_lr - base_lr) * np.maximum(0, (1 - x)))
 
 
-def _bilinear_resize(image, out_h, out_w):
-    """Plain bilinear resampling (pixel centres aligned, zero outside).  The reference calls
-    skimage.transform.resize(order=1, mode='constant', preserve_range=True) (utils.py:457-459); skimage
-    is not available here, so rescaled images are NOT bit-identical to the reference's (scale == 1,
-    the benchmarked path, never reaches this function)."""
+def _gaussian_kernel1d(sigma):
+    r = max(1, int(4.0 * sigma + 0.5))                      # scipy.ndimage truncate = 4
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    return k / k.sum()
+
+
+def _smooth_axis(img, sigma, axis):
+    """1-D Gaussian along `axis` with zero ('constant') boundary, as skimage's anti-aliasing pre-filter applies it."""
+    k = _gaussian_kernel1d(sigma)
+    r = len(k) // 2
+    pad = [(0, 0)] * img.ndim
+    pad[axis] = (r, r)
+    padded = np.pad(img, pad, mode="constant")
+    out = np.zeros_like(img)
+    n = img.shape[axis]
+    for i, kv in enumerate(k):
+        sl = [slice(None)] * img.ndim
+        sl[axis] = slice(i, i + n)
+        out += kv * padded[tuple(sl)]
+    return out
+
+
+def _bilinear_resize(image, out_h, out_w, anti_aliasing=True):
+    """Bilinear resampling with pixel centres aligned and zeros outside -- the arithmetic of
+    skimage.transform.resize(order=1, mode='constant', preserve_range=True) (utils.py:457-459).  When an axis shrinks, newer
+    skimage versions first smooth it with a Gaussian of sigma = (in/out - 1)/2 (anti_aliasing=True is their default):
+    reproduced here because real URSO / SPEED frames (1280x960, 1920x1200) are reduced by 2-3x on this path.  skimage is not
+    installed in this image, so this path is pinned only by its own tests (scale == 1, the benchmarked path, never gets here)."""
     h, w = image.shape[:2]
-    ys = (np.arange(out_h) + 0.5) * h / out_h - 0.5
-    xs = (np.arange(out_w) + 0.5) * w / out_w - 0.5
-    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
-    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
     img = image.astype(np.float64)
     if img.ndim == 2:
         img = img[:, :, None]
+    if anti_aliasing:
+        for axis, (n_in, n_out) in enumerate(((h, out_h), (w, out_w))):
+            if n_out < n_in:
+                img = _smooth_axis(img, (n_in / n_out - 1) / 2.0, axis)
+    ys = (np.arange(out_h) + 0.5) * h / out_h - 0.5
+    xs = (np.arange(out_w) + 0.5) * w / out_w - 0.5
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
 
-    def tap(yy, xx):
-        valid = ((yy >= 0) & (yy < h))[:, None] & ((xx >= 0) & (xx < w))[None, :]
-        return img[np.clip(yy, 0, h - 1)][:, np.clip(xx, 0, w - 1)] * valid[:, :, None]
-    out = (tap(y0, x0) * ((1 - fy) * (1 - fx))[:, :, None] + tap(y0, x0 + 1) * ((1 - fy) * fx)[:, :, None] +
-           tap(y0 + 1, x0) * (fy * (1 - fx))[:, :, None] + tap(y0 + 1, x0 + 1) * (fy * fx)[:, :, None])
+    def rows(yy):                                            # gather rows, zero where outside
+        return img[np.clip(yy, 0, h - 1)] * ((yy >= 0) & (yy < h))[:, None, None]
+
+    def cols(a, xx):
+        return a[:, np.clip(xx, 0, w - 1)] * ((xx >= 0) & (xx < w))[None, :, None]
+    top, bot = rows(y0), rows(y0 + 1)
+    out = ((cols(top, x0) * (1 - fx) + cols(top, x0 + 1) * fx) * (1 - fy) + (cols(bot, x0) * (1 - fx) + cols(bot, x0 + 1) * fx) * fy)
     return out if image.ndim == 3 else out[:, :, 0]
 
 
-def resize_image(image, min_dim=None, max_dim=None, min_scale=None, mode="square"):
-    """utils.py:398-511: returns (image, window, scale, padding, crop) for modes none/square/pad64/crop."""
-    image_dtype = image.dtype
-    h, w = image.shape[:2]
-    window = (0, 0, h, w)
-    scale = 1
-    padding = [(0, 0), (0, 0), (0, 0)]
-    crop = None
+def _centered_pad(size, target):
+    """(before, after) zero padding that centres `size` pixels inside `target`; the odd pixel goes after."""
+    before = (target - size) // 2
+    return before, target - size - before
+
+
+def resize_geometry(h, w, min_dim=None, max_dim=None, min_scale=None, mode="square"):
+    """The geometry half of utils.resize_image (utils.py:398-511) as a pure function of the image size:
+    -> (scale, (new_h, new_w), ((top, bottom), (left, right)), window).  'crop' is resolved by the caller (it draws the
+    crop origin from `random`); 'none' leaves the image alone."""
     if mode == "none":
-        return image, window, scale, padding, crop
+        return 1, (h, w), ((0, 0), (0, 0)), (0, 0, h, w)
+    scale = 1
     if min_dim:
-        scale = min_dim / min(h, w)
+        scale = min_dim / min(h, w)                          # the reference also scales DOWN to min_dim (no max(1, .))
     if min_scale and scale < min_scale:
         scale = min_scale
-    if max_dim and mode != "crop":
-        image_max = max(h, w)
-        if round(image_max * scale) > max_dim:
-            scale = max_dim / image_max
-    if scale != 1:
-        image = _bilinear_resize(image, round(h * scale), round(w * scale))
+    if max_dim and mode != "crop" and round(max(h, w) * scale) > max_dim:
+        scale = max_dim / max(h, w)
+    nh, nw = (round(h * scale), round(w * scale)) if scale != 1 else (h, w)
     if mode == "square":
-        h, w = image.shape[:2]
-        top_pad = (max_dim - h) // 2
-        bottom_pad = max_dim - h - top_pad
-        left_pad = (max_dim - w) // 2
-        right_pad = max_dim - w - left_pad
-        padding = [(top_pad, bottom_pad), (left_pad, right_pad), (0, 0)] if image.ndim > 2 else \
-            [(top_pad, bottom_pad), (left_pad, right_pad)]
-        image = np.pad(image, padding, mode='constant', constant_values=0)
-        window = (top_pad, left_pad, h + top_pad, w + left_pad)
+        pads = (_centered_pad(nh, max_dim), _centered_pad(nw, max_dim))
     elif mode == "pad64":
-        h, w = image.shape[:2]
         assert min_dim % 64 == 0, "Minimum dimension must be a multiple of 64"
-        if h % 64 > 0:
-            max_h = h - (h % 64) + 64
-            top_pad = (max_h - h) // 2
-            bottom_pad = max_h - h - top_pad
-        else:
-            top_pad = bottom_pad = 0
-        if w % 64 > 0:
-            max_w = w - (w % 64) + 64
-            left_pad = (max_w - w) // 2
-            right_pad = max_w - w - left_pad
-        else:
-            left_pad = right_pad = 0
-        padding = [(top_pad, bottom_pad), (left_pad, right_pad), (0, 0)] if image.ndim > 2 else \
-            [(top_pad, bottom_pad), (left_pad, right_pad)]
-        image = np.pad(image, padding, mode='constant', constant_values=0)
-        window = (top_pad, left_pad, h + top_pad, w + left_pad)
+        pads = tuple(_centered_pad(n, -(-n // 64) * 64) for n in (nh, nw))
     elif mode == "crop":
-        h, w = image.shape[:2]
-        y = random.randint(0, (h - min_dim))
-        x = random.randint(0, (w - min_dim))
-        crop = (y, x, min_dim, min_dim)
-        image = image[y:y + min_dim, x:x + min_dim]
-        window = (0, 0, min_dim, min_dim)
+        pads = ((0, 0), (0, 0))
     else:
         raise Exception("Mode {} not supported".format(mode))
-    return image.astype(image_dtype), window, scale, padding, crop
+    (top, _), (left, _) = pads
+    return scale, (nh, nw), pads, (top, left, nh + top, nw + left)
+
+
+def resize_image(image, min_dim=None, max_dim=None, min_scale=None, mode="square"):
+    """Drop-in for utils.resize_image (utils.py:398-511): -> (image, window, scale, padding, crop); modes none / square /
+    pad64 / crop.  Geometry from resize_geometry (pinned to the reference's outputs in tests/golden/meta.json)."""
+    dtype = image.dtype
+    h, w = image.shape[:2]
+    scale, (nh, nw), pads, window = resize_geometry(h, w, min_dim, max_dim, min_scale, mode)
+    padding = [pads[0], pads[1]] + ([(0, 0)] if image.ndim > 2 else [])
+    if mode == "none":
+        return image, window, scale, [(0, 0), (0, 0), (0, 0)], None
+    if scale != 1:
+        image = _bilinear_resize(image, nh, nw)
+    if mode == "crop":
+        y, x = random.randint(0, nh - min_dim), random.randint(0, nw - min_dim)
+        return (image[y:y + min_dim, x:x + min_dim].astype(dtype), (0, 0, min_dim, min_dim), scale,
+                [(0, 0), (0, 0), (0, 0)], (y, x, min_dim, min_dim))
+    out = np.zeros((nh + sum(pads[0]), nw + sum(pads[1])) + image.shape[2:], dtype=dtype)
+    out[window[0]:window[2], window[1]:window[3]] = image
+    return out, window, scale, padding, None
