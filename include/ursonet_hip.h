@@ -334,6 +334,21 @@ int urso_encode_ori(int B, int K, const double* q_d, const float* hquat_d, const
                     float* out_d, void* stream);
 
 /*
+ * sim2real augmentation on the GPU (net.py:390-406; "next" scope row f-1): grey conversion and ONE stage of the reference's
+ * imgaug.Sequential(random_order=True) per call, on a uint8 batch [B,H,W,3] resident in HBM.  op_d[b] selects the stage applied
+ * to sample b in this call (-1 copy, 0 AdditiveGaussianNoise, 1 GaussianBlur, 2 Add, 3 Multiply, 4 CoarseDropout); par_d is
+ * fp32 [B][4] (noise sigma | blur sigma | add value | factor | dropout mask height, width), seed_d uint32 [B] (noise),
+ * drop_d uint8 [B][drop_stride] the coarse dropout masks (1 = drop).  src and dst must differ (the host ping-pongs).  The
+ * operators' arithmetic follows imgaug's documented behaviour on uint8 images (saturating, re-quantised after every stage);
+ * imgaug is not importable here, so there is no reference output to pin it to.
+ *   urso_pad_images_u8: resize_image's zero padding (utils.py:461-497) of a uint8 batch, on the device.
+ */
+int urso_rgb_to_grey3(int B, int H, int W, const uint8_t* src_d, uint8_t* dst_d, void* stream);
+int urso_sim2real_op(int B, int H, int W, const uint8_t* src_d, uint8_t* dst_d, const int32_t* op_d, const float* par_d,
+                     const uint32_t* seed_d, const uint8_t* drop_d, int drop_stride, void* stream);
+int urso_pad_images_u8(int B, int H, int W, int C, int OH, int OW, int top, int left, const uint8_t* src_d, uint8_t* dst_d, void* stream);
+
+/*
  * Opt-in launch profiler: when enabled every urso_* launch is bracketed by HIP events on
  * its stream.  urso_prof_collect() synchronises and returns per-record milliseconds.
  */

@@ -153,3 +153,102 @@ def test_load_image_gt_rotation_augmentation_keypoint_mode():
         assert np.array_equal(img, w) and np.allclose(loc, tn, atol=1e-12)
         assert np.asarray(k1).shape == (1, 3) and np.allclose(k1, r1.T, atol=1e-12) and np.allclose(k2, r2.T, atol=1e-12)
     assert hit >= 2
+
+
+# ------------------------------------------------------------------ sim2real stages (net.py:390-406)
+def _s2r_ref(img, code, par, mask):
+    """NumPy restatement of one urso_sim2real_op stage on a uint8 frame [H,W,3] (noise excluded: checked statistically)."""
+    f = img.astype(np.float32)
+    sat = lambda v: np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    if code == 2:
+        return sat(f + par[0])
+    if code == 3:
+        return sat(f * np.float32(par[0]))
+    if code == 4:
+        dh, dw = int(par[0]), int(par[1])
+        H, W = img.shape[:2]
+        my = np.minimum(np.arange(H) * dh // H, dh - 1); mx = np.minimum(np.arange(W) * dw // W, dw - 1)
+        return np.where(mask[my][:, mx][:, :, None], 0, img).astype(np.uint8)
+    if code == 1:
+        s = float(par[0])
+        if s < 1e-3:
+            return img.copy()
+        r = int(np.ceil(3 * s))
+        k = np.exp(-0.5 * (np.arange(-r, r + 1) / s) ** 2).astype(np.float32)
+        pad = np.pad(f, ((r, r), (r, r), (0, 0)), mode="reflect")
+        H, W = img.shape[:2]
+        acc = np.zeros_like(f); wsum = 0.0
+        for dy in range(2 * r + 1):
+            for dx in range(2 * r + 1):
+                w = k[dy] * k[dx]
+                acc += w * pad[dy:dy + H, dx:dx + W]; wsum += w
+        return sat(acc / wsum)
+    return img.copy()
+
+
+def test_sim2real_stages_against_numpy_restatement():
+    """urso_rgb_to_grey3 and the deterministic stages of urso_sim2real_op (blur / add / multiply / dropout / copy) vs NumPy;
+    the Gaussian-noise stage statistically (zero mean, sigma 2.55, identical on the three channels: per_channel=False)."""
+    import ursonet_amd.hip as hip
+    from ursonet_amd import augment as A
+    rng = np.random.default_rng(5)
+    B, H, W = 6, 40, 56
+    rgb = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    x = torch.as_tensor(rgb).cuda()
+    g = torch.empty_like(x)
+    hip.rgb_to_grey3(B, H, W, x, g)
+    grey = (0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]).astype(np.uint8)
+    assert np.array_equal(g.cpu().numpy(), np.repeat(grey[..., None], 3, -1))
+    codes = np.array([1, 2, 3, 4, -1, 1], dtype=np.int32)
+    par = np.zeros((B, 4), dtype=np.float32)
+    par[0, 0], par[1, 0], par[2, 0], par[5, 0] = 1.2, -17.0, 1.7, 0.0005
+    masks = rng.random((B, 3 * 5)) < 0.4
+    par[3, 0], par[3, 1] = 3, 5
+    out = torch.empty_like(g)
+    hip.sim2real_op(B, H, W, g, out, torch.as_tensor(codes).cuda(), torch.as_tensor(par).cuda(), torch.zeros(B, dtype=torch.int32, device="cuda"),
+                    torch.as_tensor(masks.astype(np.uint8)).cuda(), 15)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy(); gi = g.cpu().numpy()
+    for b in range(B):
+        ref = _s2r_ref(gi[b], int(codes[b]), par[b], masks[b].reshape(3, 5))
+        d = np.abs(o[b].astype(int) - ref.astype(int)).max()
+        assert d <= (1 if codes[b] == 1 else 0), (b, int(codes[b]), d)       # blur: fp32 summation order may move a .5 tie by one level
+    # noise
+    flat = torch.full((2, 64, 64, 3), 128, dtype=torch.uint8, device="cuda"); outn = torch.empty_like(flat)
+    hip.sim2real_op(2, 64, 64, flat, outn, torch.zeros(2, dtype=torch.int32, device="cuda"),
+                    torch.tensor([[2.55, 0, 0, 0]] * 2, dtype=torch.float32, device="cuda"),
+                    torch.tensor([11, 12], dtype=torch.int32, device="cuda"), None, 0)
+    n = outn.cpu().numpy().astype(np.float64) - 128
+    assert np.array_equal(n[..., 0], n[..., 1]) and np.array_equal(n[..., 0], n[..., 2])
+    assert abs(n.mean()) < 0.15 and 2.2 < n[..., 0].std() < 2.9 and not np.array_equal(n[0], n[1])
+    with pytest.raises(hip.UrsoHipError):
+        hip.sim2real_op(2, 64, 64, flat, flat, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(2, 4, device="cuda"),
+                        torch.zeros(2, dtype=torch.int32, device="cuda"), None, 0)
+
+
+def test_load_image_gt_sim2real_branch_end_to_end():
+    """net.load_image_gt with SIM2REAL_AUG (net.py:390-413): grey always; with the dice > 0.5 the five stages in the drawn order."""
+    from ursonet_amd import net, augment as A
+    from ursonet_amd.dataset import SyntheticPoses
+    cfg = make_config("resnet50", 64, 128, batch=2, regress_ori=True)
+    cfg.SIM2REAL_AUG = True
+    ds = SyntheticPoses(4, 64, 128, cfg, seed=4)
+    raw = ds.load_image(1)
+    np.random.seed(3)
+    d = A.sim2real_draw(1, 64, 128)
+    np.random.seed(3)
+    img, meta, loc, ori = net.load_image_gt(ds, cfg, 1)
+    assert img.shape == (64, 128, 3) and img.dtype == np.uint8 and np.array_equal(img[..., 0], img[..., 1])
+    grey = (0.2126 * raw[..., 0] + 0.7152 * raw[..., 1] + 0.0722 * raw[..., 2]).astype(np.uint8)
+    if not d["apply"][0]:
+        assert np.array_equal(img[..., 0], grey)
+    else:
+        assert not np.array_equal(img[..., 0], grey)
+    # the other dice outcome too
+    for seed in range(4, 12):
+        np.random.seed(seed)
+        if A.sim2real_draw(1, 64, 128)["apply"][0] != d["apply"][0]:
+            np.random.seed(seed)
+            img2 = net.load_image_gt(ds, cfg, 1)[0]
+            assert np.array_equal(img2[..., 0], grey) == bool(d["apply"][0])
+            break

@@ -182,9 +182,66 @@ def test_data_generator_and_mold_image():
     assert np.abs(net.unmold_image(imgs[0], cfg).astype(int) - raw.astype(int)).max() <= 1
     img, m, loc, ori = net.load_image_gt(ds, cfg, 2)
     assert m[0] == 2 and tuple(m[1:4]) == (64, 128, 3) and tuple(m[7:11]) == (0, 0, 64, 128)
-    cfg.SIM2REAL_AUG = True
-    with pytest.raises(NotImplementedError):
-        net.load_image_gt(ds, cfg, 0)
+    # keypoint mode yields five inputs (net.py:540-545)
+    cfgk = make_config("resnet18", 64, 128, batch=2, keypoints=True)
+    dsk = SyntheticPoses(5, 64, 128, cfgk, seed=2)
+    (imgs, meta, locs, k1, k2), _ = next(net.data_generator(dsk, cfgk, shuffle=False, batch_size=2))
+    assert imgs.shape == (2, 64, 128, 3) and k1.shape == (2, 3) and k2.shape == (2, 3)
+
+
+def test_data_generator_skips_up_to_five_bad_samples():
+    """net.py:553-559: a failing sample is logged and skipped; the sixth failure re-raises."""
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    cfg = make_config("resnet50", 64, 128, batch=2, regress_ori=True)
+
+    class Flaky(SyntheticPoses):
+        bad = {1, 2}
+
+        def load_image(self, image_id):
+            if int(image_id) in self.bad:
+                raise IOError("corrupt frame %d" % image_id)
+            return super(Flaky, self).load_image(image_id)
+    ds = Flaky(6, 64, 128, cfg, seed=3)
+    (imgs, meta, locs, oris), _ = next(net.data_generator(ds, cfg, shuffle=False, batch_size=2))
+    assert [int(m[0]) for m in meta] == [0, 3]                        # samples 1 and 2 were skipped
+    ds.bad = set(range(6))
+    with pytest.raises(RuntimeError):
+        next(net.data_generator(ds, cfg, shuffle=False, batch_size=2))
+
+
+def test_sim2real_draws_follow_the_reference_distributions():
+    """Host half of the sim2real branch (net.py:390-406): p = 0.5 dice, a permutation of the five stages, parameter ranges of the
+    imgaug operators -- CoarseDropout's p is a CHOICE between 0.0 and 0.03 (a list), its mask 2-10 % of the frame size."""
+    from ursonet_amd import augment
+    rng = np.random.RandomState(0)
+    d = augment.sim2real_draw(400, 480, 640, rng)
+    assert 0.4 < d["apply"].mean() < 0.6
+    assert all(sorted(o) == [0, 1, 2, 3, 4] for o in d["order"])
+    assert np.all(d["par"][:, 0, 0] == np.float32(2.55))
+    assert d["par"][:, 1, 0].min() >= 0 and d["par"][:, 1, 0].max() <= 1.5 and d["par"][:, 1, 0].std() > 0.3
+    assert set(np.unique(d["par"][:, 2, 0])) <= set(range(-20, 21)) and d["par"][:, 2, 0].min() < -15 and d["par"][:, 2, 0].max() > 15
+    assert d["par"][:, 3, 0].min() >= 0.5 and d["par"][:, 3, 0].max() <= 2.0
+    dh, dw = d["par"][:, 4, 0], d["par"][:, 4, 1]
+    assert dh.min() >= 9 and dh.max() <= 48 and dw.min() >= 12 and dw.max() <= 64
+    frac = np.array([m.mean() for m in d["masks"]])
+    assert (frac == 0).mean() > 0.3 and 0.01 < frac[frac > 0].mean() < 0.06
+
+
+def test_resize_antialiasing_and_identity():
+    """utils._bilinear_resize: identity at equal size; when shrinking, the Gaussian pre-filter (sigma = (s - 1)/2, skimage's
+    anti_aliasing default) keeps a one-pixel checkerboard from aliasing into a constant pattern of the wrong mean."""
+    from ursonet_amd import utils
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, size=(12, 16, 3)).astype(np.float64)
+    assert np.allclose(utils._bilinear_resize(img, 12, 16), img)
+    chk = (np.indices((64, 64)).sum(0) % 2 * 255.0)[:, :, None].repeat(3, 2)
+    aa = utils._bilinear_resize(chk, 32, 32)[4:-4, 4:-4]
+    noaa = utils._bilinear_resize(chk, 32, 32, anti_aliasing=False)[4:-4, 4:-4]
+    assert abs(aa.mean() - 127.5) < 2 and aa.std() < 12
+    assert noaa.std() < 1e-9 or noaa.std() > aa.std()                # point sampling: a constant (aliased) or high-contrast pattern
+    out, window, scale, padding, crop = utils.resize_image(chk.astype(np.uint8), min_dim=64, max_dim=64, min_scale=0, mode="square")
+    assert out.shape == (64, 64, 3) and scale == 1 and window == (0, 0, 64, 64)
 
 
 def test_augment_host_math_matches_reference_goldens():

@@ -83,3 +83,104 @@ def test_f16_config_runs_fp16_path():
     gl, go = eng.outputs()
     assert torch.isfinite(gl).all() and torch.isfinite(go).all()
     assert float((go.cpu() - ref_o).abs().max() / ref_o.abs().max()) < 5e-2
+
+
+def test_uint8_input_path_equals_molded_float_path():
+    """Engine.load_batch_u8 (mean subtraction inside urso_mold_images, net.py:1337-1348) gives bit-identical network inputs and
+    outputs to molding on the host; detect() takes that path for uint8 frames."""
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet18", 64, 128, batch=3, regress_ori=True, dtype="float32")
+    eng = Engine(cfg, "inference", seed=4, randomize_bn=True)
+    rng = np.random.default_rng(1)
+    u8 = rng.integers(0, 256, size=(3, 64, 128, 3), dtype=np.uint8)
+    eng.load_batch(u8.astype(np.float32) - np.asarray(cfg.MEAN_PIXEL, dtype=np.float32)); eng.forward(); torch.cuda.synchronize()
+    a = [t.clone() for t in eng.outputs()]
+    eng.load_batch_u8(u8); eng.forward(); torch.cuda.synchronize()
+    b = eng.outputs()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    eng.set_input_u8(False)
+    eng.load_batch(u8.astype(np.float32) - np.asarray(cfg.MEAN_PIXEL, dtype=np.float32)); eng.forward(); torch.cuda.synchronize()
+    assert torch.equal(a[0], eng.outputs()[0])
+
+
+def test_device_feeder_delivers_the_generator_batches_in_order():
+    """ursonet_amd.feeder.DeviceFeeder (pinned uint8 batches, side-stream upload, double buffer) must put exactly the batches of
+    the reference-format generator into the engine, in order -- frames (after the device-side mean subtraction) and targets."""
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    from ursonet_amd.engine import Engine
+    from ursonet_amd.feeder import DeviceFeeder
+    cfg = make_config("resnet18", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype="float32")
+    ds = SyntheticPoses(10, 64, 128, cfg, seed=7)
+    eng = Engine(cfg, "training", seed=1)
+    feed = DeviceFeeder(eng, ds, cfg, shuffle=False, workers=3)
+    gen = net.data_generator(ds, cfg, shuffle=False, batch_size=4)
+    mean = torch.tensor(np.asarray(cfg.MEAN_PIXEL, dtype=np.float32), device="cuda")
+    for _ in range(4):
+        (imgs, meta, locs, oris), _o = next(gen)
+        feed.next_into()
+        torch.cuda.synchronize()
+        assert float((eng.in_images_u8.float() - mean - torch.as_tensor(imgs).cuda()).abs().max()) < 1e-4      # float64 vs float32 mean subtraction
+        assert torch.equal(eng.gt_loc.cpu(), torch.as_tensor(locs)) and torch.equal(eng.gt_ori.cpu(), torch.as_tensor(oris))
+        eng.step()
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in eng.losses().values())
+    feed.close()
+
+
+def test_keras_h5_weight_files_through_a_stand_in_h5py(tmp_path, monkeypatch):
+    """load_weights / save_weights on Keras .h5 files (net.py:816-852): h5py is not installed in this image, so the branch is
+    executed against a minimal in-memory stand-in that implements the h5py calls it makes (File, attrs, groups, datasets): the
+    layer_names / weight_names attributes (bytes), the nested 'model_weights' group of full-model files and by-name matching."""
+    import sys
+    import types
+    from ursonet_amd import net
+    store = {}
+
+    class Node(dict):
+        def __init__(self):
+            super(Node, self).__init__()
+            self.attrs = {}
+
+        def create_group(self, name):
+            self[name] = Node(); return self[name]
+
+        def create_dataset(self, name, data):
+            self[name] = np.array(data)
+
+    class File(Node):
+        def __init__(self, path, mode="r"):
+            super(File, self).__init__()
+            self.path, self.mode = path, mode
+            if mode == "r":
+                root = store[path]
+                self.update(root); self.attrs = root.attrs
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            if self.mode == "w":
+                store[self.path] = self
+            return False
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    cfg = make_config("resnet18", 64, 64, batch=1, regress_ori=True, dtype="float32")
+    cfg.NAME = "h5"
+    m = net.UrsoNet(mode="inference", config=cfg, model_dir=str(tmp_path))
+    w0 = m._engine.get_weights()
+    path = str(tmp_path / "weights_h5_0001.h5")
+    written = net.write_weights_file(path, w0)
+    assert path in written and path in store
+    f = store[path]
+    assert f.attrs["layer_names"][0] == b"conv0" and f["conv0"].attrs["weight_names"][0] == b"conv0/kernel:0"
+    back = net.read_weights_file(path)
+    assert all(np.array_equal(back[l][w], w0[l][w]) for l in w0 for w in w0[l])
+    # a full-model file keeps the layers under 'model_weights' (net.py:831-832)
+    nested = Node(); nested["model_weights"] = store[path]; store["nested.h5"] = nested
+    back2 = net.read_weights_file("nested.h5")
+    assert list(back2) == list(w0)
+    m2 = net.UrsoNet(mode="inference", config=cfg, model_dir=str(tmp_path))
+    m2._engine.set_weights({l: {w: np.zeros_like(a) for w, a in ws.items()} for l, ws in w0.items()})
+    m2.load_weights(path, path, by_name=True)
+    w2 = m2._engine.get_weights()
+    assert all(np.array_equal(w2[l][w], w0[l][w]) for l in w0 for w in w0[l])

@@ -158,3 +158,62 @@ def rotate_image(image, t, q, K):
     change = (np.random.rand(1) - 0.5) * 170
     w, tn, qn = rotate_cam_batch(np.asarray(image)[None], t, q, K, np.array([[0.0, 0.0, change[0]]]))
     return w[0].cpu().numpy(), tn[0], qn[0]
+
+
+# --------------------------------------------------------------------------- sim2real (net.py:390-406)
+SIM2REAL_OPS = ("noise", "blur", "add", "multiply", "dropout")
+
+
+def sim2real_draw(n, height, width, rng=np.random):
+    """The random decisions of the reference's sim2real branch for `n` samples, drawn sample by sample from `rng` (NumPy's global
+    generator by default, like net.py:395 and imgaug's seeding from it): whether the pipeline runs (p = 0.5), the random order of its
+    five stages and each stage's parameter -- AdditiveGaussianNoise(scale=0.01*255), GaussianBlur(sigma=(0, 1.5)), Add((-20, 20)),
+    Multiply((0.5, 2.0)), CoarseDropout([0.0, 0.03], size_percent=(0.02, 0.1)).  Returns a dict of arrays."""
+    apply = np.zeros(n, dtype=bool)
+    order = np.tile(np.arange(5), (n, 1))
+    par = np.zeros((n, 5, 4), dtype=np.float32)
+    seeds = np.zeros(n, dtype=np.uint32)
+    masks = []
+    for i in range(n):
+        apply[i] = rng.rand(1)[0] > 0.5
+        order[i] = rng.permutation(5)
+        par[i, 0, 0] = 0.01 * 255
+        par[i, 1, 0] = rng.uniform(0.0, 1.5)
+        par[i, 2, 0] = float(rng.randint(-20, 21))
+        par[i, 3, 0] = rng.uniform(0.5, 2.0)
+        p = (0.0, 0.03)[rng.randint(0, 2)]                  # a LIST of two values is a choice in imgaug, not a range
+        sp = rng.uniform(0.02, 0.1)
+        dh, dw = max(int(height * sp), 1), max(int(width * sp), 1)
+        par[i, 4, 0], par[i, 4, 1] = dh, dw
+        masks.append(rng.rand(dh, dw) < p)
+        seeds[i] = rng.randint(0, 2 ** 31 - 1)
+    return {"apply": apply, "order": order, "par": par, "seeds": seeds, "masks": masks}
+
+
+def sim2real_batch(images, draw=None, rng=np.random):
+    """net.py:390-406 for a uint8 batch [B,H,W,3] (array or device tensor): grey conversion, then for the samples whose dice say
+    so the five imgaug stages in their drawn order -- five passes of urso_sim2real_op over the batch, ping-ponging two HBM
+    buffers.  Returns a uint8 CUDA tensor."""
+    import torch
+    from . import hip
+    x = torch.as_tensor(images)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] == 3
+    x = x.cuda().contiguous()
+    B, H, W, _ = x.shape
+    d = draw if draw is not None else sim2real_draw(B, H, W, rng)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    hip.rgb_to_grey3(B, H, W, x, a)
+    if not d["apply"].any():
+        return a
+    stride = max(m.size for m in d["masks"])
+    drop = np.zeros((B, stride), dtype=np.uint8)
+    for i, m in enumerate(d["masks"]):
+        drop[i, :m.size] = m.reshape(-1)
+    drop_d = torch.as_tensor(drop).cuda()
+    seed_d = torch.as_tensor(d["seeds"].view(np.int32).copy()).cuda()
+    for slot in range(5):
+        ops = np.where(d["apply"], d["order"][:, slot], -1).astype(np.int32)
+        par = np.stack([d["par"][i, d["order"][i, slot]] for i in range(B)]).astype(np.float32)
+        hip.sim2real_op(B, H, W, a, b, torch.as_tensor(ops).cuda(), torch.as_tensor(par).cuda(), seed_d, drop_d, stride)
+        a, b = b, a
+    return a

@@ -99,3 +99,109 @@ extern "C" int urso_encode_ori(int B, int K, const double* q_d, const float* hqu
     hipLaunchKernelGGL(encode_ori_kernel, dim3(B), dim3(256), 0, st, K, q_d, hquat_d, redundant_d, var, out_d);
     return urso_check_launch("urso_encode_ori");
 }
+
+// ---------------------------------------------------------------- sim2real augmentation (net.py:390-406)
+// The reference converts the frame to grey (0.2126 R + 0.7152 G + 0.0722 B written back into the uint8 channels) and, half of the
+// time, runs imgaug.Sequential([AdditiveGaussianNoise(0.01*255), GaussianBlur((0, 1.5)), Add((-20, 20)), Multiply((0.5, 2.0)),
+// CoarseDropout([0.0, 0.03], size_percent=(0.02, 0.1))], random_order=True).  imgaug / OpenCV are not available (and their
+// random streams could not be reproduced anyway), so this is a restatement of the five operators' documented arithmetic on
+// uint8 images -- every operator reads uint8 and writes uint8 with saturation, as imgaug does between the stages of a Sequential --
+// with the random parameters drawn by the host (ursonet_amd/augment.py): "parity unpinned" for this part.
+__global__ void grey3_kernel(size_t npix, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t* p = src + i * 3;
+        const double g = 0.2126 * p[0] + 0.7152 * p[1] + 0.0722 * p[2];       // float64, truncated by the uint8 assignment (net.py:391-394)
+        const uint8_t v = (uint8_t)g;
+        dst[i * 3] = v; dst[i * 3 + 1] = v; dst[i * 3 + 2] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t s2r_hash(uint32_t x) {            // lowbias32
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ uint8_t s2r_sat(float v) {                 // round half to even + saturate, as np.clip(np.round(.), 0, 255)
+    return (uint8_t)fminf(fmaxf(rintf(v), 0.f), 255.f);
+}
+
+// op codes: -1 copy, 0 additive Gaussian noise (par0 = sigma; same sample on the three channels: per_channel=False), 1 Gaussian blur
+// (par0 = sigma, reflect-101 border, radius ceil(3 sigma)), 2 add (par0 = integer value), 3 multiply (par0 = factor), 4 coarse dropout
+// (par0, par1 = mask height / width; nearest-neighbour upsampling of drop[b][dh][dw]).
+__global__ void sim2real_op_kernel(int H, int W, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int32_t* __restrict__ op,
+                                   const float* __restrict__ par, const uint32_t* __restrict__ seed, const uint8_t* __restrict__ drop, int dmax) {
+    const int b = blockIdx.y;
+    const int code = op[b];
+    const float p0 = par[b * 4], p1 = par[b * 4 + 1];
+    const size_t base = (size_t)b * H * W * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const uint8_t* p = src + base + (size_t)i * 3;
+        uint8_t* o = dst + base + (size_t)i * 3;
+        if (code == 0) {
+            const uint32_t h1 = s2r_hash(seed[b] ^ (uint32_t)i * 2u + 1u), h2 = s2r_hash(h1 ^ 0x9e3779b9u ^ (uint32_t)i);
+            const float u1 = ((h1 >> 8) + 1) * (1.0f / 16777217.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);
+            const float n = p0 * sqrtf(-2.f * logf(u1)) * cosf(6.283185307f * u2);
+            for (int c = 0; c < 3; ++c) o[c] = s2r_sat((float)p[c] + n);
+        } else if (code == 1) {
+            if (p0 < 1e-3f) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; continue; }
+            const int r = (int)ceilf(3.f * p0), y = i / W, x = i - y * W;
+            float acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+            for (int dy = -r; dy <= r; ++dy) {
+                int yy = y + dy; yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy); yy = min(max(yy, 0), H - 1);
+                const float wy = expf(-0.5f * dy * dy / (p0 * p0));
+                for (int dx = -r; dx <= r; ++dx) {
+                    int xx = x + dx; xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx); xx = min(max(xx, 0), W - 1);
+                    const float w = wy * expf(-0.5f * dx * dx / (p0 * p0));
+                    const uint8_t* q = src + base + ((size_t)yy * W + xx) * 3;
+                    acc[0] += w * q[0]; acc[1] += w * q[1]; acc[2] += w * q[2]; wsum += w;
+                }
+            }
+            for (int c = 0; c < 3; ++c) o[c] = s2r_sat(acc[c] / wsum);
+        } else if (code == 2) {
+            for (int c = 0; c < 3; ++c) o[c] = s2r_sat((float)p[c] + p0);
+        } else if (code == 3) {
+            for (int c = 0; c < 3; ++c) o[c] = s2r_sat((float)p[c] * p0);
+        } else if (code == 4) {
+            const int dh = (int)p0, dw = (int)p1, y = i / W, x = i - y * W;
+            const int my = min((int)((long long)y * dh / H), dh - 1), mx = min((int)((long long)x * dw / W), dw - 1);
+            const bool dr = drop && drop[(size_t)b * dmax + my * dw + mx];
+            for (int c = 0; c < 3; ++c) o[c] = dr ? 0 : p[c];
+        } else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+    }
+}
+
+extern "C" int urso_rgb_to_grey3(int B, int H, int W, const uint8_t* src_d, uint8_t* dst_d, void* stream) {
+    if (!src_d || !dst_d || B <= 0 || H <= 0 || W <= 0) { urso_set_error("urso_rgb_to_grey3: bad argument"); return URSO_EINVAL; }
+    const size_t npix = (size_t)B * H * W;
+    int blocks = (int)((npix + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(grey3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, npix, src_d, dst_d);
+    return urso_check_launch("urso_rgb_to_grey3");
+}
+
+extern "C" int urso_sim2real_op(int B, int H, int W, const uint8_t* src_d, uint8_t* dst_d, const int32_t* op_d, const float* par_d,
+                                const uint32_t* seed_d, const uint8_t* drop_d, int drop_stride, void* stream) {
+    if (!src_d || !dst_d || !op_d || !par_d || !seed_d || src_d == dst_d || B <= 0 || H <= 0 || W <= 0 || drop_stride < 0) {
+        urso_set_error("urso_sim2real_op: bad argument (src and dst must differ)"); return URSO_EINVAL;
+    }
+    int bx = (H * W + 255) / 256; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(sim2real_op_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, src_d, dst_d, op_d, par_d, seed_d, drop_d, drop_stride);
+    return urso_check_launch("urso_sim2real_op");
+}
+
+// resize_image's zero padding (utils.py:461-497) for a whole uint8 batch on the device: dst [B,OH,OW,C] = 0 outside the window, src
+// [B,H,W,C] placed at (top, left).  With image_scale 1 this IS the reference's resize step.
+__global__ void place_kernel(int H, int W, int C, int OH, int OW, int top, int left, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
+    const int b = blockIdx.y;
+    const size_t n = (size_t)OH * OW * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), x = (int)((i / C) % OW) - left, y = (int)(i / ((size_t)C * OW)) - top;
+        dst[(size_t)b * n + i] = ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? src[(((size_t)b * H + y) * W + x) * C + c] : (uint8_t)0;
+    }
+}
+extern "C" int urso_pad_images_u8(int B, int H, int W, int C, int OH, int OW, int top, int left, const uint8_t* src_d, uint8_t* dst_d, void* stream) {
+    if (!src_d || !dst_d || B <= 0 || H <= 0 || W <= 0 || C <= 0 || top < 0 || left < 0 || top + H > OH || left + W > OW) {
+        urso_set_error("urso_pad_images_u8: bad argument"); return URSO_EINVAL;
+    }
+    const size_t n = (size_t)OH * OW * C;
+    int bx = (int)((n + 255) / 256); if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(place_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, C, OH, OW, top, left, src_d, dst_d);
+    return urso_check_launch("urso_pad_images_u8");
+}

@@ -165,10 +165,18 @@ class Engine(object):
             return self.acts[spec.id]
 
         # ---- inputs
+        # two input forms: molded float32 frames (the reference's generator format) or raw uint8 frames whose mean subtraction
+        # (mold_image, net.py:1337-1348) happens in the molding kernel -- 4x fewer bytes over PCIe (ursonet_amd/feeder.py)
         self.in_images = torch.zeros(B, self.H, self.W, 3, dtype=torch.float32, device=dev)
+        if not hasattr(self, "input_u8"):
+            self.input_u8 = False
+            self.in_images_u8 = None
+        mp = np.asarray(cfg.MEAN_PIXEL, dtype=np.float32)
+        self.mean3 = torch.tensor(mp if mp.size == 3 else np.full(3, float(mp.mean()), dtype=np.float32), device=dev)
         img_spec = g.tensors[0]
         x0 = act(img_spec, B * self.H * self.W * 4)               # channels padded 3 -> 4, viewed as pixel pairs
-        self.fwd_ops.append(lambda: hip.mold_images(B, self.H, self.W, self.in_images, None, dt, x0.data))
+        self.fwd_ops.append(lambda: hip.mold_images(B, self.H, self.W, self.in_images_u8 if self.input_u8 else self.in_images,
+                                                    self.mean3 if self.input_u8 else None, dt, x0.data))
         self.labels["fwd"].append("mold")
 
         max_ws = 0
@@ -636,6 +644,24 @@ class Engine(object):
             self.gt_ori.copy_(torch.as_tensor(gt_ori, dtype=torch.float32).reshape(self.gt_ori.shape), non_blocking=True)
         if gt_k3 is not None:
             self.gt_k3.copy_(torch.as_tensor(gt_k3, dtype=torch.float32).reshape(self.gt_k3.shape), non_blocking=True)
+
+    def set_input_u8(self, on=True):
+        """Switch the first kernel between molded float32 input (load_batch) and raw uint8 input (load_batch_u8)."""
+        on = bool(on)
+        if on and self.in_images_u8 is None:
+            self.in_images_u8 = torch.zeros(self.B, self.H, self.W, 3, dtype=torch.uint8, device=self.device)
+        if on != self.input_u8:
+            self.input_u8 = on
+            self._graphs = None                    # the captured graph holds the other buffer's address
+
+    def load_batch_u8(self, images_u8, gt_loc=None, gt_ori=None, gt_k3=None):
+        """Raw uint8 frames [B,H,W,3] (host array or device tensor, already resized / padded to the model size) + targets;
+        device tensors are copied device-to-device on the current stream."""
+        self.set_input_u8(True)
+        self.in_images_u8.copy_(torch.as_tensor(images_u8).reshape(self.in_images_u8.shape), non_blocking=True)
+        for buf, src in ((getattr(self, "gt_loc", None), gt_loc), (getattr(self, "gt_ori", None), gt_ori), (getattr(self, "gt_k3", None), gt_k3)):
+            if src is not None and buf is not None:
+                buf.copy_(torch.as_tensor(src).reshape(buf.shape), non_blocking=True)
 
     def outputs(self):
         """(loc [B, n_loc], ori [B, n_ori]) as fp32 device tensors (raw network outputs, net.py:1254-1258)."""

@@ -104,6 +104,9 @@ _SIGS = {
     "urso_quat_wavg_decode": (_i, [_i, _i, _fp, _fp, _fp, _fp, _vp]),
     "urso_warp_perspective": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "urso_encode_ori": (_i, [_i, _i, _vp, _fp, _vp, C.c_double, _fp, _vp]),
+    "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
+    "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_prof_enable": (_i, [_i]),
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
 }
@@ -379,6 +382,23 @@ def warp_perspective(B, H, W, Cc, interp, src, m, dst, stream=None):
 def encode_ori(B, K, q, hquat, redundant, var, out, stream=None):
     assert q.dtype == torch.float64 and redundant.dtype == torch.uint8
     _chk(_lib.urso_encode_ori(B, K, ptr(q), ptr(hquat), ptr(redundant), float(var), ptr(out), stream_ptr(stream)), "urso_encode_ori")
+
+
+def rgb_to_grey3(B, H, W, src, dst, stream=None):
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8
+    _chk(_lib.urso_rgb_to_grey3(B, H, W, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rgb_to_grey3")
+
+
+def sim2real_op(B, H, W, src, dst, op, par, seed, drop, drop_stride, stream=None):
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and op.dtype == torch.int32 and par.dtype == torch.float32
+    assert seed.dtype == torch.int32, "seeds are passed as the bit pattern of uint32 in an int32 tensor"
+    _chk(_lib.urso_sim2real_op(B, H, W, ptr(src), ptr(dst), ptr(op), ptr(par), ptr(seed), ptr(drop), int(drop_stride), stream_ptr(stream)),
+         "urso_sim2real_op")
+
+
+def pad_images_u8(B, H, W, Cc, OH, OW, top, left, src, dst, stream=None):
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8
+    _chk(_lib.urso_pad_images_u8(B, H, W, Cc, OH, OW, int(top), int(left), ptr(src), ptr(dst), stream_ptr(stream)), "urso_pad_images_u8")
 
 
 def prof_enable(on):

@@ -97,100 +97,23 @@ def unmold_image(normalized_images, config):
 #  Data generator (net.py:358-559)
 ############################################################
 def load_image_gt(dataset, config, image_id):
-    """Image + pose targets for one sample (net.py:363-461).  ROT_AUG / ROT_IMAGE_AUG warp on the GPU;
-    SIM2REAL_AUG (imgaug) raises instead of silently training on un-augmented data."""
-    image = dataset.load_image(image_id)
-    loc = dataset.load_location(image_id) if config.REGRESS_LOC else dataset.load_location_encoded(image_id)
+    """Image + pose targets for one sample (net.py:363-461): raw sample -> augmentation (sim2real stages and the camera /
+    in-plane rotation warps run on the GPU, same NumPy global-RNG draws as the reference) -> resize / pad -> image_meta.
+    Returns (image, image_meta, loc, ori), or (image, image_meta, loc, k1, k2) in keypoint mode."""
+    from . import feeder
+    s = feeder.augment_samples([feeder.load_sample(dataset, config, image_id)], dataset, config)[0]
+    image, image_meta = feeder.finish_sample(s, config)
     if config.REGRESS_KEYPOINTS:
-        keypoints = dataset.load_keypoints(image_id)
-        k1, k2 = keypoints[0], keypoints[1]
-    if config.REGRESS_KEYPOINTS or config.REGRESS_ORI:
-        if config.ORIENTATION_PARAM == 'quaternion':
-            ori = dataset.load_quaternion(image_id)
-        elif config.ORIENTATION_PARAM == 'euler_angles':
-            ori = dataset.load_euler_angles(image_id)
-        elif config.ORIENTATION_PARAM == 'angle_axis':
-            ori = dataset.load_angle_axis(image_id)
-    else:
-        ori = dataset.load_orientation_encoded(image_id)
-    if config.SIM2REAL_AUG:
-        raise NotImplementedError("SIM2REAL_AUG (imgaug pipeline, net.py:390-413) is not implemented in this build")
-    if config.ROT_AUG or config.ROT_IMAGE_AUG:
-        # net.py:415-438: camera-rotation / in-plane-rotation warps (mutually exclusive, one dice throw); the warp and
-        # the target re-encode run on the GPU (ursonet_amd.augment), same NumPy global-RNG draws as the reference
-        assert config.REGRESS_LOC
-        assert config.ORIENTATION_PARAM == 'quaternion'
-        from . import augment
-        dice = np.random.rand(1)
-        which = "cam" if (config.ROT_AUG and dice > 0.5) else ("image" if (config.ROT_IMAGE_AUG and dice <= 0.5) else None)
-        if which is not None:
-            if not (config.REGRESS_ORI or config.REGRESS_KEYPOINTS):
-                ori = dataset.load_quaternion(image_id)
-            if which == "cam":
-                image, loc, ori = augment.rotate_cam(image, loc, ori, dataset.camera.K, 20)
-            else:
-                image, loc, ori = augment.rotate_image(image, loc, ori, dataset.camera.K)
-            if config.REGRESS_KEYPOINTS:
-                k1, k2 = augment.encode_as_keypoints(ori, loc)          # net.py:424, 433: keypoints follow the rotated pose
-            elif not config.REGRESS_ORI:
-                ori = augment.encode_orientations(ori, dataset.ori_histogram_map, dataset.ori_output_mask, config.BETA)[0].cpu().numpy()
-    original_shape = image.shape
-    image, window, scale, padding, crop = utils.resize_image(
-        image, min_dim=config.IMAGE_MIN_DIM, min_scale=config.IMAGE_MIN_SCALE, max_dim=config.IMAGE_MAX_DIM,
-        mode=config.IMAGE_RESIZE_MODE)
-    image_meta = compose_image_meta(image_id, original_shape, image.shape, window, scale)
-    if config.REGRESS_KEYPOINTS:
-        return image, image_meta, loc, k1.T, k2.T
-    return image, image_meta, loc, ori
+        return image, image_meta, s.loc, np.asarray(s.k1).T, np.asarray(s.k2).T
+    return image, image_meta, s.loc, s.ori
 
 
 def data_generator(dataset, config, shuffle=True, batch_size=1):
-    """Yields ([images, image_meta, gt_locs, gt_oris], []) forever; tolerates <= 5 bad samples."""
-    b, image_index, error_count = 0, -1, 0
-    image_ids = np.copy(dataset.image_ids)
-    dt = np.float16 if config.F16 else np.float32
-    while True:
-        try:
-            image_index = (image_index + 1) % len(image_ids)
-            if shuffle and image_index == 0:
-                np.random.shuffle(image_ids)
-            image_id = image_ids[image_index]
-            if config.REGRESS_KEYPOINTS:
-                image, image_meta, gt_loc, gt_k1, gt_k2 = load_image_gt(dataset, config, image_id)
-            else:
-                image, image_meta, gt_loc, gt_ori = load_image_gt(dataset, config, image_id)
-            if b == 0:
-                batch_image_meta = np.zeros((batch_size,) + image_meta.shape, dtype=image_meta.dtype)
-                batch_images = np.zeros((batch_size,) + image.shape, dtype=dt)
-                batch_gt_locs = np.zeros((batch_size, 3 if config.REGRESS_LOC else config.LOC_BINS_PER_DIM ** 3), dtype=dt)
-                if config.REGRESS_KEYPOINTS:
-                    batch_gt_k1 = np.zeros((batch_size, 3), dtype=dt)
-                    batch_gt_k2 = np.zeros((batch_size, 3), dtype=dt)
-                elif config.REGRESS_ORI:
-                    batch_gt_oris = np.zeros((batch_size, 4 if config.ORIENTATION_PARAM == 'quaternion' else 3), dtype=dt)
-                else:
-                    batch_gt_oris = np.zeros((batch_size, config.ORI_BINS_PER_DIM ** 3), dtype=dt)
-            batch_image_meta[b] = image_meta
-            batch_images[b] = mold_image(image.astype(dt), config)
-            batch_gt_locs[b] = gt_loc
-            if config.REGRESS_KEYPOINTS:
-                batch_gt_k1[b], batch_gt_k2[b] = gt_k1, gt_k2
-            else:
-                batch_gt_oris[b] = gt_ori
-            b += 1
-            if b >= batch_size:
-                if config.REGRESS_KEYPOINTS:
-                    yield [batch_images, batch_image_meta, batch_gt_locs, batch_gt_k1, batch_gt_k2], []
-                else:
-                    yield [batch_images, batch_image_meta, batch_gt_locs, batch_gt_oris], []
-                b = 0
-        except (GeneratorExit, KeyboardInterrupt):
-            raise
-        except Exception:
-            logging.exception("Error processing image {}".format(dataset.image_info[image_id]))
-            error_count += 1
-            if error_count > 5:
-                raise
+    """net.py:463-559: yields ([molded images, image_meta, gt_loc, gt_ori], []) forever (keypoint mode: gt_loc, gt_k1, gt_k2);
+    tolerates up to 5 failing samples.  Built on ursonet_amd.feeder (pre-allocated per-field batch arrays, batched augmentation)."""
+    from . import feeder
+    for asm in feeder.batches(dataset, config, shuffle, batch_size, molded=True):
+        yield asm.inputs(), []
 
 
 ############################################################
@@ -373,8 +296,12 @@ class UrsoNet(object):
         assert self.mode == "training", "Create model in training mode."
         layers = _layer_regex(layers)
         cfg, eng = self.config, self._engine
-        train_generator = data_generator(train_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
-        val_generator = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
+        # the reference hands Keras two Python generators and `workers = cpu_count` processes (net.py:1100-1163); here a producer
+        # thread + loader threads assemble uint8 batches in pinned memory and a side stream uploads batch k+1 while step k runs
+        from .feeder import DeviceFeeder
+        workers = int(getattr(cfg, "LOADER_WORKERS", min(8, os.cpu_count() or 1)))
+        train_feed = DeviceFeeder(eng, train_dataset, cfg, shuffle=True, workers=workers)
+        val_feed = DeviceFeeder(eng, val_dataset, cfg, shuffle=True, workers=workers) if int(cfg.VALIDATION_STEPS) > 0 else None
         history_full = BatchLogger()
         log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
         log("Checkpoint Path: {}".format(self.checkpoint_path))
@@ -384,75 +311,88 @@ class UrsoNet(object):
         clr_it = 0
         for epoch in range(self.epoch, epochs):
             for _ in range(int(cfg.STEPS_PER_EPOCH)):
-                inputs, _o = next(train_generator)
                 if cfg.CLR:
                     eng.set_lr(utils.clr_triangular(clr_it, cfg.BASE_LEARNING_RATE, cfg.MAX_LEARNING_RATE, cfg.CLR_STEP_SIZE))
                     clr_it += 1
-                eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
+                train_feed.next_into()
                 eng.step()
                 ls = eng.losses()
                 history_full.ori_loss_acc.append(ls.get("ori_loss"))      # None in keypoint mode, as logs.get('ori_loss') is (net.py:1112)
                 history_full.loc_loss_acc.append(ls["loc_loss"])
-                last_train = ls
             val = {}
             for _ in range(int(cfg.VALIDATION_STEPS)):
-                inputs, _o = next(val_generator)
-                eng.load_batch(inputs[0], inputs[2], inputs[3], inputs[4] if cfg.REGRESS_KEYPOINTS else None)
+                val_feed.next_into()
                 for k, v in eng.evaluate().items():
                     val.setdefault(k, []).append(v)
             log("epoch %d  loc_loss %.5f  %s" % (
                 epoch + 1, float(np.mean(history_full.loc_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
                 "  ".join("val_%s %.5f" % (k, float(np.mean(v))) for k, v in sorted(val.items()))))
             self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))
+        train_feed.close()
+        if val_feed is not None:
+            val_feed.close()
         self.epoch = max(self.epoch, epochs)
         return history_full
 
     # ---------------------------------------------------------------- inference
-    def mold_inputs(self, images):
-        """net.py:1169-1205."""
-        molded_images, image_metas, windows = [], [], []
+    def _resized(self, images):
+        """resize / pad every frame to the model's input geometry (utils.resize_image) -> [(uint8 frame, window, scale)]."""
+        cfg = self.config
+        out = []
         for image in images:
-            molded_image, window, scale, padding, crop = utils.resize_image(
-                image, min_dim=self.config.IMAGE_MIN_DIM, min_scale=self.config.IMAGE_MIN_SCALE,
-                max_dim=self.config.IMAGE_MAX_DIM, mode=self.config.IMAGE_RESIZE_MODE)
-            molded_image = mold_image(molded_image, self.config)
-            image_metas.append(compose_image_meta(0, image.shape, molded_image.shape, window, scale))
-            molded_images.append(molded_image)
-            windows.append(window)
-        return np.stack(molded_images), np.stack(image_metas), np.stack(windows)
+            frame, window, scale, _pad, _crop = utils.resize_image(image, min_dim=cfg.IMAGE_MIN_DIM, min_scale=cfg.IMAGE_MIN_SCALE,
+                                                                   max_dim=cfg.IMAGE_MAX_DIM, mode=cfg.IMAGE_RESIZE_MODE)
+            out.append((frame, window, scale))
+        return out
+
+    def mold_inputs(self, images):
+        """net.py:1169-1205: (molded images [N,h,w,3], image metas [N,12], windows [N,4])."""
+        frames = self._resized(images)
+        molded = np.stack([mold_image(f, self.config) for f, _, _ in frames])
+        metas = np.stack([compose_image_meta(0, im.shape, f.shape, w, s) for im, (f, w, s) in zip(images, frames)])
+        return molded, metas, np.stack([w for _, w, _ in frames])
 
     def _predict(self, molded_images):
-        import torch
+        """keras_model.predict on molded float images -> list of raw output arrays."""
         eng = self._engine
         assert molded_images.shape[0] == eng.B, "batch %d != engine batch %d" % (molded_images.shape[0], eng.B)
+        eng.set_input_u8(False)
         eng.load_batch(molded_images.astype(np.float32))
+        return self._outputs_after_forward()
+
+    def _outputs_after_forward(self):
+        import torch
+        eng = self._engine
         eng.forward()
-        loc, ori = eng.outputs()
+        loc, rest = eng.outputs()
         torch.cuda.synchronize()
         if self.config.REGRESS_KEYPOINTS:
-            g = self._graph
-            ks = [eng.acts[g.outputs[k].id].data.view(eng.B, -1)[:, :3].cpu().numpy() for k in ("k1", "k2", "k3")]
-            return ks
-        return [loc.cpu().numpy(), ori.cpu().numpy()]
+            return [loc.cpu().numpy()] + [k.cpu().numpy() for k in rest]
+        return [loc.cpu().numpy(), rest.cpu().numpy()]
 
     def detect(self, images, verbose=0):
-        """net.py:1207-1259: list of {'loc', 'ori'} (or {'loc','k1','k2'}) dicts with the RAW network outputs."""
+        """net.py:1207-1259: one dict of RAW network outputs per image -- {'loc', 'ori'}, or {'loc', 'k1', 'k2'} in keypoint mode
+        (the reference's key names for the three keypoint heads).  uint8 frames take the device path: they are padded on the host,
+        uploaded as uint8 and mean-subtracted by the first kernel; anything else goes through mold_inputs / predict."""
         assert self.mode == "inference", "Create model in inference mode."
         assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
         if verbose:
             log("Processing {} images".format(len(images)))
             for image in images:
                 log("image", image)
-        molded_images, image_metas, windows = self.mold_inputs(images)
-        image_shape = molded_images[0].shape
-        for g in molded_images[1:]:
-            assert g.shape == image_shape, \
+        if all(getattr(im, "dtype", None) == np.uint8 and im.ndim == 3 and im.shape[-1] == 3 for im in images):
+            frames = [f for f, _, _ in self._resized(images)]
+            assert all(f.shape == frames[0].shape for f in frames), \
                 "After resizing, all images must have the same size. Check IMAGE_RESIZE_MODE and image sizes."
-        if verbose:
-            log("molded_images", molded_images)
-            log("image_metas", image_metas)
-        if self.config.REGRESS_KEYPOINTS:
-            loc_pred, k1_pred, k2_pred = self.keras_model.predict(molded_images, verbose=0)
-            return [{"loc": loc_pred[i], "k1": k1_pred[i], "k2": k2_pred[i]} for i in range(len(images))]
-        loc_pred, ori_pred = self.keras_model.predict(molded_images, verbose=0)
-        return [{"loc": loc_pred[i], "ori": ori_pred[i]} for i in range(len(images))]
+            self._engine.load_batch_u8(np.stack(frames))
+            outs = self._outputs_after_forward()
+        else:
+            molded, metas, _ = self.mold_inputs(images)
+            assert all(m.shape == molded[0].shape for m in molded), \
+                "After resizing, all images must have the same size. Check IMAGE_RESIZE_MODE and image sizes."
+            if verbose:
+                log("molded_images", molded)
+                log("image_metas", metas)
+            outs = self.keras_model.predict(molded, verbose=0)
+        keys = ("loc", "k1", "k2") if self.config.REGRESS_KEYPOINTS else ("loc", "ori")
+        return [dict((k, o[i]) for k, o in zip(keys, outs)) for i in range(len(images))]
