@@ -105,3 +105,43 @@ def test_dp_exact_rel_loss_equals_big_batch():
     pre-scaled by the world size, the AVERAGED shard gradients equal the gradient of the one global-batch loss."""
     out = _run(regress_loc=True, exact=True)
     assert out["err"] < 2e-5, out
+
+
+def _worker_bf16(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ursonet_amd.dp import GradReducer
+    n, steps = 5000, 40
+    buckets = [(3000, 5000, ["b"]), (0, 3000, ["a"])]
+    gen = torch.Generator().manual_seed(100 + rank)
+    flat = torch.zeros(n)
+    red = GradReducer(flat, buckets, compress="bf16")
+    acc, exact = torch.zeros(n), torch.zeros(n)
+    worst_single = 0.0
+    for _ in range(steps):
+        g = torch.randn(n, generator=gen) * 0.3 + 1.0
+        gs = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(gs, g)
+        mean = sum(gs) / world
+        flat.copy_(g)
+        for k in range(len(buckets)):
+            red.launch(k)
+        red.wait_all()
+        worst_single = max(worst_single, float((flat - mean).abs().max() / mean.abs().max()))
+        acc += flat; exact += mean
+    if rank == 0:
+        out["single"] = worst_single
+        out["accumulated"] = float((acc - exact).abs().max() / exact.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_buckets_with_error_feedback():
+    """GradReducer(compress='bf16'): one step's averaged gradient carries bf16 rounding (~4e-3 of max); over many steps -- what
+    momentum SGD integrates -- each rank's own rounding cancels (error feedback), leaving only the rounding of the bf16 additions
+    inside the collective: the 40-step sum is 5-10x closer to the exact one than a single step is."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_bf16, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert 5e-4 < out["single"] < 8e-3, dict(out)
+    assert out["accumulated"] < 2e-3 and out["accumulated"] < 0.3 * out["single"], dict(out)

@@ -293,7 +293,13 @@ def test_frozen_layers_get_no_update():
     cfg = make_config(backbone="resnet50", h=64, w=64, batch=2, dtype="float32")
     img, loc, ori, _ = synthetic_batch(cfg, 2, seed=2)
     eng = Engine(cfg, "training", seed=1)
+    eng.set_lr(0.0123)                                   # compile(lr) before set_trainable must survive the plan rebuild
     eng.set_trainable(layer_regex("heads"))
+    assert abs(float(eng.hyper[0]) - 0.0123) < 1e-9
+    # the data-gradient chain stops at the earliest trainable layer: nothing is back-propagated through the frozen backbone
+    labs = [l for l in eng.labels["bwd"] if l]
+    assert not any(l.startswith(("dgrad:res", "wgrad:res", "maxpool_bwd", "dgrad:bottleneck")) for l in labs), labs
+    assert any(l.startswith("wgrad:bottleneck") for l in labs)
     w0 = eng.get_weights()
     eng.load_batch(img, loc, ori)
     eng.step(); torch.cuda.synchronize()

@@ -46,10 +46,20 @@ def _force_collectives():
 
 
 class GradReducer(object):
-    """Averages slices of a flat gradient tensor across the process group, asynchronously."""
+    """Averages slices of a flat gradient tensor across the process group, asynchronously.
 
-    def __init__(self, flat_g, buckets, group=None):
+    compress='bf16' halves the bytes on the wire (xGMI is the DP bottleneck candidate: 134 MB of fp32 gradients per step at
+    cfg2): each bucket is rounded to bf16 before the all-reduce and expanded afterwards, with ERROR FEEDBACK in fp32 -- what the
+    rounding dropped on this rank is kept (`resid`) and added to the next step's gradient, so the fp32 master weights see every
+    bit of gradient eventually (the rounding error does not accumulate as a bias).  Default None: exact fp32 averaging."""
+
+    def __init__(self, flat_g, buckets, group=None, compress=None):
+        assert compress in (None, "bf16")
         self.flat_g, self.buckets, self.group = flat_g, buckets, group
+        self.compress = compress
+        if compress:
+            self.cbuf = torch.zeros_like(flat_g, dtype=torch.bfloat16)
+            self.resid = torch.zeros_like(flat_g)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.works = []
@@ -62,16 +72,25 @@ class GradReducer(object):
             return
         s, e, _ = self.buckets[k]
         t = self.flat_g[s:e]
+        back = None
+        if self.compress:
+            r, c = self.resid[s:e], self.cbuf[s:e]
+            t.add_(r)                       # error feedback: last step's rounding remainder
+            c.copy_(t)                      # round to bf16
+            torch.sub(t, c.float(), out=r)  # what this rounding dropped, kept for the next step
+            back, t = t, c
         if self.backend == "nccl":          # RCCL: averaging happens inside the collective
-            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, back, t))
         else:                               # gloo (CPU tests): sum, then scale on wait
-            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t, back, t))
 
     def wait_all(self):
-        for w, t in self.works:
+        for w, scale, back, t in self.works:
             w.wait()
-            if t is not None:
-                t.div_(self.world)
+            if scale is not None:
+                scale.div_(self.world)
+            if back is not None:
+                back.copy_(t)               # averaged bf16 gradient -> the fp32 buffer the optimizer reads
         self.works = []
 
 
@@ -80,8 +99,8 @@ class DataParallelEngine(object):
     [prep+forward+loss+backward-part-0], [backward-part-1], ..., [optimizer] hipGraphs and
     interleaves the bucket all-reduces between their replays."""
 
-    def __init__(self, engine, bucket_bytes=32 << 20, group=None):
-        self.eng, self.group = engine, group
+    def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None):
+        self.eng, self.group, self.compress = engine, group, compress
         self.world = dist.get_world_size(group)
         # DP_EXACT_REL_LOSS: the location loss is ONE ratio of norms over the global batch (net.py:750-762); its two squared norms are
         # summed over the ranks between forward and backward and the gradient is pre-scaled by the world size (undone by the averaging)
@@ -96,8 +115,15 @@ class DataParallelEngine(object):
             eng.grad_bucket_bytes = int(bucket_bytes)
             eng._graphs = None
             eng._build_plan()
+        self._derive_cuts()
+
+    def _derive_cuts(self):
+        """Bucket list, reducer and the backward cut points of the engine's CURRENT plan (set_trainable / a bucket-size change
+        rebuild the plan: stale cuts would start an all-reduce before its bucket's finalisation ran)."""
+        eng, group = self.eng, self.group
+        self.plan_version = eng.plan_version
         self.buckets = eng.buckets
-        self.reducer = GradReducer(eng.flat_g, self.buckets, group)
+        self.reducer = GradReducer(eng.flat_g, self.buckets, group, compress=self.compress)
         # split the backward op list where each bucket becomes complete
         last_op_of_layer = {}
         for i, (tag, _) in enumerate(eng.bwd_ops):
@@ -161,6 +187,8 @@ class DataParallelEngine(object):
         self._graphs = graphs
 
     def step(self):
+        if self.plan_version != self.eng.plan_version:
+            self._derive_cuts()
         if self._graphs is None:
             self.capture()
         if self._pre_graph is not None:

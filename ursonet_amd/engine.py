@@ -148,6 +148,7 @@ class Engine(object):
     def _build_plan(self):
         cfg, g, B, dt, dev = self.config, self.graph, self.B, self.dt, self.device
         training = self.mode == "training"
+        self.plan_version = getattr(self, "plan_version", 0) + 1       # ursonet_amd/dp.py re-derives its graph cuts when this moves
         # TRAIN_BN = None ("Train BN layers", net.py:60-76): batch statistics while training -- the BN is not folded, the conv
         # writes its raw output and separate stats / apply / backward kernels run (csrc/bn_train.hip).  Inference and
         # TRAIN_BN = False use the moving statistics folded into the filters.
@@ -332,8 +333,24 @@ class Engine(object):
             if self.layer_trainable[node.name] or (folded_bn and self.layer_trainable[node.bn]):
                 groups.setdefault(bucket_of[node.name], []).append(node.name)
         last_of_group = {names[-1]: k for k, names in groups.items()}
-        for node in reversed(g.nodes):
+        # which activation gradients are needed at all: a tensor's gradient only if a trainable parameter lies at or upstream of its
+        # producer.  With layers='heads' / '4+' / '5+' (net.py:1086-1095) the data-gradient chain stops at the earliest trainable
+        # layer instead of running through the frozen backbone (TF prunes those gradients too)
+        need = {g.tensors[0].id: False}
+        for node in g.nodes:
             if node.op == "pool":
+                need[node.dst.id] = need.get(node.src.id, False)
+            else:
+                own = self.layer_trainable[node.name] or bool(node.bn and self.layer_trainable[node.bn])
+                need[node.dst.id] = (own or (not node.stem and need.get(node.src.id, False)) or
+                                     (node.residual is not None and need.get(node.residual.id, False)))
+        self.grad_needed = need
+        for node in reversed(g.nodes):
+            if not need[node.dst.id]:
+                continue                                   # nothing trainable at or below this node
+            if node.op == "pool":
+                if not need[node.src.id]:
+                    continue
                 src, dst = self.acts[node.src.id], self.acts[node.dst.id]
                 h, w, cc = node.src.h, node.src.w, node.src.c
                 gsrc = src.grad_buf()
@@ -397,7 +414,7 @@ class Engine(object):
                         self.bwd_ops.append((tuple(groups[k]), (ph, k)))          # resolved to launches once the table is on the device
                         self.labels["bwd"].append("%s:bucket%d" % (nm, k))
             # -- residual branch: its gradient IS G (Add); fold it into the next dgrad (post-ReLU tensors) or alias it
-            if c.res is not None:
+            if c.res is not None and need[c.res.spec.id]:
                 R = c.res
                 if R.grad_written or R.pending is not None:
                     raise AssertionError("unexpected second residual consumer for %s" % node.name)
@@ -406,7 +423,7 @@ class Engine(object):
                 else:
                     R.grad, R.grad_written = Gsum, True
             # -- data gradient into the conv input
-            if not node.stem:
+            if not node.stem and need[c.src.spec.id]:
                 X = c.src
                 add = X.grad if X.grad_written else X.pending
                 dstg = X.grad_buf()
@@ -439,13 +456,17 @@ class Engine(object):
         n = self.n_flat
         self.adam = str(getattr(cfg, "OPTIMIZER", "SGD")).upper() != "SGD"          # net.py:979-983: anything else is Adam(amsgrad)
         clip = float(cfg.GRADIENT_CLIP_NORM or 0.0)
+        # hyper-parameters live in device memory so that one captured graph serves a changing learning rate; they are created ONCE:
+        # a later set_trainable() (which rebuilds the plan) must not undo compile(lr) / set_lr() (net.py:1073-1075 calls them in
+        # either order)
         if self.adam:
             eps = 1e-4 if getattr(cfg, "F16", False) else 1e-7                      # K.epsilon(); net.py:590-593 sets 1e-4 in F16 mode
-            self.hyper = torch.tensor([float(cfg.LEARNING_RATE), 0.9, 0.999, eps, clip, 0.0, 1.0 - 0.9, 1.0 - 0.999],
-                                      dtype=torch.float32, device=dev)
+            if getattr(self, "hyper", None) is None or self.hyper.numel() != 8:
+                self.hyper = torch.tensor([float(cfg.LEARNING_RATE), 0.9, 0.999, eps, clip, 0.0, 1.0 - 0.9, 1.0 - 0.999],
+                                          dtype=torch.float32, device=dev)
             if not hasattr(self, "flat_v2") or self.flat_v2.numel() != self.flat_w.numel():
                 self.flat_v2, self.flat_vhat = torch.zeros_like(self.flat_w), torch.zeros_like(self.flat_w)
-        else:
+        elif getattr(self, "hyper", None) is None or self.hyper.numel() != 3:
             self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), clip], dtype=torch.float32, device=dev)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sq_ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, dtype=torch.float32, device=dev)
