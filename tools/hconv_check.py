@@ -27,7 +27,7 @@ def run(B, H, W, C, N, mask=False, add=False, relu=True, ref=False):
     outs = {}
     for hc in (0, 1):
         y = torch.full((B, H, W, N), 7.0, device="cuda").to(tdt)
-        with hip.options(hconv=hc):
+        with hip.options(hconv=2 if hc else 0):
             hip.conv_igemm(g, dt, hip.EPI_RELU if relu else 0, x, wf, bias, res if add else None, res if mask else None, y)
         torch.cuda.synchronize()
         outs[hc] = y.float()
@@ -55,11 +55,15 @@ def bench(B, H, W, C, N, mask=False):
     y = torch.empty(B, H, W, N, device="cuda", dtype=tdt)
     g = hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
     flops = 2.0 * B * H * W * N * 9 * C
-    best = {0: 1e9, 1: 1e9}
+    best = {0: 1e9, 1: 1e9, 2: 1e9}
+    ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, dtype=torch.float32, device="cuda")
     for r in range(a.rounds):
-        for hc in (0, 1):
-            with hip.options(hconv=hc):
-                fn = lambda: hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y)
+        for hc in (0, 1, 2):
+            with hip.options(hconv=2 if hc else 0):
+                if hc == 2:
+                    fn = lambda: hip.conv_igemm_ws(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y, ws)
+                else:
+                    fn = lambda: hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y)
                 for _ in range(3):
                     fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,8 +72,8 @@ def bench(B, H, W, C, N, mask=False):
                     fn()
                 e1.record(); torch.cuda.synchronize()
                 best[hc] = min(best[hc], e0.elapsed_time(e1) / a.iters)
-    print("bench B%d %dx%d C%d N%d mask%d: old %.1f us (%.0f TF)  new %.1f us (%.0f TF)" % (
-        B, H, W, C, N, mask, best[0] * 1e3, flops / best[0] / 1e9, best[1] * 1e3, flops / best[1] / 1e9), flush=True)
+    print("bench B%d %dx%d C%d N%d mask%d: dma %.1f us (%.0f TF)  halo %.1f us (%.0f TF)  halo+stream-K %.1f us (%.0f TF)" % (
+        B, H, W, C, N, mask, best[0] * 1e3, flops / best[0] / 1e9, best[1] * 1e3, flops / best[1] / 1e9, best[2] * 1e3, flops / best[2] / 1e9), flush=True)
 
 
 worst = 0.0

@@ -36,7 +36,12 @@ struct HcArgs {
     int krow;                  // bytes per filter row (9 * C * 2)
     float rcp_vw, rcp_vh;
     int relu;
-    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop
+    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 2 switches stream-K off
+    // stream-K: the (tile, chunk, tap) steps of the whole layer are dealt to the blocks in equal contiguous runs; a tile cut by a run
+    // boundary is finished by the block that holds its first step, the other pieces hand their fp32 accumulators over through `part`
+    int run_q, run_r;          // run b covers run_q (+1 for b < run_r) units starting at b run_q + min(b, run_r); unit = step (stream-K) or tile
+    unsigned int* flags;       // [gridDim.x] hand-over flags, zero on entry and on exit (NULL: whole tiles per block, no stream-K)
+    float* part;               // [gridDim.x][512 threads][64] fp32 partial accumulators
 };
 
 template <typename T> struct Mma32;
@@ -91,11 +96,17 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     const int wm = wave & 3, wn = wave >> 2;
     const int l31 = lane & 31, h = lane >> 5, c8 = lane & 7, r8 = lane >> 3;
 
-    // ---- this block's contiguous run of tiles; logical ids are XCD-contiguous so that neighbouring runs (which share halo rows and,
-    //      with several filter tiles per pixel tile, the whole pixel tile) meet in one L2
+    // ---- this block's contiguous run of steps g = tile * nsteps + chunk * 9 + tap.  Logical block ids are XCD-contiguous so that
+    //      neighbouring runs (which share halo rows and, with several filter tiles per pixel tile, the whole pixel tile) meet in one L2.
+    //      Without a hand-over workspace the runs are rounded to whole tiles.
+    const int nsteps = a.nchunks * 9;
     const int G = gridDim.x, lid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int t_begin = (int)(((long long)lid * a.ntiles) / G), t_end = (int)(((long long)(lid + 1) * a.ntiles) / G);
-    if (t_begin >= t_end) return;
+    auto run_begin = [&](int b) -> long long {                 // no divisions: the host split total = G run_q + run_r
+        const long long units = (long long)b * a.run_q + (b < a.run_r ? b : a.run_r);
+        return a.flags ? units : units * nsteps;
+    };
+    const long long g0 = run_begin(lid), g1 = run_begin(lid + 1);
+    if (g0 >= g1) return;
 
     const i32x4_t rs = hc_rsrc(a.src, a.src_bytes), rw = hc_rsrc(a.wgt, a.wgt_bytes);
     const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
@@ -164,18 +175,42 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
         hc_dma16(rw, lds0 + slot * BSLOT + (wave + 8) * 1024, bsrc0[1] + koff);
     };
 
-    int tile = t_begin;
+    // ---- pipeline state: (tile, chunk cc, tap t = 3 ky + kx) of the step being multiplied, its ring slot and halo buffer
+    int tile = (int)(g0 / nsteps);
+    int cc, t;
+    {
+        const int s0 = (int)(g0 - (long long)tile * nsteps);
+        cc = s0 / 9; t = s0 - cc * 9;
+    }
+    long long g = g0;
+    int slot = 0, buf = 0;
+    int u = 0;                                                // steps done in the current chunk by THIS run (paces the next halo copy)
     set_arow(tile);
-    {   // ---- block prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
+    // a run that enters its first chunk at tap >= 6 has too few steps left there to stream the next chunk's halo tile behind the
+    // multiplications: that tile is fetched up front as well
+    bool halo_ahead = false;
+    {   // ---- block prologue: the entry chunk's halo tile, the filter tiles of the first two steps
         const int n0 = (tile % a.tilesN) * BN;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) dma_a(j, 0, 0);
-        dma_b(n0, 0, 0, 0);
-        dma_b(n0, 0, 1, 1);
+        for (int j = 0; j < 7; ++j) dma_a(j, cc, 0);
+        dma_b(n0, cc, t, 0);
+        {
+            int t1 = t + 1, c1 = cc, tl1 = tile;
+            if (t1 == 9) { t1 = 0; if (++c1 == a.nchunks) { c1 = 0; ++tl1; } }
+            if (g + 1 < g1) dma_b((tl1 % a.tilesN) * BN, c1, t1, 1);
+        }
+        const long long next_chunk_g = (long long)tile * nsteps + (cc + 1) * 9;
+        if (t >= 6 && next_chunk_g < g1) {
+            const bool lastc = cc + 1 == a.nchunks;
+            if (lastc) set_arow(tile + 1);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) dma_a(j, lastc ? 0 : cc + 1, 1);
+            halo_ahead = true;
+        }
         hc_wait_vm<0>();
         hc_barrier();                                         // also publishes the bias written above
     }
-    int buf = 0;
+    bool after_epilogue = false;                              // the next mid-step wait must leave the epilogue's stores outstanding
     i32x4_t fw0[2], fp0[2], fw1[2], fp1[2];                  // fragment sets of two consecutive 16-deep k sub-steps
     auto rd = [&](i32x4_t (&fw)[2], i32x4_t (&fp)[2], uint32_t bbase, uint32_t abase, int shift, int k) {
 #pragma unroll
@@ -183,87 +218,147 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) fp[i] = *(const i32x4_t*)(smem + abase + (hc_rd(rb[i] + shift, h) ^ (uint32_t)(k << 5)));
     };
-    rd(fw0, fp0, 0, AOFF, 0, 0);                              // step 0, k = 0
+    auto tapshift = [&](int tt) -> int { const int ky = (tt * 11) >> 5; return ky * a.Vw + (tt - 3 * ky); };     // tt / 3 for tt < 9
+    rd(fw0, fp0, 0, AOFF, tapshift(t), 0);                    // first step, k = 0
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     while (true) {
-        const bool has_next = tile + 1 < t_end;
-        const int p0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
-        const int n0n = ((tile + 1) % a.tilesN) * BN;
-        f32x16_t acc[2][2];
+        const long long tile_g0 = (long long)tile * nsteps, tile_g1 = tile_g0 + nsteps;
+        const int n0 = (tile % a.tilesN) * BN, n0n = ((tile + 1) % a.tilesN) * BN;
+        const bool last = cc + 1 == a.nchunks;
+        const bool more_a = tile_g0 + (cc + 1) * 9 < g1;       // the run continues into the next chunk (of this or the next tile)
+        const int cca = last ? 0 : cc + 1;
+        const uint32_t abase = AOFF + buf * ABUF, abase_n = AOFF + (buf ^ 1) * ABUF, bbase = slot * BSLOT;
+        const int shift = tapshift(t);
+        // the read addresses depend on (lane, tap) only: keep the compiler from hoisting them out of the step loop into registers
+        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(boff[0]), "+v"(boff[1]));
+        if (u == 0 && last && more_a && !halo_ahead) set_arow(tile + 1);     // the halo copies of this chunk target the next tile's chunk 0
+        // ---- k = 0 fragments are in fw0 / fp0 (read during the previous step)
+        {
+        rd(fw1, fp1, bbase, abase, shift, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fw0, fp0, bbase, abase, shift, 2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int cc = 0; cc < ((a.dbg & 2) ? 0 : a.nchunks); ++cc) {
-            const bool last = cc + 1 == a.nchunks;
-            if (last && has_next) set_arow(tile + 1);          // from here on the halo copies target the next tile's chunk 0
-            const bool more_a = !last || has_next;
-            const int cca = last ? 0 : cc + 1;
-            const uint32_t abase = AOFF + buf * ABUF, abase_n = AOFF + (buf ^ 1) * ABUF;
-            const bool first_wait_after_epilogue = cc == 0 && tile != t_begin && !(a.dbg & 1);
-            // the read addresses are functions of (lane, tap) only: keep the compiler from hoisting all 9 x 2 x 4 of them out of the
-            // chunk loop into registers (it then spills the accumulators)
-            asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(boff[0]), "+v"(boff[1]));
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const uint32_t bbase = (t % 3) * BSLOT;
-                const int shift = (t / 3) * a.Vw + (t % 3);
-                // k = 0 fragments are in fw0 / fp0 (read during the previous step)
-                rd(fw1, fp1, bbase, abase, shift, 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-                rd(fw0, fp0, bbase, abase, shift, 2);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-                rd(fw1, fp1, bbase, abase, shift, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- mid-step: this wave's copies issued one step ago have landed -> barrier -> every wave's have, and every wave has
-                //      finished reading the previous step's ring slot and (at t = 0) the previous chunk's halo buffer
-                if (t == 0 && first_wait_after_epilogue) hc_wait_vm<HC_NST>(); else hc_wait_vm<0>();
-                hc_sbarrier();
-                {   // filter tile two steps ahead -> ring slot (t + 2) % 3; one piece of the next halo tile -> the other halo buffer
-                    const int t2 = (t + 2) % 9;
-                    const bool wrap = t + 2 >= 9;
-                    const bool okb = !wrap || more_a;
-                    if (okb) dma_b((wrap && last) ? n0n : n0, wrap ? cca : cc, t2, (t + 2) % 3);
-                    if (t < 7 && t < a.JA && more_a) dma_a(t, cca, buf ^ 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-                // next step's k = 0 fragments (its filter tile and -- across a chunk seam -- its halo tile became visible at this or an
-                // earlier mid-step barrier)
-                if (t < 8) rd(fw0, fp0, ((t + 1) % 3) * BSLOT, abase, ((t + 1) / 3) * a.Vw + ((t + 1) % 3), 0);
-                else rd(fw0, fp0, 0, abase_n, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            buf ^= 1;
+            for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fw1, fp1, bbase, abase, shift, 3);
+        __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- mid-step: this wave's copies issued one step ago have landed -> barrier -> every wave's have, and every wave has
+        //      finished reading the previous step's ring slot and (in a chunk's first step) the previous chunk's halo buffer
+        if (after_epilogue) hc_wait_vm<HC_NST>(); else hc_wait_vm<0>();
+        after_epilogue = false;
+        hc_sbarrier();
+        {   // filter tile two steps ahead -> ring slot (slot + 2) % 3; the next halo tile -> the other halo buffer, in three portions
+            if (g + 2 < g1) {
+                int t2 = t + 2, c2 = cc, nn = n0;
+                if (t2 >= 9) { t2 -= 9; c2 = cca; if (last) nn = n0n; }
+                dma_b(nn, c2, t2, slot >= 1 ? slot - 1 : 2);
+            }
+            if (more_a && !halo_ahead) {
+                if (u == 0) { dma_a(0, cca, buf ^ 1); dma_a(1, cca, buf ^ 1); dma_a(2, cca, buf ^ 1); }
+                else if (u == 1) { dma_a(3, cca, buf ^ 1); dma_a(4, cca, buf ^ 1); }
+                else if (u == 2) { dma_a(5, cca, buf ^ 1); dma_a(6, cca, buf ^ 1); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma32<T>::run(fw0[j], fp0[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- next step's k = 0 fragments (its filter tile and -- across a chunk seam -- its halo tile became visible at this or an
+        //      earlier mid-step barrier)
+        const int slot_n = slot == 2 ? 0 : slot + 1;
+        if (t < 8) rd(fw0, fp0, slot_n * BSLOT, abase, tapshift(t + 1), 0);
+        else rd(fw0, fp0, slot_n * BSLOT, abase_n, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma32<T>::run(fw1[j], fp1[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- advance
+        ++g; ++u; slot = slot_n;
+        const bool run_done = g >= g1;
+        bool tile_done = false;
+        if (++t == 9) { t = 0; u = 0; buf ^= 1; halo_ahead = false; if (++cc == a.nchunks) { cc = 0; tile_done = true; } }
+        if (!tile_done && !run_done) continue;
+        // ======== the run's part of `tile` is complete
+        const int p0 = (tile / a.tilesN) * BM;
+        const bool head = tile_g0 >= g0;                       // this run holds the tile's first step: it finishes the tile
+        const int sbuf = (t == 0) ? (buf ^ 1) : buf;           // halo buffer of the chunk just left: free for the epilogue's staging
 
+        if (!head) {
+            // ---- a later piece of a tile that an earlier run finishes: hand the accumulators over (plain stores -> every wave drains
+            //      them -> one lane: agent-scope release, drained again behind the compiler's back, relaxed flag store)
+            f32x4_t* pp = (f32x4_t*)(a.part + (size_t)lid * (512 * 64)) + tid;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        pp[((i * 2 + j) * 4 + q) * 512] = f32x4_t{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (!tile_done) {
+                // ---- the tile continues in the following run(s): add their accumulators in run order (fixed order: deterministic)
+                for (int b = lid + 1; b < G && run_begin(b) < tile_g1; ++b) {
+                    if (run_begin(b) == run_begin(b + 1)) continue;          // an empty run hands nothing over
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(a.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
+                            __builtin_amdgcn_s_sleep(8);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const f32x4_t* pp = (const f32x4_t*)(a.part + (size_t)b * (512 * 64)) + tid;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4_t v = pp[((i * 2 + j) * 4 + q) * 512];
+                                acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);          // 16 registers of loads in flight at a time, not 64
+                        }
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(a.flags + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+                }
+            }
         // ---- epilogue: + bias -> ReLU -> 16-bit, transposed through LDS (this wave's 4 KiB of the halo buffer that has just been
         //      retired: nothing is copied into it before the next mid-step barrier) so that every store instruction writes whole
         //      128-byte lines; the mask is applied after the transposition, read with the same coalesced addresses
         if (!(a.dbg & 1)) {
-            const uint32_t sbase = AOFF + (buf ^ 1) * ABUF + wave * 4096;
+            const uint32_t sbase = AOFF + sbuf * ABUF + wave * 4096;
             int vx, vy, vb;                                   // virtual coordinates of this lane's first store pixel
             {
                 int q1;
@@ -314,9 +409,17 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
                     buf_store16(rds, so[q], ov[q]);
                 }
             }
+            after_epilogue = true;
         }
-        if (!has_next) break;
+        }
+        if (run_done) break;
         ++tile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
 }
 
@@ -350,8 +453,12 @@ bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add
     return true;
 }
 
+// hand-over workspace of the stream-K schedule: 4 KiB of flags (zero on entry, left zero) + one 128 KiB accumulator slab per block
+size_t urso_hconv_ws_bytes() { return 4096 + (size_t)hc_device_cus() * 512 * 64 * sizeof(float); }
+
 int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
-                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
+                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
     HcArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
     a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
@@ -368,6 +475,13 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);
+    // stream-K needs every block resident (a finishing block waits for the pieces of the runs that follow it): one block per CU,
+    // never more blocks than CUs; hconv_dbg bit 2 switches it off (whole tiles per block)
+    const bool streamk = ws && ws_bytes >= urso_hconv_ws_bytes() && (int)grid.x <= hc_device_cus() && !(a.dbg & 4);
+    a.flags = streamk ? (unsigned int*)ws : nullptr;
+    a.part = streamk ? (float*)((char*)ws + 4096) : nullptr;
+    const long long units = streamk ? (long long)a.ntiles * a.nchunks * 9 : (long long)a.ntiles;
+    a.run_q = (int)(units / grid.x); a.run_r = (int)(units % grid.x);
     if (dt == URSO_BF16) hipLaunchKernelGGL((hconv_kernel<__bf16>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((hconv_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(halo)");
