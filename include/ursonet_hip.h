@@ -121,14 +121,8 @@ int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
                        void* ws_d, size_t ws_bytes, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
- * says so (policy option "hconv").  Given a workspace of urso_conv_igemm_halo_ws_bytes() through ws_d, that kernel balances the
- * chip by dealing the (tile, channel-chunk, tap) steps of the layer to one block per CU in equal contiguous runs ("stream-K"): a
- * tile cut by a run boundary is finished by the block that holds its first step, the other pieces hand over fp32 accumulators
- * in a fixed order (deterministic).  CONTRACT: the first 4 KiB of that workspace are hand-over flags -- zero on entry, left zero
- * on return; a workspace shared with other entry points must be re-zeroed there before the call.  Without a workspace every
- * block walks whole tiles. */
+ * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel). */
 int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_add);
-size_t urso_conv_igemm_halo_ws_bytes(void);
 
 /*
  * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):

@@ -55,15 +55,11 @@ def bench(B, H, W, C, N, mask=False):
     y = torch.empty(B, H, W, N, device="cuda", dtype=tdt)
     g = hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
     flops = 2.0 * B * H * W * N * 9 * C
-    best = {0: 1e9, 1: 1e9, 2: 1e9}
-    ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, dtype=torch.float32, device="cuda")
+    best = {0: 1e9, 1: 1e9}
     for r in range(a.rounds):
-        for hc in (0, 1, 2):
+        for hc in (0, 1):
             with hip.options(hconv=2 if hc else 0):
-                if hc == 2:
-                    fn = lambda: hip.conv_igemm_ws(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y, ws)
-                else:
-                    fn = lambda: hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y)
+                fn = lambda: hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, res if mask else None, y)
                 for _ in range(3):
                     fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -72,8 +68,8 @@ def bench(B, H, W, C, N, mask=False):
                     fn()
                 e1.record(); torch.cuda.synchronize()
                 best[hc] = min(best[hc], e0.elapsed_time(e1) / a.iters)
-    print("bench B%d %dx%d C%d N%d mask%d: dma %.1f us (%.0f TF)  halo %.1f us (%.0f TF)  halo+stream-K %.1f us (%.0f TF)" % (
-        B, H, W, C, N, mask, best[0] * 1e3, flops / best[0] / 1e9, best[1] * 1e3, flops / best[1] / 1e9, best[2] * 1e3, flops / best[2] / 1e9), flush=True)
+    print("bench B%d %dx%d C%d N%d mask%d: dma %.1f us (%.0f TF)  halo %.1f us (%.0f TF)" % (
+        B, H, W, C, N, mask, best[0] * 1e3, flops / best[0] / 1e9, best[1] * 1e3, flops / best[1] / 1e9), flush=True)
 
 
 worst = 0.0

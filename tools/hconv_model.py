@@ -30,8 +30,8 @@ def t_us(B, H, W, C, N, dbg, iters=30, rounds=3):
     return best
 
 
-print("tiles/block steps/tile   full   no-epilogue")
+print("tiles/block steps/tile   full   no-epilogue   no-mainloop   neither")
 for C in (128, 256, 512):
     for B in (64, 128, 192):
-        r = [t_us(B, 31, 31, C, 128, d) for d in (0, 1)]
-        print("%5d %10d   %6.1f %10.1f" % (B // 64, 9 * C // 64, r[0], r[1]), flush=True)
+        r = [t_us(B, 31, 31, C, 128, d) for d in (0, 1, 2, 3)]
+        print("%5d %10d   %6.1f %10.1f %12.1f %10.1f" % (B // 64, 9 * C // 64, r[0], r[1], r[2], r[3]), flush=True)
