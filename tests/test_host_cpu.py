@@ -121,6 +121,16 @@ def test_resize_image_geometry_matches_reference():
         assert out[window[0] + c["h"] // 2, window[1] + c["w"] // 2, 0] == 255 and out.dtype == np.uint8
 
 
+def test_clr_triangular_matches_reference_callback():
+    """utils.clr_triangular (what UrsoNet.train feeds Engine.set_lr per batch) against the learning rates the reference's
+    CyclicLR callback put in force batch by batch (tests/golden/clr.json, generated by importing clr_callback.py)."""
+    from ursonet_amd.utils import clr_triangular
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "clr.json")))
+    for g in gold.values():
+        for i, lr in enumerate(g["lr"]):
+            assert clr_triangular(i, g["base_lr"], g["max_lr"], g["step_size"]) == pytest.approx(lr, rel=1e-12, abs=1e-18), i
+
+
 def test_clr_triangular_shape():
     from ursonet_amd.utils import clr_triangular
     assert clr_triangular(0, 1e-4, 5e-4, 100) == pytest.approx(1e-4)
