@@ -98,6 +98,52 @@ def cpu_baseline(cfg_kw, sample_batch, steps):
                       % (cfg_kw["backbone"], cfg_kw["h"], cfg_kw["w"], sample_batch, steps, dt, dtf)}
 
 
+def pcie_inclusive(eng, cfg, batch, steps):
+    """The same training step fed the way net.UrsoNet.train feeds it (ursonet_amd.feeder.DeviceFeeder): every step takes a NEW
+    uint8 batch + targets from pinned host memory, uploaded on a side stream into a staging buffer while the previous step runs,
+    then copied into the engine's input (mean subtraction + cast happen in the first kernel).  Reported beside `value`, never as
+    it: `value` is quoted with the inputs resident in HBM."""
+    from util import synthetic_batch
+    host = []
+    for k in range(2):
+        img, loc, ori, _ = synthetic_batch(cfg, batch, seed=77 + k)
+        u8 = np.clip(np.rint(img + np.asarray(cfg.MEAN_PIXEL, dtype=np.float32)), 0, 255).astype(np.uint8)
+        host.append([torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in (u8, loc, ori)])
+    side = torch.cuda.Stream()
+    stage = [[torch.empty(h.shape, dtype=h.dtype, device="cuda") for h in host[0]] for _ in range(2)]
+    ev = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def upload(k):
+        slot = k & 1
+        with torch.cuda.stream(side):
+            side.wait_event(consumed[slot])                 # the step that read this staging slot has copied it out
+            for d, h in zip(stage[slot], host[slot]):
+                d.copy_(h, non_blocking=True)
+            ev[slot].record(side)
+
+    def run(n, k0):
+        for k in range(k0, k0 + n):
+            slot = k & 1
+            torch.cuda.current_stream().wait_event(ev[slot])
+            eng.load_batch_u8(*stage[slot])
+            consumed[slot].record(torch.cuda.current_stream())
+            upload(k + 1) if k + 1 < k0 + n else None
+            eng.step()
+    for c in consumed:
+        c.record(torch.cuda.current_stream())
+    upload(0); run(4, 0)                                    # warm-up (re-captures the graph for the uint8 input)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    upload(4); run(steps, 4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = sum(h.numel() * h.element_size() for h in host[0])
+    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "host_bytes_per_step": nbytes,
+            "what": "pinned uint8 batch + targets -> side-stream upload (double buffer) -> step, a new batch every step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +159,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--pcie-steps", type=int, default=20, help="steps of the host-buffer-inclusive leg (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,6 +253,7 @@ def main():
                 "avg_launch_ms": round(dms / dn, 4), "launches": dn // args.profile_steps,
                 "algorithmic_flops_per_launch": dfl / dn,
                 "whole_step_frac_of_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+    pcie = pcie_inclusive(eng, cfg, args.batch, args.pcie_steps) if (args.pcie_steps > 0 and world == 1) else None
     out = {
         "metric": "images/sec fwd+bwd ResNet50 640x512 bs32/GPU", "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -216,7 +264,7 @@ def main():
                                                                                      args.width, "+RCCL all-reduce" if world > 1 else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hipgraph": True,
                    "step_tflop": round(step_flops / 1e12, 3), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "kernels": kernels, "pcie_inclusive": pcie,
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline({"h": args.height, "w": args.width, "backbone": args.backbone, "ori_bins": args.ori_bins},

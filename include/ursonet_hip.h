@@ -337,6 +337,13 @@ int urso_warp_perspective(int B, int H, int W, int C, int interp, const uint8_t*
 int urso_encode_ori(int B, int K, const double* q_d, const float* hquat_d, const uint8_t* redundant_d, double var,
                     float* out_d, void* stream);
 
+/* utils.encode_loc (utils.py:349-396): soft assignment of B locations (fp64 [B][3] = x/z, y/z, z as the reference's callers pass
+ * them) to the K = m^3 metric bin centres hmap (fp64 [K][3], the second return value of encode_loc: the (x/z, y/z, z) grid between
+ * min_lim and max_lim with the first two columns multiplied by the third).  out[b,:] (fp32 [B][K]) = isotropic 3-D normal density of
+ * variance sig2 = (beta/m)^2/12 centred on (x z, y z, z), normalised to sum 1 -- evaluated in fp64 exactly as the reference does
+ * (density first, then the division, so underflow behaves the same). */
+int urso_encode_loc(int B, int K, const double* loc_d, const double* hmap_d, double sig2, float* out_d, void* stream);
+
 /*
  * sim2real augmentation on the GPU (net.py:390-406; "next" scope row f-1): grey conversion and ONE stage of the reference's
  * imgaug.Sequential(random_order=True) per call, on a uint8 batch [B,H,W,3] resident in HBM.  op_d[b] selects the stage applied

@@ -252,3 +252,24 @@ def test_load_image_gt_sim2real_branch_end_to_end():
             img2 = net.load_image_gt(ds, cfg, 1)[0]
             assert np.array_equal(img2[..., 0], grey) == bool(d["apply"][0])
             break
+
+
+@pytest.mark.parametrize("m", [4, 8])
+def test_encode_loc_kernel_matches_reference_golden(m):
+    """urso_encode_loc against the reference's utils.encode_loc outputs (tests/golden, URSO-style limits) and the oracle."""
+    from ursonet_amd import pose
+    from oracle import pose_math as P
+    g = np.load(os.path.join(GOLD, "loc_codec.npz"))
+    beta = json.load(open(os.path.join(GOLD, "meta.json")))["beta"]
+    out, H = pose.encode_locations(g["locs"], m, beta, g["max_lim"], g["min_lim"])
+    assert out.shape == g["enc_%d" % m].shape and np.allclose(H, g["map_%d" % m], rtol=1e-12, atol=1e-12)
+    assert np.abs(out.cpu().numpy() - g["enc_%d" % m]).max() < 1e-6
+    assert np.abs(out.sum(1).cpu().numpy() - 1).max() < 1e-5
+    enc_o, _ = P.encode_loc(g["locs"], m, beta, g["max_lim"], g["min_lim"])
+    assert np.abs(out.cpu().numpy() - enc_o).max() < 1e-6
+    # full-size head (cfg5: 16 bins per dimension -> 4096) on a seeded batch vs the host implementation
+    rng = np.random.default_rng(3)
+    xyz = np.stack([rng.uniform(-0.25, 0.25, 32), rng.uniform(-0.2, 0.2, 32), rng.uniform(4, 35, 32)], 1)
+    big, _ = pose.encode_locations(xyz, 16, beta, [0.3, 0.25, 40.0], [-0.3, -0.25, 3.0])
+    host, _ = pose.encode_loc(xyz, 16, beta, [0.3, 0.25, 40.0], [-0.3, -0.25, 3.0])
+    assert np.abs(big.cpu().numpy() - host).max() < 1e-6

@@ -490,7 +490,8 @@ def test_full_size_cfg5_f16_classify_loc_encode_loc_targets():
     img, _, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=14)
     rng = np.random.default_rng(6)
     xyz = np.stack([rng.uniform(-0.2, 0.2, 32), rng.uniform(-0.15, 0.15, 32), rng.uniform(5, 35, 32)], 1)
-    loc, H = pose.encode_loc(xyz, 16, cfg.BETA, max_lim=[0.3, 0.25, 40.0], min_lim=[-0.3, -0.25, 3.0])
+    loc, H = pose.encode_locations(xyz, 16, cfg.BETA, max_lim=[0.3, 0.25, 40.0], min_lim=[-0.3, -0.25, 3.0])      # urso_encode_loc
+    loc = loc.cpu().numpy()
     assert loc.shape == (32, 4096) and np.allclose(loc.sum(1), 1, atol=1e-5)
     _full_size_properties(cfg, img, loc, ori, runs=2, steps=4)
 

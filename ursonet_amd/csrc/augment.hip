@@ -100,6 +100,40 @@ extern "C" int urso_encode_ori(int B, int K, const double* q_d, const float* hqu
     return urso_check_launch("urso_encode_ori");
 }
 
+// out[b, i] = N(h_i; (x z, y z, z)_b, sig2 I) / sum_i(...)   with h_i the metric bin centre (hmap [K][3] fp64) -- utils.encode_loc
+__global__ void encode_loc_kernel(int K, const double* __restrict__ loc, const double* __restrict__ hmap, double sig2,
+                                  float* __restrict__ out) {
+    __shared__ double sh[8];
+    const int b = blockIdx.x;
+    const double z = loc[b * 3 + 2], mx = loc[b * 3] * z, my = loc[b * 3 + 1] * z;
+    const double PI = 3.14159265358979323846;
+    const double two_pi_s = 2.0 * PI * sig2;
+    const double norm = 1.0 / sqrt(two_pi_s * two_pi_s * two_pi_s);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const double dx = hmap[i * 3] - mx, dy = hmap[i * 3 + 1] - my, dz = hmap[i * 3 + 2] - z;
+        s += exp(-0.5 * (dx * dx + dy * dy + dz * dz) / sig2) * norm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += sh[w];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const double dx = hmap[i * 3] - mx, dy = hmap[i * 3 + 1] - my, dz = hmap[i * 3 + 2] - z;
+        out[(size_t)b * K + i] = (float)(exp(-0.5 * (dx * dx + dy * dy + dz * dz) / sig2) * norm / tot);
+    }
+}
+
+extern "C" int urso_encode_loc(int B, int K, const double* loc_d, const double* hmap_d, double sig2, float* out_d, void* stream) {
+    if (!loc_d || !hmap_d || !out_d || B <= 0 || K <= 0 || !(sig2 > 0)) { urso_set_error("urso_encode_loc: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 24);
+    hipLaunchKernelGGL(encode_loc_kernel, dim3(B), dim3(256), 0, st, K, loc_d, hmap_d, sig2, out_d);
+    return urso_check_launch("urso_encode_loc");
+}
+
 // ---------------------------------------------------------------- sim2real augmentation (net.py:390-406)
 // The reference converts the frame to grey (0.2126 R + 0.7152 G + 0.0722 B written back into the uint8 channels) and, half of the
 // time, runs imgaug.Sequential([AdditiveGaussianNoise(0.01*255), GaussianBlur((0, 1.5)), Add((-20, 20)), Multiply((0.5, 2.0)),

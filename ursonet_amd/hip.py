@@ -105,6 +105,7 @@ _SIGS = {
     "urso_quat_wavg_decode": (_i, [_i, _i, _fp, _fp, _fp, _fp, _vp]),
     "urso_warp_perspective": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "urso_encode_ori": (_i, [_i, _i, _vp, _fp, _vp, C.c_double, _fp, _vp]),
+    "urso_encode_loc": (_i, [_i, _i, _vp, _vp, C.c_double, _fp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -387,6 +388,11 @@ def warp_perspective(B, H, W, Cc, interp, src, m, dst, stream=None):
 def encode_ori(B, K, q, hquat, redundant, var, out, stream=None):
     assert q.dtype == torch.float64 and redundant.dtype == torch.uint8
     _chk(_lib.urso_encode_ori(B, K, ptr(q), ptr(hquat), ptr(redundant), float(var), ptr(out), stream_ptr(stream)), "urso_encode_ori")
+
+
+def encode_loc(B, K, loc, hmap, sig2, out, stream=None):
+    """urso_encode_loc: loc fp64 [B,3], hmap fp64 [K,3] -> out fp32 [B,K] (utils.encode_loc utils.py:349-396)."""
+    _chk(_lib.urso_encode_loc(B, K, ptr(loc), ptr(hmap), float(sig2), ptr(out), stream_ptr(stream)), "urso_encode_loc")
 
 
 def rgb_to_grey3(B, H, W, src, dst, stream=None):

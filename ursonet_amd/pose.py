@@ -92,6 +92,28 @@ def encode_loc(locs, nr_bins_per_dim, beta, max_lim, min_lim):
     return (pr / pr.sum(axis=1, keepdims=True)).astype(np.float32), H
 
 
+def location_map(nr_bins_per_dim, max_lim, min_lim):
+    """The metric bin-centre grid utils.encode_loc returns as its second value (utils.py:363-378): [m^3, 3] float64."""
+    max_lim, min_lim = np.asarray(max_lim, dtype=np.float64), np.asarray(min_lim, dtype=np.float64)
+    bins = np.linspace(0.0, 1.0, nr_bins_per_dim)
+    H = np.asarray(list(itertools.product(bins, repeat=3))) * (max_lim - min_lim) + min_lim
+    H[:, 0] *= H[:, 2]
+    H[:, 1] *= H[:, 2]
+    return H
+
+
+def encode_locations(locs, nr_bins_per_dim, beta, max_lim, min_lim):
+    """Batched utils.encode_loc on the GPU (urso_encode_loc): locs [B,3] -> (float32 CUDA tensor [B, m^3] of PMFs, map [m^3,3])."""
+    import torch
+    from . import hip
+    H = location_map(nr_bins_per_dim, max_lim, min_lim)
+    ld = torch.as_tensor(np.atleast_2d(np.asarray(locs, dtype=np.float64))).cuda().contiguous()
+    hd = torch.as_tensor(H).cuda().contiguous()
+    out = torch.empty(ld.shape[0], H.shape[0], dtype=torch.float32, device=ld.device)
+    hip.encode_loc(ld.shape[0], H.shape[0], ld, hd, (beta / nr_bins_per_dim) ** 2 / 12, out)
+    return out, H
+
+
 # --------------------------------------------------------------------------- GPU decode + metrics
 def decode_orientations(ori_logits, H_quat):
     """Batched probabilistic soft-argmax (pose_estimator.py:406-409) on the GPU.
