@@ -161,25 +161,32 @@ def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w):
     return worst
 
 
+@pytest.mark.parametrize("pair", [1, 0], ids=["fused", "apart"])
 @pytest.mark.parametrize("cap", [0, 8], ids=["grid", "capped"])
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 1.5e-2, 2.5e-2), ("float16", 2e-3, 5e-3)])
-def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, cap):
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 2e-3, 5e-3)])
+def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, cap, pair):
     """The benchmarked dtype against an oracle that rounds where the device rounds (oracle.graph_ref.StorageRounding: folded
     filters, every stored activation, every activation gradient): outputs, losses, EVERY parameter gradient (relative to the
     tensor's max), the global norm and the post-step weights -- not a cosine.  'capped' additionally forces the multi-tile
-    stream of the DMA conv kernels (conv_pw.hip) inside this oracle-compared step.  A mis-scaled or mis-indexed layer
+    stream of the DMA conv kernels (conv_pw.hip) and of the fused pair kernel inside this oracle-compared step; 'fused' / 'apart' run
+    the plan with and without the fused stage-2 pointwise pairs (conv_pair.hip).  A mis-scaled or mis-indexed layer
     cannot pass at these tolerances (a wrong scale of 2 in one tensor is a 50 % error).  Measured on MI355X (r50, 2 x 128 x 192):
     bf16 outputs 8e-3, losses 3e-3, worst gradient tensor 2.0e-2 (a 64-element BN gamma; filters ~1e-2), global norm 5e-3,
     post-step weights 3e-5; fp16 outputs 1.2e-3, worst gradient 3.2e-3, norm 7e-4, weights 6e-6.  What remains is the order of the
     fp32 accumulations (a value within ~1e-6 of a 16-bit rounding boundary rounds differently, ~3e-4 of all elements) and the
-    device's second rounding where two gradient contributions meet in a 16-bit buffer."""
+    device's second rounding where two gradient contributions meet in a 16-bit buffer.  That residue is chaotic in bf16: the plan
+    with the fused stage-2 pairs (conv_pair.hip: bit-identical backward, forward equal up to one rounding flip in ~1e-5 of the
+    elements) measures outputs 1.1e-2 / worst filter gradient 2.8e-2 / norm 9e-3 against 7.7e-3 / 1.5e-2 / 5e-3 with the layers
+    launched apart, while fp16 -- 8x finer, so any systematic error would show at the same absolute size -- is unchanged at 3.3e-3;
+    the bf16 gates are set to twice the larger measurement."""
     import ursonet_amd.hip as hip
     from oracle import graph_ref as G
     kw = dict(backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
     cfg = make_config(dtype=dtype, **kw)
     img, loc, ori, _ = synthetic_batch(cfg, 2, seed=1)
-    with hip.options(grid_cap=cap):
+    with hip.options(grid_cap=cap, pair=pair):
         eng, w0 = _run_engine(cfg, img, loc, ori)
+    assert len(eng.pair_first) == (2 if pair else 0)
     q = G.StorageRounding(torch.bfloat16 if dtype == "bfloat16" else torch.float16)
     dec = ReluDecisions(eng, tol=4 * tol_out)
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
@@ -527,3 +534,32 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
             assert eng.losses() == plain.losses()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
+    """Engine plan with the stage-2 pointwise pairs fused (urso_conv_pair, default) against the plan with every layer launched on
+    its own (option pair=0): same outputs and losses up to the rounding flips of the fused layers' outputs, four launches fewer (two
+    forward pairs, two backward pairs in ResNet-50)."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
+    img, loc, ori, _ = synthetic_batch(cfg, 4, seed=21)
+    res = []
+    for pair in (1, 0):
+        with hip.options(pair=pair):
+            eng = Engine(cfg, "training", seed=5, randomize_bn=True)
+        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+        res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
+                    sorted(eng.pair_first)))
+    assert res[0][5] == ["res2b_branch2a", "res2c_branch2a"] and res[1][5] == []
+    assert res[1][0] - res[0][0] == 2 and res[1][1] - res[0][1] == 2
+    tol_out = 2e-2 if dtype == "bfloat16" else 2e-3                               # the output gate of the oracle comparison above
+    eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
+    el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])
+    print("fused vs apart (%s): outputs %.2e losses %.2e" % (dtype, eo, el))
+    # the two plans differ by rounding flips in the forward pass only.  Their GRADIENTS are not compared with each other: one ReLU unit
+    # of a Dense head that flips for one of the 4 samples moves a whole filter row by O(1), so two valid 16-bit runs differ by >10 %
+    # in the tensor-max metric; each plan is compared with the oracle under pinned ReLU decisions instead
+    # (test_training_step_parity_16bit_same_rounding_points[... fused / apart])
+    assert eo <= tol_out and el <= tol_out

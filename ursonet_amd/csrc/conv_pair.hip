@@ -1,0 +1,355 @@
+// Two chained pointwise layers of the stage-2 bottleneck blocks in ONE pass over the pixels (16-bit dtypes, gfx950):
+//   forward :  mid = relu(src W1^T + bias1 + add)      = res2{a,b}_branch2c + BatchNorm + Add + ReLU        (net.py:148-157)
+//              dst = relu(mid W2^T + bias2)            = res2{b,c}_branch2a + BatchNorm + ReLU of the NEXT block (net.py:101-104)
+//   backward:  mid = (src W1^T + add) masked by bits   = data gradient of branch2a into the block input (+ the residual branch's gradient)
+//              dst = (mid W2^T) masked by (mask2 > 0)  = data gradient of the previous block's branch2c into its branch2b output
+// with src/dst [M][64], mid/add [M][256].  Run as two launches (conv_pw.hip) the 256-channel tensor `mid` (335 MB at cfg2) is written
+// by the first and read back by the second; both layers are HBM-bound (K = 64 / N = 64), so the pair costs the bytes of
+// src + add + 2 mid + dst.  Here `mid` is written once and consumed from LDS: src + add + mid + dst, 29 % fewer bytes.
+//
+// Shape of the kernel.  The two GEMMs are tiny (64 x 256 x 64 twice per 64-pixel tile, ~4 % of the CU's MFMA rate at HBM speed), so
+// the design is about keeping bytes in flight, not about MFMA issue:
+//   * 256 threads, 64-pixel tiles, 80 KiB of LDS -> two independent blocks per CU; each block double-buffers its inputs
+//     (src tile 8 KiB, add tile 32 KiB) by LDS-DMA one whole tile ahead: ~80 KiB in flight per CU;
+//   * BOTH filter matrices live in registers for the whole kernel (W1: the wave's 64 output channels x 64, W2: the wave's 16
+//     output channels x 256 -- 32 VGPRs each), so a tile moves nothing but activations;
+//   * GEMM 1 (v_mfma_f32_32x32x16, filters as the row operand) leaves each lane with 16 consecutive channels of one pixel; the
+//     epilogue adds the residual in place in the LDS tile (fp32 accumulator + bias + residual, ONE rounding, as in conv_pw.hip),
+//     which then is `mid` in its natural [pixel][channel] layout: it is stored to HBM with row-contiguous 16-byte vectors and is
+//     the pixel operand of GEMM 2 (v_mfma_f32_16x16x32) as it lies;
+//   * GEMM 2's 64 x 64 result goes through the (now free) src buffer to be stored row-contiguously.
+// LDS rows are XOR-swizzled per 16-byte slot (src: slot ^ ((row >> 1) & 7), add/mid: slot ^ (row & 15)) on the DMA source side, so
+// every ds_read_b128 / ds_write_b128 below is conflict-free.  Three LDS barriers per tile; vector-memory waits are hand-counted
+// (conv_pw.hip explains why).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct PairArgs {
+    const void* src; const void* w1; const float* bias1; const void* add; void* bits; void* mid;
+    const void* w2; const float* bias2; const void* mask2; void* dst;
+    uint32_t nar_bytes, wide_bytes, bits_bytes;      // [M][64], [M][256], [M][32]
+    int ntiles;
+};
+
+constexpr int PR_BM = 64, PR_CM = 64, PR_CW = 256;
+constexpr int PR_ABUF = PR_BM * PR_CM * 2, PR_RBUF = PR_BM * PR_CW * 2;        // 8 KiB, 32 KiB
+constexpr int PR_ROFF = 2 * PR_ABUF, PR_LDS = 2 * PR_ABUF + 2 * PR_RBUF;       // 80 KiB
+
+template <typename T> struct PrMma32;
+template <> struct PrMma32<__bf16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct PrMma32<_Float16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void pr_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    // m0 = wave-uniform LDS destination; lane l lands at m0 + 16 l (conv_pw.hip pw_dma16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t pr_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void pr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// MODE 0 forward pair, 1 backward pair.  EMIT: forward also writes the ReLU bit mask of `mid`.
+template <typename T, int MODE, bool EMIT>
+__global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    __shared__ __attribute__((aligned(1024))) char smem[PR_LDS];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5, l15 = lane & 15, g = lane >> 4;
+
+    // ---- tile stream: XCD x owns a contiguous segment, its blocks stride through it (conv_pw.hip)
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc(a.add, a.wide_bytes);
+    const __amdgpu_buffer_rsrc_t rmid = make_rsrc(a.mid, a.wide_bytes), rdst = make_rsrc(a.dst, a.nar_bytes);
+    const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? a.bits : a.mid, a.bits ? a.bits_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk2 = make_rsrc(MODE == 1 ? a.mask2 : a.dst, MODE == 1 ? a.nar_bytes : 0u);
+
+    // ---- per-thread tile-relative byte offsets.  Narrow tensors ([.][64], 128-byte rows): instruction i covers rows 8 (wave + 4 i) + (lane >> 3),
+    //      LDS slot lane & 7 holds logical slot (lane & 7) ^ ((row >> 1) & 7).  Wide tensors ([.][256], 512-byte rows): instruction i covers rows
+    //      2 (wave + 4 i) + (lane >> 5), LDS slot lane & 31 holds logical slot (lane & 31) ^ (row & 15).
+    uint32_t aoff[2], roff[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + 4 * i) + (lane >> 3);
+        aoff[i] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 2 * (wave + 4 * i) + (lane >> 5);
+        roff[i] = (uint32_t)(row * 512 + (((lane & 31) ^ (row & 15)) << 4));
+    }
+    auto dma_tile = [&](int t, int buf) {
+        const uint32_t nb = (uint32_t)t * (PR_BM * 128u), wb = (uint32_t)t * (PR_BM * 512u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pr_dma16(rs, lds0 + buf * PR_ABUF + (wave + 4 * i) * 1024, nb + aoff[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pr_dma16(ra, lds0 + PR_ROFF + buf * PR_RBUF + (wave + 4 * i) * 1024, wb + roff[i]);
+    };
+
+    // ---- filters -> registers.  GEMM 1 row operand: MFMA row rho = e + 8 q + 4 hh of the wave's 32-channel sub-tile c2 holds logical
+    //      channel 16 hh + 4 q + e, so that a lane's 16 accumulators are channels 16 h .. 16 h + 15 (one pixel, 32 contiguous bytes).
+    i32x4_t w1f[2][4], w2f[8];
+    {
+        const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(64 * wave + 32 * c2 + lg) * PR_CM + 16 * j + 8 * h) * 2);
+        // GEMM 2 row operand (16x16x32): row l15 of the wave's 16 output channels, k = 32 j + 8 g
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * PR_CW + 32 * j + 8 * g) * 2);
+    }
+    float b1[2][16], b2[4];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[64 * wave + 32 * c2 + 16 * h + r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2[r] = a.bias2 ? a.bias2[16 * wave + 4 * g + r] : 0.f;
+    }
+
+    // ---- LDS read offsets
+    uint32_t g1rd[2];                                          // GEMM 1 pixel operand: src row 32 pt + l31, slot 2 j + h  ->  g1rd[pt] ^ (j << 5)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int row = 32 * pt + l31, s = (row >> 1) & 7;
+        g1rd[pt] = (uint32_t)(row * 128 + ((s >> 1) << 5) + ((h ^ (s & 1)) << 4));
+    }
+    uint32_t e1[2][2];                                         // epilogue 1: add/mid row 32 pt + l31, slots 8 wave + 4 c2 + 2 h (+1: ^ 16)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+            e1[pt][c2] = (uint32_t)((32 * pt + l31) * 512 + (((8 * wave + 4 * c2 + 2 * h) ^ (l31 & 15)) << 4));
+    uint32_t g2rd[4];                                          // GEMM 2 pixel operand: mid row 16 pt + l15, slot 4 j + g  ->  g2rd[pt] ^ (j << 6)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) g2rd[pt] = (uint32_t)((16 * pt + l15) * 512 + ((g ^ l15) << 4));
+    uint32_t e2[4];                                            // epilogue 2: dst row 16 pt + l15, channels 16 wave + 4 g .. +3 (8 bytes)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int row = 16 * pt + l15, slot = 2 * wave + (g >> 1);
+        e2[pt] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + 8 * (g & 1));
+    }
+    // bit-mask bytes of a pixel's 64 channels owned by this wave: [pixel][32] bytes, bytes 8 wave .. 8 wave + 7
+    const uint32_t bitoff = (uint32_t)(l31 * 32 + 8 * wave);
+
+    // vector-memory operations a tile issues after its dma_tile(next): the stores
+    constexpr int NST = 8 + 2 + ((MODE == 0 && EMIT) ? 2 : 0); // mid stores + dst stores + bit-mask stores
+
+    i32x2_t pbits[2];                                          // backward: bit masks of the tile being computed
+    i32x4_t pm2[2];                                            //           mask2 vectors of its dst rows
+    auto prefetch = [&](int t) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (PR_BM * 32u) + pt * 1024u + bitoff, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (PR_BM * 128u) + aoff[i]);
+        }
+    };
+
+    prefetch(tile);
+    dma_tile(tile, 0);
+    int buf = 0;
+    bool first = true;
+    while (true) {
+        const bool has_next = tile + bpx < t_end;
+        // ---- (1) this tile's inputs have landed (issued one tile ago; younger: that tile's prefetches and stores)
+        if (first) pr_wait_vm<0>(); else pr_wait_vm<NST>();
+        first = false;
+        pr_barrier();
+        i32x2_t cbits[2]; i32x4_t cm2[2];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                       // pin the consumption of the prefetched vectors HERE: the compiler's own wait for
+                cbits[i] = pbits[i]; cm2[i] = pm2[i];           // them then sits before the next tile's requests instead of behind them
+                asm volatile("" : "+v"(cbits[i]), "+v"(cm2[i]));
+            }
+        }
+        if (has_next) { prefetch(tile + bpx); dma_tile(tile + bpx, buf ^ 1); }
+        const char* sA = smem + buf * PR_ABUF;
+        char* sR = smem + PR_ROFF + buf * PR_RBUF;
+
+        // ---- GEMM 1: [64 px] x [wave's 64 channels], K = 64
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pt][c2][r] = (MODE == 0) ? b1[c2][r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            i32x4_t px[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) px[pt] = *(const i32x4_t*)(sA + (g1rd[pt] ^ (uint32_t)(j << 5)));
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) PrMma32<T>::run(w1f[c2][j], px[pt], acc[pt][c2]);
+        }
+        // ---- epilogue 1, in place in the add tile: mid = act(acc + add)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            uint32_t keep[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                i32x4_t rv[2];
+                rv[0] = *(const i32x4_t*)(sR + e1[pt][c2]);
+                rv[1] = *(const i32x4_t*)(sR + (e1[pt][c2] ^ 16u));
+                uint32_t mbits = 0xFFFFu;
+                if constexpr (MODE == 1) mbits = ((uint32_t)(c2 ? cbits[pt].y : cbits[pt].x) >> (16 * h)) & 0xFFFFu;
+                uint32_t obits = 0;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    T res[8], out[8];
+                    __builtin_memcpy(res, &rv[v], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = acc[pt][c2][8 * v + e] + Elem<T>::to_f(res[e]);
+                        if constexpr (MODE == 0) x = fmaxf(x, 0.f);
+                        else x = ((mbits >> (8 * v + e)) & 1u) ? x : 0.f;
+                        out[e] = Elem<T>::from_f(x);
+                        if constexpr (MODE == 0 && EMIT) obits |= (Elem<T>::to_f(out[e]) > 0.f ? 1u : 0u) << (8 * v + e);
+                    }
+                    __builtin_memcpy(&rv[v], out, 16);
+                }
+                *(i32x4_t*)(sR + e1[pt][c2]) = rv[0];
+                *(i32x4_t*)(sR + (e1[pt][c2] ^ 16u)) = rv[1];
+                keep[c2] = obits;
+            }
+            if constexpr (MODE == 0 && EMIT) {
+                // the pixel's 64 channels of this wave = 8 bytes: [c2 = 0: h = 0 | h = 1][c2 = 1: h = 0 | h = 1]; lane h = 0 stores them
+                const uint32_t o0 = (uint32_t)__shfl_xor((int)keep[0], 32, 64), o1 = (uint32_t)__shfl_xor((int)keep[1], 32, 64);
+                const i32x2_t pk = i32x2_t{(int)(keep[0] | (o0 << 16)), (int)(keep[1] | (o1 << 16))};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, pk), rbit,
+                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (PR_BM * 32u) + pt * 1024u + bitoff, 0, 0);
+            }
+        }
+        pr_barrier();                                           // (2) mid complete in LDS
+        // ---- mid -> HBM, row-contiguous (same slot map as the DMA that brought the add tile in)
+        {
+            const uint32_t wb = (uint32_t)tile * (PR_BM * 512u);
+            i32x4_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *(const i32x4_t*)(sR + (wave + 4 * i) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) buf_store16(rmid, wb + roff[i], v[i]);
+        }
+        // ---- GEMM 2: [64 px] x [wave's 16 output channels], K = 256
+        f32x4_t acc2[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[pt][r] = (MODE == 0) ? b2[r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            i32x4_t px[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) px[pt] = *(const i32x4_t*)(sR + (g2rd[pt] ^ (uint32_t)(j << 6)));
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) Mma<T>::run(w2f[j], px[pt], acc2[pt]);
+        }
+        // ---- epilogue 2 -> the src buffer of this tile (every wave is past GEMM 1), then row-contiguous stores
+        char* sO = smem + buf * PR_ABUF;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            T out[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc2[pt][r];
+                if constexpr (MODE == 0) x = fmaxf(x, 0.f);
+                out[r] = Elem<T>::from_f(x);
+            }
+            i32x2_t pk;
+            __builtin_memcpy(&pk, out, 8);
+            *(i32x2_t*)(sO + e2[pt]) = pk;
+        }
+        pr_barrier();                                           // (3)
+        {
+            const uint32_t nb = (uint32_t)tile * (PR_BM * 128u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                i32x4_t v = *(const i32x4_t*)(sO + (wave + 4 * i) * 1024 + lane * 16);
+                if constexpr (MODE == 1) {
+                    T x[8], m[8];
+                    __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &cm2[i], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = Elem<T>::to_f(m[e]) > 0.f ? x[e] : Elem<T>::from_f(0.f);
+                    __builtin_memcpy(&v, x, 16);
+                }
+                buf_store16(rdst, nb + aoff[i], v);
+            }
+        }
+        if (!has_next) break;
+        tile += bpx; buf ^= 1;
+    }
+}
+
+static int pr_device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) {
+    return (M > 0 && M % PR_BM == 0 && M * PR_CW * 2 < 0x7FFFFF00ll && (dt == URSO_BF16 || dt == URSO_F16) && c_narrow == PR_CM && c_wide == PR_CW) ? 1 : 0;
+}
+
+extern "C" int urso_conv_pair(long long M, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d, const void* add_d,
+                              void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d, void* dst_d, void* stream) {
+    if (!urso_conv_pair_ok(M, dt, PR_CM, PR_CW)) { urso_set_error("urso_conv_pair: M %% 64 != 0, tensor >= 2 GiB or dtype not 16-bit"); return URSO_EINVAL; }
+    if (!src_d || !w1_d || !add_d || !mid_d || !w2_d || !dst_d || (mode != 0 && mode != 1) || (mode == 1 && (!bits_d || !mask2_d))) {
+        urso_set_error("urso_conv_pair: bad argument"); return URSO_EINVAL;
+    }
+    if ((((uintptr_t)src_d) | ((uintptr_t)w1_d) | ((uintptr_t)add_d) | ((uintptr_t)mid_d) | ((uintptr_t)w2_d) | ((uintptr_t)dst_d) |
+         ((uintptr_t)bits_d) | ((uintptr_t)mask2_d)) & 15) { urso_set_error("urso_conv_pair: pointers must be 16-byte aligned"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    PairArgs a;
+    a.src = src_d; a.w1 = w1_d; a.bias1 = bias1_d; a.add = add_d; a.bits = bits_d; a.mid = mid_d; a.w2 = w2_d; a.bias2 = bias2_d;
+    a.mask2 = mask2_d; a.dst = dst_d;
+    a.nar_bytes = (uint32_t)(M * PR_CM * 2); a.wide_bytes = (uint32_t)(M * PR_CW * 2); a.bits_bytes = (uint32_t)(M * (PR_CW / 8));
+    a.ntiles = (int)(M / PR_BM);
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = 2 * pr_device_cus() / 8;
+    if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
+    const double flops = 2.0 * (double)M * PR_CM * PR_CW * 2.0;
+    const double bytes = (double)M * (2.0 * PR_CM * 2 + 2.0 * PR_CW * 2) + (double)M * (PR_CW / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
+                         (mode == 1 ? (double)M * PR_CM * 2 : 0.0) + 2.0 * PR_CM * PR_CW * 2;
+    ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
+    const dim3 grid(8 * bpx), blk(256);
+    if (dt == URSO_BF16) {
+        if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false>), grid, blk, 0, st, a);
+        else if (bits_d) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false>), grid, blk, 0, st, a);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false>), grid, blk, 0, st, a);
+        else if (bits_d) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false>), grid, blk, 0, st, a);
+    }
+    return urso_check_launch("urso_conv_pair");
+}

@@ -289,6 +289,7 @@ class Engine(object):
                                                                      c.res.data if c.res is not None else None, n.relu, c.dst.data))
                 self.labels["fwd"].append("bn_apply:" + node.name)
             else:
+                c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
                     c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
                     c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits, self.igemm_ws if c.ws_f else None))
@@ -296,6 +297,7 @@ class Engine(object):
             if training and node.stem:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(147, c.N))
+        self._fuse_pointwise_pairs()
         self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
         self.bn_ws = torch.empty(max_bn_ws // 8 + 32, dtype=torch.float64, device=dev) if max_bn_ws else None
         self._descs = descs
@@ -423,9 +425,24 @@ class Engine(object):
                 else:
                     R.grad, R.grad_written = Gsum, True
             # -- data gradient into the conv input
+            if getattr(c, "dgrad_done_by_pair", False):
+                continue                                   # written by the fused launch of the layer above (see below)
             if not node.stem and need[c.src.spec.id]:
                 X = c.src
                 add = X.grad if X.grad_written else X.pending
+                A = self.pair_first.get(node.name)         # this layer is the second of a fused forward pair (A = the block-closing 2c)
+                if (A is not None and X.spec.relu and X.bits is not None and X.pending is not None and not X.grad_written and
+                        need[A.src.spec.id] and A.src.spec.relu and A.src.bits is None and not A.src.grad_written and A.src.pending is None):
+                    # data gradient of this layer into X (+ residual gradient, ReLU bit mask) and, from the LDS copy of that result,
+                    # the data gradient of layer A into ITS input: X.grad crosses HBM once (conv_pair.hip)
+                    dstg, dst2 = X.grad_buf(), A.src.grad_buf()
+                    self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2:
+                                         hip.conv_pair(A.Mpix, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2)))
+                    self.labels["bwd"].append("dgrad:%s+%s" % (node.name, A.name))
+                    X.grad_written, X.pending = True, None
+                    A.src.grad_written = True
+                    A.dgrad_done_by_pair = True
+                    continue
                 dstg = X.grad_buf()
                 mask = (X.bits if X.bits is not None else X.data) if X.spec.relu else None
                 mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
@@ -577,6 +594,40 @@ class Engine(object):
         else:
             self.gt_ori = torch.zeros(B, nori, dtype=torch.float32, device=dev)
             self.loss_ops.append(lambda: hip.softmax_xent(B, nori, ori.data, self.gt_ori, wo, 1, dt, self.loss_buf[1:2], gz_ori, self.row_ws))
+
+    def _fuse_pointwise_pairs(self):
+        """Forward plan rewrite: a block-closing pointwise layer (64 -> 256, + residual, ReLU) directly followed by the next block's
+        opening pointwise layer (256 -> 64, ReLU) becomes ONE launch (urso_conv_pair): the 256-channel block output is written once and
+        the second layer reads it from LDS.  self.pair_first maps the second layer's name to the first layer's _Conv; the backward
+        plan mirrors the fusion for the two data gradients.  URSO_OPT_PAIR=0 (hip.options(pair=0)) keeps the layers apart."""
+        self.pair_first = {}
+        g, dt = self.graph, self.dt
+        if dt == hip.F32 or not hip.get_option("pair"):
+            return
+        convs = [n for n in g.nodes if n.op != "pool"]
+        drop = []
+        for a_node, b_node in zip(convs[:-1], convs[1:]):
+            A, Bc = self.convs[a_node.name], self.convs[b_node.name]
+
+            def plain(n, c):
+                return (not n.stem and not n.dense and n.kh == 1 and n.kw == 1 and n.stride == 1 and n.relu and not n.out_f32 and
+                        not c.batch_bn and c.npad == c.N and hasattr(c, "fwd_index"))
+            if not (plain(a_node, A) and plain(b_node, Bc)):
+                continue
+            if a_node.residual is None or b_node.residual is not None or b_node.src.id != a_node.dst.id:
+                continue
+            M = self.B * a_node.dst.h * a_node.dst.w
+            if not (a_node.cin == b_node.cout and hip.conv_pair_ok(M, dt, a_node.cin, a_node.cout)):
+                continue
+            A.Mpix = M
+            self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc: hip.conv_pair(A.Mpix, dt, 0, A.src.data, A.wf, A.biasf, A.res.data, A.dst.bits,
+                                                                         A.dst.data, Bc.wf, Bc.biasf, None, Bc.dst.data))
+            self.labels["fwd"][A.fwd_index] = "fwd:%s+%s" % (a_node.name, b_node.name)
+            drop.append(Bc.fwd_index)
+            self.pair_first[b_node.name] = A
+        for i in sorted(drop, reverse=True):
+            del self.fwd_ops[i]
+            del self.labels["fwd"][i]
 
     # ------------------------------------------------------------------ execution
     def run_prep(self):
