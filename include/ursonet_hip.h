@@ -122,21 +122,24 @@ int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
                        const void* add_d, const void* mask_d, void* dst_d, void* bits_out_d,
                        void* ws_d, size_t ws_bytes, void* stream);
 
-/* Two chained pointwise layers of a stage-2 bottleneck boundary in one pass over the pixels (conv_pair.hip), 16-bit dtypes,
- * narrow = 64 and wide = 256 channels, M = pixels (M % 64 == 0; urso_conv_pair_ok() tells whether a shape qualifies):
+/* Two chained pointwise layers across a bottleneck-block boundary in one pass over the pixels (conv_pair.hip), 16-bit dtypes.
+ * c_narrow = 64 (stage 2: wide = 256 channels, M % 64 == 0) or 128 (stage 3: wide = 512, M % 32 == 0), M = pixels;
+ * urso_conv_pair_ok() tells whether a shape qualifies:
  *   mode 0 (forward):  mid = relu(src W1^T + bias1 + add);  dst = relu(mid W2^T + bias2)
- *                      = Conv2D 1x1 'res2x_branch2c' + BatchNorm + Add + ReLU, then the next block's 'branch2a' + BatchNorm + ReLU
+ *                      = Conv2D 1x1 'resNx_branch2c' + BatchNorm + Add + ReLU, then the next block's 'branch2a' + BatchNorm + ReLU
  *                        (net.py:148-157, 101-104); bits_d (optional) receives the ReLU bit mask of mid as URSO_EPI_EMIT_BITS does;
  *   mode 1 (backward): mid = (src W1^T + add) where bits_d is set, else 0;  dst = (mid W2^T) where mask2 > 0, else 0
  *                      = the data gradient of that 'branch2a' into the block input (add = the residual branch's gradient, bits_d = the
  *                        input's ReLU mask), then the data gradient of the previous block's 'branch2c' into its 'branch2b' output
  *                        (mask2 = that output).
- * src/dst/mask2: dt [M][64]; add/mid: dt [M][256]; w1: dt [256][64], w2: dt [64][256] (the wf / wd layouts of
- * urso_conv_weight_prep); bias1 fp32 [256], bias2 fp32 [64] (mode 0, NULL = 0); bits: [M][32] bytes.  Results are the ones of the
- * two urso_conv_igemm_ex calls it replaces (same fp32 accumulation, one rounding per stored tensor); `mid` crosses HBM once. */
+ * src/dst/mask2: dt [M][narrow]; add/mid: dt [M][wide]; w1: dt [wide][narrow], w2: dt [narrow][wide] (the wf / wd layouts of
+ * urso_conv_weight_prep); bias1 fp32 [wide], bias2 fp32 [narrow] (mode 0, NULL = 0); bits: [M][wide/8] bytes.  Results are the ones
+ * of the two urso_conv_igemm_ex calls it replaces (same fp32 accumulation, one rounding per stored tensor; bit-identical in mode 1);
+ * `mid` crosses HBM once. */
 int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide);
-int urso_conv_pair(long long M, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d, const void* add_d,
-                   void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d, void* dst_d, void* stream);
+int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,
+                   const void* add_d, void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d,
+                   void* dst_d, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel). */

@@ -705,32 +705,35 @@ def test_batch_stat_bn_kernels_against_autograd(dt, MN):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0)], ids=["one_tile", "small", "capped", "multi_tile"])
-def test_fused_pointwise_pair_forward_and_backward(dt, shape):
+@pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
+@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0), (32, 32, 40, 0)],
+                         ids=["one_tile", "small", "capped", "multi_tile", "chip"])
+def test_fused_pointwise_pair_forward_and_backward(dt, shape, c):
     """urso_conv_pair (conv_pair.hip) against a CPU fp32 reference with the same two rounding points (the 256-channel tensor and the
     64-channel output are each rounded once to the storage dtype), forward form (bias + residual + ReLU, then bias + ReLU, with the
     emitted ReLU bit mask) and backward form (residual-gradient add + bit mask, then activation mask); and against the two
-    urso_conv_igemm_ex launches it replaces.  'capped' / 'multi_tile' make every block walk several tiles."""
+    urso_conv_igemm_ex launches it replaces.  'capped' / 'multi_tile' make every block walk several tiles, 'chip' gives every resident block of the chip a few; c = 64 / 128 are the
+    stage-2 (4 waves, 2 LDS stages) and stage-3 (8 waves, 3 LDS stages) shapes of the kernel."""
     hip = _hip()
     B, H, W, cap = shape
     M = B * H * W
     tdt = hip.TORCH_DT[dt]
     torch.manual_seed(M + dt)
-    assert hip.conv_pair_ok(M, dt, 64, 256) and not hip.conv_pair_ok(M + 1, dt, 64, 256) and not hip.conv_pair_ok(M, 0, 64, 256)
-    assert not hip.conv_pair_ok(M, dt, 128, 512)
-    src, add, act = dev(torch.randn(M, 64), dt), dev(torch.randn(M, 256), dt), dev(torch.randn(M, 64), dt)
-    w1, w2 = dev(torch.randn(256, 64) / 8, dt), dev(torch.randn(64, 256) / 16, dt)
-    b1, b2 = torch.randn(256, device="cuda") * 0.3, torch.randn(64, device="cuda") * 0.3
+    assert hip.conv_pair_ok(M, dt, c, 4 * c) and not hip.conv_pair_ok(M + 1, dt, c, 4 * c) and not hip.conv_pair_ok(M, 0, c, 4 * c)
+    assert not hip.conv_pair_ok(M, dt, 256, 1024) and not hip.conv_pair_ok(M, dt, c, 2 * c)
+    src, add, act = dev(torch.randn(M, c), dt), dev(torch.randn(M, 4 * c), dt), dev(torch.randn(M, c), dt)
+    w1, w2 = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
+    b1, b2 = torch.randn(4 * c, device="cuda") * 0.3, torch.randn(c, device="cuda") * 0.3
     rnd = lambda t: t.to(tdt).float()
     f = lambda t: t.float().cpu()
     tol = 1.2e-2 if dt == 1 else 1.5e-3                     # one output rounding step on values of a few units
     # ---- forward
-    mid = torch.full((M, 256), 9.0, device="cuda").to(tdt); dst = torch.full((M, 64), 9.0, device="cuda").to(tdt)
-    bits = torch.full((M, 32), 0xAA, dtype=torch.uint8, device="cuda")
+    mid = torch.full((M, 4 * c), 9.0, device="cuda").to(tdt); dst = torch.full((M, c), 9.0, device="cuda").to(tdt)
+    bits = torch.full((M, c // 2), 0xAA, dtype=torch.uint8, device="cuda")
     with hip.options(grid_cap=cap):
-        hip.conv_pair(M, dt, 0, src, w1, b1, add, bits, mid, w2, b2, None, dst)
+        hip.conv_pair(M, c, dt, 0, src, w1, b1, add, bits, mid, w2, b2, None, dst)
         mid_nb = torch.empty_like(mid); dst_nb = torch.empty_like(dst)
-        hip.conv_pair(M, dt, 0, src, w1, b1, add, None, mid_nb, w2, b2, None, dst_nb)      # variant without the bit mask
+        hip.conv_pair(M, c, dt, 0, src, w1, b1, add, None, mid_nb, w2, b2, None, dst_nb)      # variant without the bit mask
     torch.cuda.synchronize()
     assert torch.equal(mid, mid_nb) and torch.equal(dst, dst_nb)
     ref_mid = rnd(torch.relu(f(src) @ f(w1).T + b1.cpu() + f(add)))
@@ -740,7 +743,7 @@ def test_fused_pointwise_pair_forward_and_backward(dt, shape):
     pos = (mid.float() > 0).reshape(-1, 8).to(torch.int32)
     exp = (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
     assert torch.equal(bits.reshape(-1), exp) and 0.2 < float(pos.float().mean()) < 0.8
-    g1, g2 = hip.geom(B, H, W, 64, H, W, 256, 1, 1), hip.geom(B, H, W, 256, H, W, 64, 1, 1)
+    g1, g2 = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1), hip.geom(B, H, W, 4 * c, H, W, c, 1, 1)
     m2, d2, bits2 = torch.empty_like(mid), torch.empty_like(dst), torch.empty_like(bits)
     hip.conv_igemm_ex(g1, dt, hip.EPI_RELU | hip.EPI_EMIT_BITS, src, w1, b1, add, None, m2, bits2)
     hip.conv_igemm_ex(g2, dt, hip.EPI_RELU, m2, w2, b2, None, None, d2)
@@ -748,18 +751,18 @@ def test_fused_pointwise_pair_forward_and_backward(dt, shape):
     assert float((mid.float() - m2.float()).abs().max()) <= tol * float(m2.float().abs().max())
     assert float((dst.float() - d2.float()).abs().max()) <= 2 * tol * float(d2.float().abs().max())
     # ---- backward (no bias: bit-identical to the separate launches)
-    gbits = torch.randint(0, 256, (M, 32), dtype=torch.uint8, device="cuda")
+    gbits = torch.randint(0, 256, (M, c // 2), dtype=torch.uint8, device="cuda")
     with hip.options(grid_cap=cap):
-        hip.conv_pair(M, dt, 1, src, w1, None, add, gbits, mid, w2, None, act, dst)
+        hip.conv_pair(M, c, dt, 1, src, w1, None, add, gbits, mid, w2, None, act, dst)
     hip.conv_igemm_ex(g1, dt, hip.EPI_MASK_BITS, src, w1, None, add, gbits, m2)
     hip.conv_igemm_ex(g2, dt, 0, m2, w2, None, None, act, d2)
     torch.cuda.synchronize()
     assert torch.equal(mid, m2) and torch.equal(dst, d2)
-    keep = ((gbits.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, 256).float()
+    keep = ((gbits.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, 4 * c).float()
     ref_mid = rnd((f(src) @ f(w1).T + f(add)) * keep)
     assert float((f(mid) - ref_mid).abs().max()) <= tol * max(1.0, float(ref_mid.abs().max()))
     ref_dst = rnd((f(mid) @ f(w2).T) * (f(act) > 0))
     assert float((f(dst) - ref_dst).abs().max()) <= tol * max(1.0, float(ref_dst.abs().max()))
     assert float((dst.float() != 0).float().mean()) > 0.1
     with pytest.raises(hip.UrsoHipError):
-        hip.conv_pair(M, dt, 1, src, w1, None, add, None, mid, w2, None, act, dst)          # backward form needs the bit mask
+        hip.conv_pair(M, c, dt, 1, src, w1, None, add, None, mid, w2, None, act, dst)          # backward form needs the bit mask

@@ -169,7 +169,7 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     filters, every stored activation, every activation gradient): outputs, losses, EVERY parameter gradient (relative to the
     tensor's max), the global norm and the post-step weights -- not a cosine.  'capped' additionally forces the multi-tile
     stream of the DMA conv kernels (conv_pw.hip) and of the fused pair kernel inside this oracle-compared step; 'fused' / 'apart' run
-    the plan with and without the fused stage-2 pointwise pairs (conv_pair.hip).  A mis-scaled or mis-indexed layer
+    the plan with and without the fused stage-2/3 pointwise pairs (conv_pair.hip).  A mis-scaled or mis-indexed layer
     cannot pass at these tolerances (a wrong scale of 2 in one tensor is a 50 % error).  Measured on MI355X (r50, 2 x 128 x 192):
     bf16 outputs 8e-3, losses 3e-3, worst gradient tensor 2.0e-2 (a 64-element BN gamma; filters ~1e-2), global norm 5e-3,
     post-step weights 3e-5; fp16 outputs 1.2e-3, worst gradient 3.2e-3, norm 7e-4, weights 6e-6.  What remains is the order of the
@@ -186,7 +186,7 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     img, loc, ori, _ = synthetic_batch(cfg, 2, seed=1)
     with hip.options(grid_cap=cap, pair=pair):
         eng, w0 = _run_engine(cfg, img, loc, ori)
-    assert len(eng.pair_first) == (2 if pair else 0)
+    assert len(eng.pair_first) == (5 if pair else 0)          # res2{b,c}, res3{b,c,d}: branch2a fused behind the previous block's branch2c
     q = G.StorageRounding(torch.bfloat16 if dtype == "bfloat16" else torch.float16)
     dec = ReluDecisions(eng, tol=4 * tol_out)
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
@@ -538,9 +538,9 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
-    """Engine plan with the stage-2 pointwise pairs fused (urso_conv_pair, default) against the plan with every layer launched on
-    its own (option pair=0): same outputs and losses up to the rounding flips of the fused layers' outputs, four launches fewer (two
-    forward pairs, two backward pairs in ResNet-50)."""
+    """Engine plan with the stage-2 and stage-3 pointwise pairs fused (urso_conv_pair, default) against the plan with every layer
+    launched on its own (option pair=0): same outputs and losses up to the rounding flips of the fused layers' outputs, ten launches
+    fewer (five forward pairs, five backward pairs in ResNet-50)."""
     from ursonet_amd import hip
     from ursonet_amd.engine import Engine
     cfg = make_config("resnet50", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
@@ -552,8 +552,8 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
                     sorted(eng.pair_first)))
-    assert res[0][5] == ["res2b_branch2a", "res2c_branch2a"] and res[1][5] == []
-    assert res[1][0] - res[0][0] == 2 and res[1][1] - res[0][1] == 2
+    assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
+    assert res[1][0] - res[0][0] == 5 and res[1][1] - res[0][1] == 5
     tol_out = 2e-2 if dtype == "bfloat16" else 2e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])

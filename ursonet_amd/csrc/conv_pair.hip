@@ -28,13 +28,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct PairArgs {
     const void* src; const void* w1; const float* bias1; const void* add; void* bits; void* mid;
     const void* w2; const float* bias2; const void* mask2; void* dst;
-    uint32_t nar_bytes, wide_bytes, bits_bytes;      // [M][64], [M][256], [M][32]
+    uint32_t nar_bytes, wide_bytes, bits_bytes;      // [M][CM], [M][CW], [M][CW/8]
     int ntiles;
 };
-
-constexpr int PR_BM = 64, PR_CM = 64, PR_CW = 256;
-constexpr int PR_ABUF = PR_BM * PR_CM * 2, PR_RBUF = PR_BM * PR_CW * 2;        // 8 KiB, 32 KiB
-constexpr int PR_ROFF = 2 * PR_ABUF, PR_LDS = 2 * PR_ABUF + 2 * PR_RBUF;       // 80 KiB
 
 template <typename T> struct PrMma32;
 template <> struct PrMma32<__bf16> {
@@ -59,11 +55,30 @@ __device__ __forceinline__ i32x4_t pr_rsrc(const void* p, uint32_t bytes) {
 template <int N> __device__ __forceinline__ void pr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Two shapes of the same kernel (CW = 4 CM; every wave owns 64 of the CW channels in GEMM 1 and 16 of the CM channels in GEMM 2):
+//   stage 2:  CM  64, CW 256, 4 waves, 64-pixel tiles, 2 LDS stages ( 80 KiB): two blocks per CU, inputs one tile ahead;
+//   stage 3:  CM 128, CW 512, 8 waves, 32-pixel tiles, 3 LDS stages (120 KiB): one block per CU (the filters take 128 VGPRs per lane,
+//             so only 8 waves fit), inputs TWO tiles ahead to keep the same ~80 KiB per CU in flight.
+template <int CM_, int NW_, int BM_, int NBUF_> struct PairShape {
+    static constexpr int CM = CM_, CW = 4 * CM_, NW = NW_, BM = BM_, NBUF = NBUF_, D = NBUF_ - 1;
+    static constexpr int AROW = CM * 2, RROW = CW * 2, BROW = CW / 8;         // bytes per pixel: narrow row, wide row, bit-mask row
+    static constexpr int ABUF = BM * AROW, RBUF = BM * RROW, ROFF = NBUF * ABUF, LDS = NBUF * (ABUF + RBUF);
+    static constexpr int NA = ABUF / (1024 * NW), NR = RBUF / (1024 * NW);     // DMA instructions per lane and tile
+    static constexpr int PT1 = BM / 32, KS1 = CM / 16, PT2 = BM / 16, KS2 = CW / 32;
+    static_assert(CW / NW == 64 && CM / NW == 16 && NA >= 1 && NR >= 1 && PT1 >= 1, "wave roles");
+    // 16-byte slot swizzle of a narrow row: 128-byte rows pair up per 256-byte bank row, 256-byte rows fill one each
+    static __device__ __forceinline__ int aswz(int row) { return AROW == 128 ? ((row >> 1) & 7) : (row & 15); }
+};
+using PairS2 = PairShape<64, 4, 64, 2>;
+using PairS3 = PairShape<128, 8, 32, 3>;
+
 // MODE 0 forward pair, 1 backward pair.  EMIT: forward also writes the ReLU bit mask of `mid`.
-template <typename T, int MODE, bool EMIT>
-__global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
+template <typename T, int MODE, bool EMIT, typename S>
+__global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ __attribute__((aligned(1024))) char smem[PR_LDS];
+    constexpr int BM = S::BM, CM = S::CM, CW = S::CW, NW = S::NW, AROW = S::AROW, RROW = S::RROW, BROW = S::BROW;
+    constexpr int NA = S::NA, NR = S::NR, PT1 = S::PT1, KS1 = S::KS1, PT2 = S::PT2, KS2 = S::KS2, D = S::D, NBUF = S::NBUF;
+    __shared__ __attribute__((aligned(1024))) char smem[S::LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5, l15 = lane & 15, g = lane >> 4;
@@ -80,42 +95,42 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
     const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? a.bits : a.mid, a.bits ? a.bits_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rmk2 = make_rsrc(MODE == 1 ? a.mask2 : a.dst, MODE == 1 ? a.nar_bytes : 0u);
 
-    // ---- per-thread tile-relative byte offsets.  Narrow tensors ([.][64], 128-byte rows): instruction i covers rows 8 (wave + 4 i) + (lane >> 3),
-    //      LDS slot lane & 7 holds logical slot (lane & 7) ^ ((row >> 1) & 7).  Wide tensors ([.][256], 512-byte rows): instruction i covers rows
-    //      2 (wave + 4 i) + (lane >> 5), LDS slot lane & 31 holds logical slot (lane & 31) ^ (row & 15).
-    uint32_t aoff[2], roff[8];
+    // ---- per-thread tile-relative byte offsets: instruction i of a wave moves 1024 contiguous LDS bytes (row-major rows of the tile);
+    //      LDS slot p of a row holds logical slot p ^ swizzle(row).  The same offsets serve the row-contiguous stores of mid and dst.
+    uint32_t aoff[NA], roff[NR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 8 * (wave + 4 * i) + (lane >> 3);
-        aoff[i] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+    for (int i = 0; i < NA; ++i) {
+        const int row = (1024 / AROW) * (wave + NW * i) + lane / (AROW / 16), p = lane % (AROW / 16);
+        aoff[i] = (uint32_t)(row * AROW + ((p ^ S::aswz(row)) << 4));
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 2 * (wave + 4 * i) + (lane >> 5);
-        roff[i] = (uint32_t)(row * 512 + (((lane & 31) ^ (row & 15)) << 4));
+    for (int i = 0; i < NR; ++i) {
+        const int row = (1024 / RROW) * (wave + NW * i) + lane / (RROW / 16), p = lane % (RROW / 16);
+        roff[i] = (uint32_t)(row * RROW + ((p ^ (row & 15)) << 4));
     }
     auto dma_tile = [&](int t, int buf) {
-        const uint32_t nb = (uint32_t)t * (PR_BM * 128u), wb = (uint32_t)t * (PR_BM * 512u);
+        const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)(BM * RROW);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pr_dma16(rs, lds0 + buf * PR_ABUF + (wave + 4 * i) * 1024, nb + aoff[i]);
+        for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pr_dma16(ra, lds0 + PR_ROFF + buf * PR_RBUF + (wave + 4 * i) * 1024, wb + roff[i]);
+        for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + roff[i]);
     };
+    constexpr int NDMA = NA + NR;
 
     // ---- filters -> registers.  GEMM 1 row operand: MFMA row rho = e + 8 q + 4 hh of the wave's 32-channel sub-tile c2 holds logical
     //      channel 16 hh + 4 q + e, so that a lane's 16 accumulators are channels 16 h .. 16 h + 15 (one pixel, 32 contiguous bytes).
-    i32x4_t w1f[2][4], w2f[8];
+    i32x4_t w1f[2][KS1], w2f[KS2];
     {
         const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(64 * wave + 32 * c2 + lg) * PR_CM + 16 * j + 8 * h) * 2);
+            for (int j = 0; j < KS1; ++j)
+                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(64 * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
         // GEMM 2 row operand (16x16x32): row l15 of the wave's 16 output channels, k = 32 j + 8 g
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * PR_CW + 32 * j + 8 * g) * 2);
+        for (int j = 0; j < KS2; ++j)
+            w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * CW + 32 * j + 8 * g) * 2);
     }
     float b1[2][16], b2[4];
     if constexpr (MODE == 0) {
@@ -128,88 +143,97 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
     }
 
     // ---- LDS read offsets
-    uint32_t g1rd[2];                                          // GEMM 1 pixel operand: src row 32 pt + l31, slot 2 j + h  ->  g1rd[pt] ^ (j << 5)
+    uint32_t g1rd[PT1][2];                                     // GEMM 1 pixel operand: src row 32 pt + l31, slot 2 j + h: [pt][j & 1 ... ] see below
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int row = 32 * pt + l31, s = (row >> 1) & 7;
-        g1rd[pt] = (uint32_t)(row * 128 + ((s >> 1) << 5) + ((h ^ (s & 1)) << 4));
+    for (int pt = 0; pt < PT1; ++pt) {
+        const int row = 32 * pt + l31;
+        g1rd[pt][0] = (uint32_t)(row * AROW);                  // + ((2 j + h) ^ swz) << 4, formed per k-step (constant folding keeps it cheap)
+        g1rd[pt][1] = (uint32_t)S::aswz(row);
     }
-    uint32_t e1[2][2];                                         // epilogue 1: add/mid row 32 pt + l31, slots 8 wave + 4 c2 + 2 h (+1: ^ 16)
+    uint32_t e1[PT1][2];                                       // epilogue 1: add/mid row 32 pt + l31, slots 8 wave + 4 c2 + 2 h (+1: ^ 16)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
-            e1[pt][c2] = (uint32_t)((32 * pt + l31) * 512 + (((8 * wave + 4 * c2 + 2 * h) ^ (l31 & 15)) << 4));
-    uint32_t g2rd[4];                                          // GEMM 2 pixel operand: mid row 16 pt + l15, slot 4 j + g  ->  g2rd[pt] ^ (j << 6)
+            e1[pt][c2] = (uint32_t)((32 * pt + l31) * RROW + (((8 * wave + 4 * c2 + 2 * h) ^ (l31 & 15)) << 4));
+    uint32_t g2rd[PT2];                                        // GEMM 2 pixel operand: mid row 16 pt + l15, slot 4 j + g  ->  g2rd[pt] ^ (j << 6)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) g2rd[pt] = (uint32_t)((16 * pt + l15) * 512 + ((g ^ l15) << 4));
-    uint32_t e2[4];                                            // epilogue 2: dst row 16 pt + l15, channels 16 wave + 4 g .. +3 (8 bytes)
+    for (int pt = 0; pt < PT2; ++pt) g2rd[pt] = (uint32_t)((16 * pt + l15) * RROW + ((g ^ l15) << 4));
+    uint32_t e2[PT2];                                          // epilogue 2: dst row 16 pt + l15, channels 16 wave + 4 g .. +3 (8 bytes)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT2; ++pt) {
         const int row = 16 * pt + l15, slot = 2 * wave + (g >> 1);
-        e2[pt] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + 8 * (g & 1));
+        e2[pt] = (uint32_t)(row * AROW + ((slot ^ S::aswz(row)) << 4) + 8 * (g & 1));
     }
-    // bit-mask bytes of a pixel's 64 channels owned by this wave: [pixel][32] bytes, bytes 8 wave .. 8 wave + 7
-    const uint32_t bitoff = (uint32_t)(l31 * 32 + 8 * wave);
+    // bit-mask bytes of a pixel's 64 channels owned by this wave: [pixel][CW / 8] bytes, bytes 8 wave .. 8 wave + 7
+    const uint32_t bitoff = (uint32_t)(l31 * BROW + 8 * wave);
 
-    // vector-memory operations a tile issues after its dma_tile(next): the stores
-    constexpr int NST = 8 + 2 + ((MODE == 0 && EMIT) ? 2 : 0); // mid stores + dst stores + bit-mask stores
+    // vector-memory operations a tile issues after its requests for later tiles: the stores
+    constexpr int NST = NR + NA + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
 
-    i32x2_t pbits[2];                                          // backward: bit masks of the tile being computed
-    i32x4_t pm2[2];                                            //           mask2 vectors of its dst rows
+    i32x2_t pbits[PT1];                                        // backward: bit masks of the NEXT tile (requested one tile ahead)
+    i32x4_t pm2[NA];                                           //           mask2 vectors of its dst rows
     auto prefetch = [&](int t) {
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (PR_BM * 32u) + pt * 1024u + bitoff, 0, 0));
+            for (int pt = 0; pt < PT1; ++pt)
+                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (uint32_t)(BM * BROW) + pt * 32u * BROW + bitoff, 0, 0));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (PR_BM * 128u) + aoff[i]);
+            for (int i = 0; i < NA; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (uint32_t)(BM * AROW) + aoff[i]);
         }
     };
 
+    // ---- prologue: the first D tiles' inputs
     prefetch(tile);
     dma_tile(tile, 0);
+    if constexpr (D == 2) { if (tile + bpx < t_end) dma_tile(tile + bpx, 1); }
     int buf = 0;
     bool first = true;
     while (true) {
-        const bool has_next = tile + bpx < t_end;
-        // ---- (1) this tile's inputs have landed (issued one tile ago; younger: that tile's prefetches and stores)
-        if (first) pr_wait_vm<0>(); else pr_wait_vm<NST>();
+        const bool has_next = tile + bpx < t_end;              // tile k + 1 exists
+        const bool has_far = tile + D * bpx < t_end;           // tile k + D exists (its inputs are requested in this iteration)
+        // ---- (1) this tile's inputs (and its prefetched vectors) have landed.  Younger than them: with D = 2 the inputs of tile k + 1,
+        //      and the stores of tile k - 1
+        if constexpr (D == 1) { if (first) pr_wait_vm<0>(); else pr_wait_vm<NST>(); }
+        else {
+            if (first) { if (has_next) pr_wait_vm<NDMA>(); else pr_wait_vm<0>(); }
+            else { if (has_next) pr_wait_vm<NST + NDMA>(); else pr_wait_vm<NST>(); }
+        }
         first = false;
         pr_barrier();
-        i32x2_t cbits[2]; i32x4_t cm2[2];
+        i32x2_t cbits[PT1]; i32x4_t cm2[NA];
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {                       // pin the consumption of the prefetched vectors HERE: the compiler's own wait for
-                cbits[i] = pbits[i]; cm2[i] = pm2[i];           // them then sits before the next tile's requests instead of behind them
-                asm volatile("" : "+v"(cbits[i]), "+v"(cm2[i]));
-            }
-        }
-        if (has_next) { prefetch(tile + bpx); dma_tile(tile + bpx, buf ^ 1); }
-        const char* sA = smem + buf * PR_ABUF;
-        char* sR = smem + PR_ROFF + buf * PR_RBUF;
-
-        // ---- GEMM 1: [64 px] x [wave's 64 channels], K = 64
-        f32x16_t acc[2][2];
+            for (int i = 0; i < PT1; ++i) { cbits[i] = pbits[i]; asm volatile("" : "+v"(cbits[i])); }   // pin the consumption of the prefetched
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+            for (int i = 0; i < NA; ++i) { cm2[i] = pm2[i]; asm volatile("" : "+v"(cm2[i])); }           // vectors HERE, ahead of the new requests
+        }
+        if (has_next) prefetch(tile + bpx);
+        if (has_far) { int nb_ = buf + D; if (nb_ >= NBUF) nb_ -= NBUF; dma_tile(tile + D * bpx, nb_); }
+        const char* sA = smem + buf * S::ABUF;
+        char* sR = smem + S::ROFF + buf * S::RBUF;
+
+        // ---- GEMM 1: [BM px] x [wave's 64 channels], K = CM
+        f32x16_t acc[PT1][2];
+#pragma unroll
+        for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pt][c2][r] = (MODE == 0) ? b1[c2][r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            i32x4_t px[2];
+        for (int j = 0; j < KS1; ++j) {
+            i32x4_t px[PT1];
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) px[pt] = *(const i32x4_t*)(sA + (g1rd[pt] ^ (uint32_t)(j << 5)));
+            for (int pt = 0; pt < PT1; ++pt) px[pt] = *(const i32x4_t*)(sA + g1rd[pt][0] + ((((uint32_t)(2 * j + h)) ^ g1rd[pt][1]) << 4));
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) PrMma32<T>::run(w1f[c2][j], px[pt], acc[pt][c2]);
         }
         // ---- epilogue 1, in place in the add tile: mid = act(acc + add)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < PT1; ++pt) {
             uint32_t keep[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
@@ -242,37 +266,37 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
                 const uint32_t o0 = (uint32_t)__shfl_xor((int)keep[0], 32, 64), o1 = (uint32_t)__shfl_xor((int)keep[1], 32, 64);
                 const i32x2_t pk = i32x2_t{(int)(keep[0] | (o0 << 16)), (int)(keep[1] | (o1 << 16))};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, pk), rbit,
-                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (PR_BM * 32u) + pt * 1024u + bitoff, 0, 0);
+                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (uint32_t)(BM * BROW) + pt * 32u * BROW + bitoff, 0, 0);
             }
         }
         pr_barrier();                                           // (2) mid complete in LDS
         // ---- mid -> HBM, row-contiguous (same slot map as the DMA that brought the add tile in)
         {
-            const uint32_t wb = (uint32_t)tile * (PR_BM * 512u);
-            i32x4_t v[8];
+            const uint32_t wb = (uint32_t)tile * (uint32_t)(BM * RROW);
+            i32x4_t v[NR];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *(const i32x4_t*)(sR + (wave + 4 * i) * 1024 + lane * 16);
+            for (int i = 0; i < NR; ++i) v[i] = *(const i32x4_t*)(sR + (wave + NW * i) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) buf_store16(rmid, wb + roff[i], v[i]);
+            for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + roff[i], v[i]);
         }
-        // ---- GEMM 2: [64 px] x [wave's 16 output channels], K = 256
-        f32x4_t acc2[4];
+        // ---- GEMM 2: [BM px] x [wave's 16 output channels], K = CW
+        f32x4_t acc2[PT2];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int pt = 0; pt < PT2; ++pt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc2[pt][r] = (MODE == 0) ? b2[r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            i32x4_t px[4];
+        for (int j = 0; j < KS2; ++j) {
+            i32x4_t px[PT2];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) px[pt] = *(const i32x4_t*)(sR + (g2rd[pt] ^ (uint32_t)(j << 6)));
+            for (int pt = 0; pt < PT2; ++pt) px[pt] = *(const i32x4_t*)(sR + (g2rd[pt] ^ (uint32_t)(j << 6)));
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) Mma<T>::run(w2f[j], px[pt], acc2[pt]);
+            for (int pt = 0; pt < PT2; ++pt) Mma<T>::run(w2f[j], px[pt], acc2[pt]);
         }
         // ---- epilogue 2 -> the src buffer of this tile (every wave is past GEMM 1), then row-contiguous stores
-        char* sO = smem + buf * PR_ABUF;
+        char* sO = smem + buf * S::ABUF;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT2; ++pt) {
             T out[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -286,10 +310,10 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
         }
         pr_barrier();                                           // (3)
         {
-            const uint32_t nb = (uint32_t)tile * (PR_BM * 128u);
+            const uint32_t nb = (uint32_t)tile * (uint32_t)(BM * AROW);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                i32x4_t v = *(const i32x4_t*)(sO + (wave + 4 * i) * 1024 + lane * 16);
+            for (int i = 0; i < NA; ++i) {
+                i32x4_t v = *(const i32x4_t*)(sO + (wave + NW * i) * 1024 + lane * 16);
                 if constexpr (MODE == 1) {
                     T x[8], m[8];
                     __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &cm2[i], 16);
@@ -301,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const PairArgs a) {
             }
         }
         if (!has_next) break;
-        tile += bpx; buf ^= 1;
+        tile += bpx;
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
 }
 
@@ -316,12 +341,37 @@ static int pr_device_cus() {
 }
 
 extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) {
-    return (M > 0 && M % PR_BM == 0 && M * PR_CW * 2 < 0x7FFFFF00ll && (dt == URSO_BF16 || dt == URSO_F16) && c_narrow == PR_CM && c_wide == PR_CW) ? 1 : 0;
+    if (M <= 0 || !(dt == URSO_BF16 || dt == URSO_F16) || c_wide != 4 * c_narrow) return 0;
+    const int bm = c_narrow == PairS2::CM ? PairS2::BM : (c_narrow == PairS3::CM ? PairS3::BM : 0);
+    return (bm && M % bm == 0 && M * c_wide * 2 < 0x7FFFFF00ll) ? 1 : 0;
 }
 
-extern "C" int urso_conv_pair(long long M, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d, const void* add_d,
-                              void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d, void* dst_d, void* stream) {
-    if (!urso_conv_pair_ok(M, dt, PR_CM, PR_CW)) { urso_set_error("urso_conv_pair: M %% 64 != 0, tensor >= 2 GiB or dtype not 16-bit"); return URSO_EINVAL; }
+template <typename S>
+static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st) {
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = blocks_per_cu * pr_device_cus() / 8;
+    if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
+    const dim3 grid(8 * bpx), blk(S::NW * 64);
+    if (dt == URSO_BF16) {
+        if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S>), grid, blk, 0, st, a);
+        else if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S>), grid, blk, 0, st, a);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S>), grid, blk, 0, st, a);
+        else if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S>), grid, blk, 0, st, a);
+    }
+}
+
+extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,
+                              const void* add_d, void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d,
+                              void* dst_d, void* stream) {
+    const int cm = c_narrow, cw = 4 * c_narrow;
+    if (!urso_conv_pair_ok(M, dt, cm, cw)) {
+        urso_set_error("urso_conv_pair: needs 16-bit dt, (64, 256) channels with M %% 64 == 0 or (128, 512) with M %% 32 == 0, tensors < 2 GiB");
+        return URSO_EINVAL;
+    }
     if (!src_d || !w1_d || !add_d || !mid_d || !w2_d || !dst_d || (mode != 0 && mode != 1) || (mode == 1 && (!bits_d || !mask2_d))) {
         urso_set_error("urso_conv_pair: bad argument"); return URSO_EINVAL;
     }
@@ -331,25 +381,12 @@ extern "C" int urso_conv_pair(long long M, int dt, int mode, const void* src_d, 
     PairArgs a;
     a.src = src_d; a.w1 = w1_d; a.bias1 = bias1_d; a.add = add_d; a.bits = bits_d; a.mid = mid_d; a.w2 = w2_d; a.bias2 = bias2_d;
     a.mask2 = mask2_d; a.dst = dst_d;
-    a.nar_bytes = (uint32_t)(M * PR_CM * 2); a.wide_bytes = (uint32_t)(M * PR_CW * 2); a.bits_bytes = (uint32_t)(M * (PR_CW / 8));
-    a.ntiles = (int)(M / PR_BM);
-    int bpx = ceil_div(a.ntiles, 8);
-    const int cap = 2 * pr_device_cus() / 8;
-    if (bpx > cap) bpx = cap;
-    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
-    const double flops = 2.0 * (double)M * PR_CM * PR_CW * 2.0;
-    const double bytes = (double)M * (2.0 * PR_CM * 2 + 2.0 * PR_CW * 2) + (double)M * (PR_CW / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
-                         (mode == 1 ? (double)M * PR_CM * 2 : 0.0) + 2.0 * PR_CM * PR_CW * 2;
+    a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
+    const double flops = 2.0 * (double)M * cm * cw * 2.0;
+    const double bytes = (double)M * (2.0 * cm * 2 + 2.0 * cw * 2) + (double)M * (cw / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
+                         (mode == 1 ? (double)M * cm * 2 : 0.0) + 2.0 * cm * cw * 2;
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    const dim3 grid(8 * bpx), blk(256);
-    if (dt == URSO_BF16) {
-        if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false>), grid, blk, 0, st, a);
-        else if (bits_d) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false>), grid, blk, 0, st, a);
-    } else {
-        if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false>), grid, blk, 0, st, a);
-        else if (bits_d) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false>), grid, blk, 0, st, a);
-    }
+    if (cm == PairS2::CM) { a.ntiles = (int)(M / PairS2::BM); pr_launch<PairS2>(a, dt, mode, bits_d != nullptr, 2, st); }
+    else { a.ntiles = (int)(M / PairS3::BM); pr_launch<PairS3>(a, dt, mode, bits_d != nullptr, 1, st); }
     return urso_check_launch("urso_conv_pair");
 }

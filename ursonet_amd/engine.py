@@ -437,7 +437,7 @@ class Engine(object):
                     # the data gradient of layer A into ITS input: X.grad crosses HBM once (conv_pair.hip)
                     dstg, dst2 = X.grad_buf(), A.src.grad_buf()
                     self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2:
-                                         hip.conv_pair(A.Mpix, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2)))
+                                         hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2)))
                     self.labels["bwd"].append("dgrad:%s+%s" % (node.name, A.name))
                     X.grad_written, X.pending = True, None
                     A.src.grad_written = True
@@ -596,8 +596,8 @@ class Engine(object):
             self.loss_ops.append(lambda: hip.softmax_xent(B, nori, ori.data, self.gt_ori, wo, 1, dt, self.loss_buf[1:2], gz_ori, self.row_ws))
 
     def _fuse_pointwise_pairs(self):
-        """Forward plan rewrite: a block-closing pointwise layer (64 -> 256, + residual, ReLU) directly followed by the next block's
-        opening pointwise layer (256 -> 64, ReLU) becomes ONE launch (urso_conv_pair): the 256-channel block output is written once and
+        """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly
+        followed by the next block's opening pointwise layer (4c -> c, ReLU) becomes ONE launch (urso_conv_pair): the block output is written once and
         the second layer reads it from LDS.  self.pair_first maps the second layer's name to the first layer's _Conv; the backward
         plan mirrors the fusion for the two data gradients.  URSO_OPT_PAIR=0 (hip.options(pair=0)) keeps the layers apart."""
         self.pair_first = {}
@@ -620,7 +620,7 @@ class Engine(object):
             if not (a_node.cin == b_node.cout and hip.conv_pair_ok(M, dt, a_node.cin, a_node.cout)):
                 continue
             A.Mpix = M
-            self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc: hip.conv_pair(A.Mpix, dt, 0, A.src.data, A.wf, A.biasf, A.res.data, A.dst.bits,
+            self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc: hip.conv_pair(A.Mpix, A.node.cin, dt, 0, A.src.data, A.wf, A.biasf, A.res.data, A.dst.bits,
                                                                          A.dst.data, Bc.wf, Bc.biasf, None, Bc.dst.data))
             self.labels["fwd"][A.fwd_index] = "fwd:%s+%s" % (a_node.name, b_node.name)
             drop.append(Bc.fwd_index)

@@ -107,7 +107,7 @@ _SIGS = {
     "urso_encode_ori": (_i, [_i, _i, _vp, _fp, _vp, C.c_double, _fp, _vp]),
     "urso_encode_loc": (_i, [_i, _i, _vp, _vp, C.c_double, _fp, _vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
-    "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
+    "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -396,9 +396,9 @@ def conv_pair_ok(M, dt, c_narrow, c_wide):
     return bool(_lib.urso_conv_pair_ok(int(M), dt, int(c_narrow), int(c_wide)))
 
 
-def conv_pair(M, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, mask2, dst, stream=None):
-    """urso_conv_pair: two chained pointwise layers (64 -> 256 (+add) -> 64) in one pass; mode 0 forward, 1 backward."""
-    _chk(_lib.urso_conv_pair(int(M), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
+def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, mask2, dst, stream=None):
+    """urso_conv_pair: two chained pointwise layers (c -> 4c (+add) -> c, c = 64 or 128) in one pass; mode 0 forward, 1 backward."""
+    _chk(_lib.urso_conv_pair(int(M), int(c_narrow), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
                              ptr(mask2), ptr(dst), stream_ptr(stream)), "urso_conv_pair")
 
 
