@@ -395,6 +395,25 @@ enum { URSO_K_IGEMM = 1, URSO_K_WGRAD = 2, URSO_K_PREP = 3, URSO_K_FINALIZE = 4,
 int urso_prof_enable(int on);
 int urso_prof_collect(urso_prof_record* out, int max_records);   /* returns #records, clears */
 
+/*
+ * Data-parallel exchange (replaces keras.utils.multi_gpu_model's gradient gather, pose_estimator.py:28): bucketed
+ * gradient AVERAGING over RCCL, one communicator per process = per GPU.  The collectives run on the communicator's own stream:
+ *   urso_comm_unique_id(id)                       on rank 0; the host ships the URSO_COMM_ID_BYTES bytes to the other ranks
+ *   urso_comm_init(&comm, world, rank, id)        collective over all ranks (current HIP device = this rank's GPU)
+ *   urso_comm_allreduce_bucket(comm, p, n, dt, s) in-place average of n elements (URSO_F32 / URSO_BF16 / URSO_F16) ordered after the work
+ *                                                 already enqueued on compute stream s; returns at once, later kernels on s overlap it
+ *   urso_comm_wait(comm, s)                       stream s waits for every bucket launched so far (call before the optimizer)
+ *   urso_comm_destroy(comm)
+ * RCCL is bound at run time (dlopen); without it these five return URSO_ELAUNCH and the rest of the library is unaffected.
+ */
+#define URSO_COMM_ID_BYTES 128
+typedef struct urso_comm urso_comm;
+int urso_comm_unique_id(void* id_out);
+int urso_comm_init(urso_comm** comm, int world, int rank, const void* id);
+int urso_comm_allreduce_bucket(urso_comm* comm, void* buf_d, size_t count, int dt, void* compute_stream);
+int urso_comm_wait(urso_comm* comm, void* compute_stream);
+int urso_comm_destroy(urso_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,11 @@ _SIGS = {
     "urso_warp_perspective": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "urso_encode_ori": (_i, [_i, _i, _vp, _fp, _vp, C.c_double, _fp, _vp]),
     "urso_encode_loc": (_i, [_i, _i, _vp, _vp, C.c_double, _fp, _vp]),
+    "urso_comm_unique_id": (_i, [_vp]),
+    "urso_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
+    "urso_comm_allreduce_bucket": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "urso_comm_wait": (_i, [_vp, _vp]),
+    "urso_comm_destroy": (_i, [_vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
@@ -432,3 +437,46 @@ def prof_collect(max_records=65536):
     buf = (ProfRecord * max_records)()
     n = _lib.urso_prof_collect(buf, max_records)
     return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes) for i in range(n)]
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """urso_comm_unique_id: the 128 bytes rank 0 creates and every rank passes to Comm()."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(_lib.urso_comm_unique_id(C.cast(buf, C.c_void_p)), "urso_comm_unique_id")
+    return buf.raw
+
+
+class Comm(object):
+    """urso_comm_*: bucketed gradient averaging over RCCL on the communicator's own stream (include/ursonet_hip.h)."""
+
+    def __init__(self, world, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        h = C.c_void_p()
+        self._id = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _chk(_lib.urso_comm_init(C.byref(h), int(world), int(rank), C.cast(self._id, C.c_void_p)), "urso_comm_init")
+        self.h, self.world, self.rank = h, int(world), int(rank)
+
+    @classmethod
+    def from_torch_group(cls, group=None):
+        """One communicator over the ranks of an initialised torch.distributed group (the id travels through that group)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor(list(comm_unique_id()) if rank == 0 else [0] * COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        return cls(world, rank, bytes(t.cpu().tolist()))
+
+    def allreduce_bucket(self, t, stream=None):
+        """In-place average of tensor t (fp32 / bf16 / fp16, contiguous) after the work already on `stream` (default: current)."""
+        _chk(_lib.urso_comm_allreduce_bucket(self.h, ptr(t), t.numel(), DT_OF_TORCH[t.dtype], stream_ptr(stream)), "urso_comm_allreduce_bucket")
+
+    def wait(self, stream=None):
+        _chk(_lib.urso_comm_wait(self.h, stream_ptr(stream)), "urso_comm_wait")
+
+    def close(self):
+        if self.h:
+            _lib.urso_comm_destroy(self.h)
+            self.h = None
