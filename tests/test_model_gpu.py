@@ -563,3 +563,45 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
     # in the tensor-max metric; each plan is compared with the oracle under pinned ReLU decisions instead
     # (test_training_step_parity_16bit_same_rounding_points[... fused / apart])
     assert eo <= tol_out and el <= tol_out
+
+
+def test_urso_comm_bucket_averaging_one_rank():
+    """The C-ABI exchange step (urso_comm_*: RCCL bound at run time) with one rank: the average over one rank is the identity, the
+    collective runs on the communicator's own stream ordered after the producer kernel, and urso_comm_wait orders the consumer
+    after it; then the same transport under DataParallelEngine reproduces the plain engine's step bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    from ursonet_amd.dp import DataParallelEngine
+    comm = hip.Comm(1, 0, hip.comm_unique_id())
+    try:
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            x = torch.randn(3_000_001, device="cuda").to(dtype)
+            y = x.clone()
+            y.mul_(2)                                   # producer on the compute stream
+            comm.allreduce_bucket(y)
+            comm.wait()
+            z = y * 0.5                                 # consumer, ordered after the collective
+            torch.cuda.synchronize()
+            assert torch.equal(z, x)
+        with pytest.raises((hip.UrsoHipError, KeyError)):                # float64 has no URSO dtype
+            comm.allreduce_bucket(torch.zeros(4, device="cuda", dtype=torch.float64))
+    except BaseException:
+        comm.close()
+        raise
+    cfg = make_config("resnet18", 64, 128, batch=4, regress_ori=True, dtype="bfloat16", lr=1e-2)
+    img, loc, ori, _ = synthetic_batch(cfg, 4, seed=2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        ref = Engine(cfg, "training", seed=9, randomize_bn=True)
+        ref.load_batch(img, loc, ori); ref.step(); ref.step(); torch.cuda.synchronize()
+        eng = Engine(cfg, "training", seed=9, randomize_bn=True)
+        dp = DataParallelEngine(eng, bucket_bytes=4 << 20, comm=comm)
+        assert len(dp.buckets) >= 2
+        eng.load_batch(img, loc, ori); dp.step(); dp.step(); torch.cuda.synchronize()
+        assert torch.equal(eng.flat_w, ref.flat_w) and torch.equal(eng.flat_g, ref.flat_g)
+    finally:
+        dist.destroy_process_group()
+        comm.close()

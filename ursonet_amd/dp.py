@@ -53,10 +53,11 @@ class GradReducer(object):
     rounding dropped on this rank is kept (`resid`) and added to the next step's gradient, so the fp32 master weights see every
     bit of gradient eventually (the rounding error does not accumulate as a bias).  Default None: exact fp32 averaging."""
 
-    def __init__(self, flat_g, buckets, group=None, compress=None):
+    def __init__(self, flat_g, buckets, group=None, compress=None, comm=None):
         assert compress in (None, "bf16")
         self.flat_g, self.buckets, self.group = flat_g, buckets, group
         self.compress = compress
+        self.comm = comm                    # ursonet_amd.hip.Comm: the C-ABI transport (urso_comm_*) instead of torch.distributed
         if compress:
             self.cbuf = torch.zeros_like(flat_g, dtype=torch.bfloat16)
             self.resid = torch.zeros_like(flat_g)
@@ -68,7 +69,7 @@ class GradReducer(object):
 
     def launch(self, k):
         """Start the all-reduce of bucket k (call after the kernels producing it were enqueued)."""
-        if self.world == 1 and not self.force:
+        if self.world == 1 and not self.force and self.comm is None:
             return
         s, e, _ = self.buckets[k]
         t = self.flat_g[s:e]
@@ -79,14 +80,20 @@ class GradReducer(object):
             c.copy_(t)                      # round to bf16
             torch.sub(t, c.float(), out=r)  # what this rounding dropped, kept for the next step
             back, t = t, c
-        if self.backend == "nccl":          # RCCL: averaging happens inside the collective
+        if self.comm is not None:           # urso_comm_allreduce_bucket: RCCL average on the communicator's own stream
+            self.comm.allreduce_bucket(t)
+            self.works.append((None, None, back, t))
+        elif self.backend == "nccl":        # RCCL: averaging happens inside the collective
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, back, t))
         else:                               # gloo (CPU tests): sum, then scale on wait
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t, back, t))
 
     def wait_all(self):
+        if self.comm is not None and self.works:
+            self.comm.wait()                # the compute stream waits for every bucket launched so far
         for w, scale, back, t in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
             if scale is not None:
                 scale.div_(self.world)
             if back is not None:
@@ -99,8 +106,8 @@ class DataParallelEngine(object):
     [prep+forward+loss+backward-part-0], [backward-part-1], ..., [optimizer] hipGraphs and
     interleaves the bucket all-reduces between their replays."""
 
-    def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None):
-        self.eng, self.group, self.compress = engine, group, compress
+    def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None, comm=None):
+        self.eng, self.group, self.compress, self.comm = engine, group, compress, comm
         self.world = dist.get_world_size(group)
         # DP_EXACT_REL_LOSS: the location loss is ONE ratio of norms over the global batch (net.py:750-762); its two squared norms are
         # summed over the ranks between forward and backward and the gradient is pre-scaled by the world size (undone by the averaging)
@@ -123,7 +130,7 @@ class DataParallelEngine(object):
         eng, group = self.eng, self.group
         self.plan_version = eng.plan_version
         self.buckets = eng.buckets
-        self.reducer = GradReducer(eng.flat_g, self.buckets, group, compress=self.compress)
+        self.reducer = GradReducer(eng.flat_g, self.buckets, group, compress=self.compress, comm=self.comm)
         # split the backward op list where each bucket becomes complete
         last_op_of_layer = {}
         for i, (tag, _) in enumerate(eng.bwd_ops):
