@@ -766,3 +766,45 @@ def test_fused_pointwise_pair_forward_and_backward(dt, shape, c):
     assert float((dst.float() != 0).float().mean()) > 0.1
     with pytest.raises(hip.UrsoHipError):
         hip.conv_pair(M, c, dt, 1, src, w1, None, add, None, mid, w2, None, act, dst)          # backward form needs the bit mask
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
+@pytest.mark.parametrize("variant", ["add_relu_bits", "add_relu", "plain", "relu_only"])
+def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
+    """urso_conv_igemm_ex on a c -> 4c pointwise layer (res2c/res3d_branch2c, the stride-1 shortcut conv) runs the single-layer form
+    of conv_pair.hip (option pair, default on): against the CPU fp32 reference, against the DMA kernel (pair = 0) and, for the bit
+    mask, bit for bit against (stored output > 0); grid at production size and capped to 8 blocks (multi-tile stream)."""
+    hip = _hip()
+    B, H, W = 3, 40, 48
+    M = B * H * W
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(c + dt)
+    x = dev(torch.randn(B, H, W, c), dt)
+    w = torch.randn(1, 1, c, 4 * c) / c ** 0.5
+    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(4 * c) * 0.2)
+    add = dev(torch.randn(B, H, W, 4 * c), dt) if variant.startswith("add") else None
+    relu = variant != "plain"
+    bits = torch.full((M * 4 * c // 8,), 0x55, dtype=torch.uint8, device="cuda") if variant.endswith("bits") else None
+    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_EMIT_BITS if bits is not None else 0)
+    g = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1)
+    ref = x.float().cpu().reshape(M, c) @ wf.float().cpu().reshape(4 * c, c).T + biasf.cpu()
+    if add is not None:
+        ref = ref + add.float().cpu().reshape(M, 4 * c)
+    if relu:
+        ref = torch.relu(ref)
+    outs = {}
+    for pair, cap in ((1, 0), (1, 8), (0, 0)):
+        y = torch.full((B, H, W, 4 * c), 5.0, device="cuda").to(tdt)
+        if bits is not None:
+            bits.fill_(0x55)
+        with hip.options(pair=pair, grid_cap=cap):
+            hip.conv_igemm_ex(g, dt, flags, x, wf, biasf, add, None, y, bits)
+        torch.cuda.synchronize()
+        assert relerr(y.reshape(M, 4 * c), ref) < (1.2e-2 if dt == 1 else 1.5e-3)
+        if bits is not None:
+            pos = (y.float() > 0).reshape(-1, 8).to(torch.int32)
+            assert torch.equal(bits, (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8))
+        outs[(pair, cap)] = y.float()
+    assert torch.equal(outs[(1, 0)], outs[(1, 8)])
+    assert float((outs[(1, 0)] - outs[(0, 0)]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[(0, 0)].abs().max())

@@ -163,7 +163,7 @@ def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w):
 
 @pytest.mark.parametrize("pair", [1, 0], ids=["fused", "apart"])
 @pytest.mark.parametrize("cap", [0, 8], ids=["grid", "capped"])
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 2e-3, 5e-3)])
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 4e-3, 7e-3)])
 def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, cap, pair):
     """The benchmarked dtype against an oracle that rounds where the device rounds (oracle.graph_ref.StorageRounding: folded
     filters, every stored activation, every activation gradient): outputs, losses, EVERY parameter gradient (relative to the
@@ -178,7 +178,8 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     with the fused stage-2 pairs (conv_pair.hip: bit-identical backward, forward equal up to one rounding flip in ~1e-5 of the
     elements) measures outputs 1.1e-2 / worst filter gradient 2.8e-2 / norm 9e-3 against 7.7e-3 / 1.5e-2 / 5e-3 with the layers
     launched apart, while fp16 -- 8x finer, so any systematic error would show at the same absolute size -- is unchanged at 3.3e-3;
-    the bf16 gates are set to twice the larger measurement."""
+    with the single wide layers also on the register-filter kernel fp16 measures outputs 2.1e-3 / worst gradient 3.4e-3.  Every gate is
+    set to about twice the largest value measured over the kernel plans (fused / apart, grid / capped)."""
     import ursonet_amd.hip as hip
     from oracle import graph_ref as G
     kw = dict(backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
@@ -554,7 +555,7 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
                     sorted(eng.pair_first)))
     assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
     assert res[1][0] - res[0][0] == 5 and res[1][1] - res[0][1] == 5
-    tol_out = 2e-2 if dtype == "bfloat16" else 2e-3                               # the output gate of the oracle comparison above
+    tol_out = 2e-2 if dtype == "bfloat16" else 4e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])
     print("fused vs apart (%s): outputs %.2e losses %.2e" % (dtype, eo, el))

@@ -30,6 +30,7 @@ struct PairArgs {
     const void* w2; const float* bias2; const void* mask2; void* dst;
     uint32_t nar_bytes, wide_bytes, bits_bytes;      // [M][CM], [M][CW], [M][CW/8]
     int ntiles;
+    int relu1;                                       // VAR != 0 (single layer): ReLU on the wide output or not
 };
 
 template <typename T> struct PrMma32;
@@ -73,9 +74,14 @@ using PairS2 = PairShape<64, 4, 64, 2>;
 using PairS3 = PairShape<128, 8, 32, 3>;
 
 // MODE 0 forward pair, 1 backward pair.  EMIT: forward also writes the ReLU bit mask of `mid`.
-template <typename T, int MODE, bool EMIT, typename S>
+// VAR 0: the pair.  VAR 1 / 2: ONLY the first layer (c -> 4c pointwise, MODE 0) with / without a residual operand -- the same input
+// pipeline, filters in registers and row-contiguous stores for the block-closing layers that have no partner (res2c/res3d_branch2c,
+// the stride-1 shortcut conv): urso_conv_igemm_ex sends them here.
+template <typename T, int MODE, bool EMIT, typename S, int VAR>
 __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
+    static_assert(VAR == 0 || MODE == 0, "single-layer variants are forward-form only");
+    constexpr bool G2 = VAR == 0, HAS_ADD = VAR != 2;
     constexpr int BM = S::BM, CM = S::CM, CW = S::CW, NW = S::NW, AROW = S::AROW, RROW = S::RROW, BROW = S::BROW;
     constexpr int NA = S::NA, NR = S::NR, PT1 = S::PT1, KS1 = S::KS1, PT2 = S::PT2, KS2 = S::KS2, D = S::D, NBUF = S::NBUF;
     __shared__ __attribute__((aligned(1024))) char smem[S::LDS];
@@ -112,10 +118,12 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)(BM * RROW);
 #pragma unroll
         for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
+        if constexpr (HAS_ADD) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + roff[i]);
+            for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + roff[i]);
+        }
     };
-    constexpr int NDMA = NA + NR;
+    constexpr int NDMA = NA + (HAS_ADD ? NR : 0);
 
     // ---- filters -> registers.  GEMM 1 row operand: MFMA row rho = e + 8 q + 4 hh of the wave's 32-channel sub-tile c2 holds logical
     //      channel 16 hh + 4 q + e, so that a lane's 16 accumulators are channels 16 h .. 16 h + 15 (one pixel, 32 contiguous bytes).
@@ -128,9 +136,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
             for (int j = 0; j < KS1; ++j)
                 w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(64 * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
         // GEMM 2 row operand (16x16x32): row l15 of the wave's 16 output channels, k = 32 j + 8 g
+        if constexpr (G2) {
 #pragma unroll
-        for (int j = 0; j < KS2; ++j)
-            w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * CW + 32 * j + 8 * g) * 2);
+            for (int j = 0; j < KS2; ++j)
+                w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * CW + 32 * j + 8 * g) * 2);
+        }
     }
     float b1[2][16], b2[4];
     if constexpr (MODE == 0) {
@@ -138,8 +148,10 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[64 * wave + 32 * c2 + 16 * h + r] : 0.f;
+        if constexpr (G2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b2[r] = a.bias2 ? a.bias2[16 * wave + 4 * g + r] : 0.f;
+            for (int r = 0; r < 4; ++r) b2[r] = a.bias2 ? a.bias2[16 * wave + 4 * g + r] : 0.f;
+        }
     }
 
     // ---- LDS read offsets
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     const uint32_t bitoff = (uint32_t)(l31 * BROW + 8 * wave);
 
     // vector-memory operations a tile issues after its requests for later tiles: the stores
-    constexpr int NST = NR + NA + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
+    constexpr int NST = NR + (G2 ? NA : 0) + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
 
     i32x2_t pbits[PT1];                                        // backward: bit masks of the NEXT tile (requested one tile ahead)
     i32x4_t pm2[NA];                                           //           mask2 vectors of its dst rows
@@ -238,8 +250,10 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 i32x4_t rv[2];
-                rv[0] = *(const i32x4_t*)(sR + e1[pt][c2]);
-                rv[1] = *(const i32x4_t*)(sR + (e1[pt][c2] ^ 16u));
+                if constexpr (HAS_ADD) {
+                    rv[0] = *(const i32x4_t*)(sR + e1[pt][c2]);
+                    rv[1] = *(const i32x4_t*)(sR + (e1[pt][c2] ^ 16u));
+                } else rv[0] = rv[1] = i32x4_t{0, 0, 0, 0};
                 uint32_t mbits = 0xFFFFu;
                 if constexpr (MODE == 1) mbits = ((uint32_t)(c2 ? cbits[pt].y : cbits[pt].x) >> (16 * h)) & 0xFFFFu;
                 uint32_t obits = 0;
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float x = acc[pt][c2][8 * v + e] + Elem<T>::to_f(res[e]);
-                        if constexpr (MODE == 0) x = fmaxf(x, 0.f);
+                        if constexpr (MODE == 0) x = (VAR == 0 || a.relu1) ? fmaxf(x, 0.f) : x;
                         else x = ((mbits >> (8 * v + e)) & 1u) ? x : 0.f;
                         out[e] = Elem<T>::from_f(x);
                         if constexpr (MODE == 0 && EMIT) obits |= (Elem<T>::to_f(out[e]) > 0.f ? 1u : 0u) << (8 * v + e);
@@ -278,6 +292,12 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
             for (int i = 0; i < NR; ++i) v[i] = *(const i32x4_t*)(sR + (wave + NW * i) * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + roff[i], v[i]);
+        }
+        if constexpr (!G2) {
+            if (!has_next) break;
+            tile += bpx;
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+            continue;
         }
         // ---- GEMM 2: [BM px] x [wave's 16 output channels], K = CW
         f32x4_t acc2[PT2];
@@ -346,22 +366,57 @@ extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) 
     return (bm && M % bm == 0 && M * c_wide * 2 < 0x7FFFFF00ll) ? 1 : 0;
 }
 
-template <typename S>
+template <typename S, int VAR>
 static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st) {
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = blocks_per_cu * pr_device_cus() / 8;
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(S::NW * 64);
-    if (dt == URSO_BF16) {
-        if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S>), grid, blk, 0, st, a);
-        else if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S>), grid, blk, 0, st, a);
+    if constexpr (VAR == 0) {
+        if (dt == URSO_BF16) {
+            if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0>), grid, blk, 0, st, a);
+            else if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, 0>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, 0>), grid, blk, 0, st, a);
+        } else {
+            if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 0>), grid, blk, 0, st, a);
+            else if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, 0>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, 0>), grid, blk, 0, st, a);
+        }
     } else {
-        if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S>), grid, blk, 0, st, a);
-        else if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S>), grid, blk, 0, st, a);
+        if (dt == URSO_BF16) {
+            if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR>), grid, blk, 0, st, a);
+        } else {
+            if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, VAR>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, VAR>), grid, blk, 0, st, a);
+        }
     }
+}
+
+// The first layer alone (conv_igemm.hip dispatches here): dst[M][4c] = act(src[M][c] W^T + bias (+ add)), optional ReLU bit mask.
+bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* mask) {
+    if (!g_urso_opt.pair || mask || (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS))) return false;
+    if (g->KH != 1 || g->KW != 1 || g->SH != 1 || g->SW != 1 || g->PH || g->PW || g->DH != 1 || g->DW != 1 || g->FH > 0 || g->N != 4 * g->C ||
+        g->OH != g->H || g->OW != g->W) return false;
+    return urso_conv_pair_ok((long long)g->B * g->OH * g->OW, dt, g->C, g->N) != 0;
+}
+int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                            void* dst, void* bits_out, hipStream_t st) {
+    const long long M = (long long)g->B * g->OH * g->OW;
+    const int cm = g->C, cw = g->N;
+    PairArgs a;
+    a.src = src; a.w1 = wgt; a.bias1 = bias; a.add = add ? add : dst; a.bits = bits_out; a.mid = dst; a.w2 = nullptr; a.bias2 = nullptr;
+    a.mask2 = nullptr; a.dst = dst; a.relu1 = relu;
+    a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
+    if (cm == PairS2::CM) {
+        a.ntiles = (int)(M / PairS2::BM);
+        if (add) pr_launch<PairS2, 1>(a, dt, 0, bits_out != nullptr, 2, st); else pr_launch<PairS2, 2>(a, dt, 0, bits_out != nullptr, 2, st);
+    } else {
+        a.ntiles = (int)(M / PairS3::BM);
+        if (add) pr_launch<PairS3, 1>(a, dt, 0, bits_out != nullptr, 1, st); else pr_launch<PairS3, 2>(a, dt, 0, bits_out != nullptr, 1, st);
+    }
+    return urso_check_launch("urso_conv_igemm(wide pointwise)");
 }
 
 extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,
@@ -380,13 +435,13 @@ extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const
     hipStream_t st = (hipStream_t)stream;
     PairArgs a;
     a.src = src_d; a.w1 = w1_d; a.bias1 = bias1_d; a.add = add_d; a.bits = bits_d; a.mid = mid_d; a.w2 = w2_d; a.bias2 = bias2_d;
-    a.mask2 = mask2_d; a.dst = dst_d;
+    a.mask2 = mask2_d; a.dst = dst_d; a.relu1 = 1;
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
     const double flops = 2.0 * (double)M * cm * cw * 2.0;
     const double bytes = (double)M * (2.0 * cm * 2 + 2.0 * cw * 2) + (double)M * (cw / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
                          (mode == 1 ? (double)M * cm * 2 : 0.0) + 2.0 * cm * cw * 2;
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    if (cm == PairS2::CM) { a.ntiles = (int)(M / PairS2::BM); pr_launch<PairS2>(a, dt, mode, bits_d != nullptr, 2, st); }
-    else { a.ntiles = (int)(M / PairS3::BM); pr_launch<PairS3>(a, dt, mode, bits_d != nullptr, 1, st); }
+    if (cm == PairS2::CM) { a.ntiles = (int)(M / PairS2::BM); pr_launch<PairS2, 0>(a, dt, mode, bits_d != nullptr, 2, st); }
+    else { a.ntiles = (int)(M / PairS3::BM); pr_launch<PairS3, 0>(a, dt, mode, bits_d != nullptr, 1, st); }
     return urso_check_launch("urso_conv_pair");
 }
