@@ -808,3 +808,26 @@ def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
         outs[(pair, cap)] = y.float()
     assert torch.equal(outs[(1, 0)], outs[(1, 8)])
     assert float((outs[(1, 0)] - outs[(0, 0)]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[(0, 0)].abs().max())
+
+
+C3_CASES = [
+    (1, 4, 32, 64, 64, 3, 1, (1, 1), "c3_one_tile"),
+    (2, 12, 20, 64, 64, 3, 1, (1, 1), "c3_narrow_image"),        # W < tile width: partial tiles, right border inside the patch
+    (3, 17, 45, 64, 64, 3, 1, (1, 1), "c3_ragged"),              # H % 4 != 0, W % 32 != 0
+    (2, 64, 96, 64, 64, 3, 1, (1, 1), "c3_multi_tile"),
+    (4, 256, 320, 64, 64, 3, 1, (1, 1), "c3_full_size_rows"),    # more tiles than resident blocks at production grid size
+]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("cap", [0, 8])
+@pytest.mark.parametrize("c3", [1, 0], ids=["regfilter", "dma"])
+@pytest.mark.parametrize("case", C3_CASES, ids=[c[-1] for c in C3_CASES])
+def test_3x3_64_channel_layers_register_filter_kernel(case, dt, cap, c3):
+    """The 64-channel 3x3 layers (res2x_branch2b, forward and -- through the flipped filter -- data gradient with its ReLU mask) in
+    conv_c3.hip (option c3, default on) and, for reference, in the DMA kernel: forward, data gradient and weight gradient against the
+    CPU fp32 reference of test_conv_forward_and_gradients; image sizes that are not multiples of the 4 x 32 tile (zero-filled halo,
+    dropped out-of-image stores) and a grid capped to 8 blocks (double-buffered halo stream across several tiles)."""
+    hip = _hip()
+    with hip.options(c3=c3, grid_cap=cap):
+        test_conv_forward_and_gradients(case, dt)

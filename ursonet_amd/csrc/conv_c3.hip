@@ -1,0 +1,244 @@
+// 3x3 / stride-1 / pad-1 convolution with 64 channels and 64 filters (net.py:106,143: res2x_branch2b forward and, with the flipped
+// filter of urso_conv_weight_prep, its data gradient), 16-bit dtypes, gfx950.
+//
+// These three layers (x2 directions) are the only 3x3 layers whose WHOLE filter (9 x 64 x 64 x 2 B = 72 KiB) fits in the register file
+// of one block: each of the 4 waves keeps the 9 x 64 filter rows of its 32 output channels (144 VGPRs per lane) for the whole kernel,
+// so the only operand that moves is the pixel tile -- fetched once as a 2-D halo patch and read by the nine taps at shifted LDS rows
+// (the idea of conv_halo.hip, which needs >= 128 channels and short image rows; here the rows are 160-240 pixels long and the patch is
+// two-dimensional instead).  conv_pw.hip copies the pixel tile of every tap from L2 (9x the bytes) plus a filter tile per tap.
+//   * tile = 4 x 32 output pixels; halo patch 6 x 34 pixels x 128 B = 26 KiB, double-buffered by LDS-DMA one tile ahead; pixels outside
+//     the image are zero-filled by the buffer descriptor (out-of-range offsets), so borders need no masks in the main loop;
+//   * 256 threads = 4 waves as (channel half cw) x (row pair pw): a wave computes 32 filters x 2 rows x 32 pixels with v_mfma_f32_32x32x16
+//     (filters as the row operand): 72 MFMAs fed by 48 ds_read_b128 per tile (a halo-row fragment serves both output rows), fragments
+//     requested three steps ahead in named register sets;
+//   * LDS rows are 128 B with slot ^ ((row >> 1) & 7): conflict-free for any tap shift (conv_halo.hip derivation);
+//   * the result goes through a 16 KiB LDS tile to row-contiguous 16-byte stores (+ the ReLU mask of the data gradient, loaded with the
+//     same coalesced addresses); 72 KiB of LDS -> two blocks per CU.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct C3Args {
+    const void* src; const void* wgt; const float* bias; const void* mask; void* dst;
+    uint32_t bytes;                 // of src / dst / mask: B * H * W * 128
+    int B, H, W, tiles_x, tiles_y, ntiles;
+    int relu;
+};
+
+constexpr int C3_TH = 4, C3_TW = 32, C3_HW = C3_TW + 2, C3_HROWS = (C3_TH + 2) * C3_HW;      // 204 halo pixels
+constexpr int C3_NA = 7;                                                                    // DMA instructions per lane and tile (4 waves x 7 x 8 rows = 224)
+constexpr int C3_ABUF = 224 * 128, C3_OOFF = 2 * C3_ABUF, C3_BOFF = C3_OOFF + C3_TH * C3_TW * 128, C3_LDS = C3_BOFF + 256;   // 2 x 28 KiB + 16 KiB + bias
+
+template <typename T> struct C3Mma;
+template <> struct C3Mma<__bf16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct C3Mma<_Float16> {
+    static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+__device__ __forceinline__ void c3_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t c3_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// byte offset of (row, 16-byte slot 2 j + h) in a [rows][128 B] tile with slot ^ ((row >> 1) & 7)
+__device__ __forceinline__ uint32_t c3_rd(int row, int h, int j) {
+    const int s = (row >> 1) & 7;
+    return (uint32_t)(row * 128 + ((((2 * j + h) ^ s)) << 4));
+}
+
+template <typename T, bool MASK>
+__global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    __shared__ __attribute__((aligned(1024))) char smem[C3_LDS];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, pw = wave >> 1;
+    int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = c3_rsrc(a.src, a.bytes);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.bytes);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(MASK ? a.mask : a.dst, MASK ? a.bytes : 0u);
+
+    // ---- halo DMA roles: instruction i covers halo rows 8 (wave + 4 i) + (lane >> 3), LDS slot lane & 7.  (hy, hx) are re-derived per
+    //      tile from the lane id (a handful of VALU ops) instead of living in 14 registers next to the 144 filter registers
+    int lane_d = lane;
+    auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+        const int tx = t % a.tiles_x, q = t / a.tiles_x;
+        const int ty = q % a.tiles_y;
+        b = q / a.tiles_y; y0 = ty * C3_TH; x0 = tx * C3_TW;
+    };
+    auto dma_tile = [&](int t, int buf) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        const int base = ((b * a.H + y0 - 1) * a.W + x0 - 1) * 128;       // may be negative: only used for in-image pixels
+        asm volatile("" : "+v"(lane_d));                                   // keep the per-instruction constants out of long-lived registers
+#pragma unroll
+        for (int i = 0; i < C3_NA; ++i) {
+            const int hr = 8 * (wave + 4 * i) + (lane_d >> 3);
+            const int hy = (hr * 241) >> 13, hx = hr - hy * C3_HW;         // hr / 34 for hr < 224
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hr < C3_HROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 128 + (((lane_d & 7) ^ ((hr >> 1) & 7)) << 4));
+            c3_dma16(rs, lds0 + buf * C3_ABUF + (wave + 4 * i) * 1024, ok ? off : URSO_OOB_SHIFT);
+        }
+    };
+
+    // ---- the wave's filter rows -> registers: MFMA row rho = e + 8 q + 4 hh holds filter 32 cw + 16 hh + 4 q + e, so a lane's 16
+    //      accumulators are 16 consecutive filters of one pixel.  Filter layout [n][tap][c] (wf) / [c][flipped tap][n] (wd): [out][9][64]
+    i32x4_t wfr[9][4];
+    {
+        const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+        const char* wrow = (const char*)a.wgt + (size_t)(32 * cw + lg) * (9 * 64 * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wfr[t][j] = *(const i32x4_t*)(wrow + (t * 64 + 16 * j + 8 * h) * 2);
+    }
+    // bias -> LDS (read back per tile: 16 registers fewer next to the filter)
+    if (tid < 64) *(float*)(smem + C3_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
+
+    // store roles: instruction i covers output-tile rows 8 (wave + 4 i) + (lane >> 3) (pixel ty = row / 32, tx = row % 32), LDS slot lane & 7
+    constexpr int NST = 4;
+
+    dma_tile(tile, 0);
+    int buf = 0;
+    bool first = true;
+    while (true) {
+        const bool has_next = tile + bpx < t_end;
+        if (first) c3_wait_vm<0>(); else c3_wait_vm<NST>();      // this tile's patch (requested one tile ago); younger: that tile's stores
+        first = false;
+        c3_barrier();
+        if (has_next) dma_tile(tile + bpx, buf ^ 1);
+        const char* sA = smem + buf * C3_ABUF;
+
+        f32x16_t acc[2];
+        {
+            const f32x4_t* bp = (const f32x4_t*)(smem + C3_BOFF + (32 * cw + 16 * h) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t b4 = bp[q];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { acc[r][4 * q] = b4.x; acc[r][4 * q + 1] = b4.y; acc[r][4 * q + 2] = b4.z; acc[r][4 * q + 3] = b4.w; }
+            }
+        }
+        // the fragment addresses are functions of (lane, tap) only: keep them from being hoisted out of the tile loop into registers
+        asm volatile("" : "+v"(l31));
+        // step s = (halo row hr of the wave's 4, column shift kx, 16-channel slice j): ONE fragment, used by output row 0 as tap (hr, kx)
+        // and by output row 1 as tap (hr - 1, kx) -- 48 LDS reads feed the 72 MFMAs; fragments are requested three steps ahead
+        i32x4_t f[4];
+        auto rd = [&](i32x4_t& fs, int s) {
+            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            const int row = (2 * pw + hr) * C3_HW + l31 + kx;
+            fs = *(const i32x4_t*)(sA + c3_rd(row, h, j));
+        };
+        rd(f[0], 0);
+        rd(f[1], 1);
+        rd(f[2], 2);
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {
+            if (s + 3 < 48) rd(f[(s + 3) & 3], s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            if (hr <= 2) C3Mma<T>::run(wfr[3 * hr + kx][j], f[s & 3], acc[0]);
+            if (hr >= 1) C3Mma<T>::run(wfr[3 * (hr - 1) + kx][j], f[s & 3], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: ReLU -> 16-bit -> LDS tile [128 pixels][64 filters] -> row-contiguous stores (+ mask)
+        char* sO = smem + C3_OOFF;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int px = (2 * pw + r) * 32 + l31;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                T o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float y = acc[r][8 * v + e]; y = a.relu ? fmaxf(y, 0.f) : y; o[e] = Elem<T>::from_f(y); }
+                i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+                *(i32x4_t*)(sO + px * 128 + (((4 * cw + 2 * h + v) ^ ((px >> 1) & 7)) << 4)) = ov;
+            }
+        }
+        int b, y0, x0;
+        tile_origin(tile, b, y0, x0);
+        uint32_t so[NST];
+        i32x4_t mv[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int row = 8 * (wave + 4 * i) + (lane >> 3);
+            const int y = y0 + (row >> 5), x = x0 + (row & 31);
+            so[i] = (y < a.H && x < a.W) ? (uint32_t)(((b * a.H + y) * a.W + x) * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) : URSO_OOB_SHIFT;
+            if constexpr (MASK) mv[i] = buf_load16(rmk, so[i]);
+        }
+        c3_barrier();
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            i32x4_t v = *(const i32x4_t*)(sO + (wave + 4 * i) * 1024 + lane * 16);
+            if constexpr (MASK) {
+                T x[8], m[8];
+                __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &mv[i], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = Elem<T>::to_f(m[e]) > 0.f ? x[e] : Elem<T>::from_f(0.f);
+                __builtin_memcpy(&v, x, 16);
+            }
+            buf_store16(rds, so[i], v);
+        }
+        if (!has_next) break;
+        tile += bpx; buf ^= 1;
+    }
+}
+
+static int c3_device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+// conv_igemm.hip asks before choosing a kernel.  Policy option "c3": 0 never, 1 (default) wherever the shape qualifies.
+bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
+    if (!g_urso_opt.c3 || add || (dt != URSO_BF16 && dt != URSO_F16) || (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS))) return false;
+    if (g->KH != 3 || g->KW != 3 || g->SH != 1 || g->SW != 1 || g->PH != 1 || g->PW != 1 || g->DH != 1 || g->DW != 1 || g->FH > 0) return false;
+    if (g->C != 64 || g->N != 64 || g->OH != g->H || g->OW != g->W) return false;
+    return (long long)g->B * g->H * g->W * 128 < 0x7FFFFF00ll;
+}
+
+int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* mask,
+                   void* dst, hipStream_t st) {
+    C3Args a;
+    a.src = src; a.wgt = wgt; a.bias = bias; a.mask = mask; a.dst = dst; a.relu = relu;
+    a.B = g->B; a.H = g->H; a.W = g->W;
+    a.bytes = (uint32_t)((size_t)g->B * g->H * g->W * 128);
+    a.tiles_x = ceil_div(g->W, C3_TW); a.tiles_y = ceil_div(g->H, C3_TH); a.ntiles = g->B * a.tiles_y * a.tiles_x;
+    int bpx = ceil_div(a.ntiles, 8);
+    const int cap = 2 * c3_device_cus() / 8;
+    if (bpx > cap) bpx = cap;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
+    const dim3 grid(8 * bpx), blk(256);
+    if (dt == URSO_BF16) {
+        if (mask) hipLaunchKernelGGL((c3_kernel<__bf16, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((c3_kernel<__bf16, false>), grid, blk, 0, st, a);
+    } else {
+        if (mask) hipLaunchKernelGGL((c3_kernel<_Float16, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((c3_kernel<_Float16, false>), grid, blk, 0, st, a);
+    }
+    return urso_check_launch("urso_conv_igemm(3x3, 64 channels)");
+}
