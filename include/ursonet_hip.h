@@ -140,7 +140,13 @@ int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
 int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide);
 int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,
                    const void* add_d, void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d,
-                   void* dst_d, void* stream);
+                   void* dst_d, int add_h, int add_w, void* stream);
+/* add_h = add_w = 0: add_d is dense.  add_h, add_w > 0 (mode 1 only): the gradient in add_d reached this block through stride-2
+ * pointwise layers (the entry of the next stage, net.py:121-126), so it is non-zero only at even rows and columns of the
+ * [B][add_h][add_w] pixel grid: add_d then holds just those pixels, [B][add_h/2][add_w/2][wide] -- the dense tensor (three quarters
+ * zeros) is never written or read.  urso_rows_subsample2 gathers the matching rows of a per-pixel byte array (the ReLU bit mask the
+ * stride-2 layers' data gradients need): out[b][y/2][x/2][:] = in[b][y][x][:], row_bytes % 16 == 0. */
+int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel). */

@@ -831,3 +831,38 @@ def test_3x3_64_channel_layers_register_filter_kernel(case, dt, cap, c3):
     hip = _hip()
     with hip.options(c3=c3, grid_cap=cap):
         test_conv_forward_and_gradients(case, dt)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 0), (4, 8, 24, 0), (4, 64, 80, 8), (8, 64, 80, 0)], ids=["small", "rows_straddle_tiles", "capped", "multi_tile"])
+def test_backward_pair_with_compact_add_operand(dt, c, shape):
+    """urso_conv_pair mode 1 with the residual gradient given in COMPACT form (only the even rows / columns of the pixel grid, the
+    pixels a stride-2 stage entry samples) must equal, bit for bit, the same call on the dense tensor with explicit zeros; image
+    widths that do not divide the 64- / 32-pixel tiles make tiles straddle image rows.  urso_rows_subsample2 against indexing."""
+    hip = _hip()
+    B, H, W, cap = shape
+    M = B * H * W
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + c)
+    src, act = dev(torch.randn(M, c), dt), dev(torch.randn(M, c), dt)
+    w1, w2 = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
+    compact = dev(torch.randn(B, H // 2, W // 2, 4 * c), dt)
+    dense = torch.zeros(B, H, W, 4 * c, dtype=tdt, device="cuda")
+    dense[:, ::2, ::2] = compact
+    bits = torch.randint(0, 256, (M, c // 2), dtype=torch.uint8, device="cuda")
+    outs = []
+    for add, hw in ((dense, None), (compact, (H, W))):
+        mid = torch.full((M, 4 * c), 3.0, device="cuda").to(tdt); dst = torch.full((M, c), 3.0, device="cuda").to(tdt)
+        with hip.options(grid_cap=cap):
+            hip.conv_pair(M, c, dt, 1, src, w1, None, add, bits, mid, w2, None, act, dst, add_hw=hw)
+        torch.cuda.synchronize()
+        outs.append((mid, dst))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[1][0].float() != 0).float().mean()) > 0.2
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_pair(M, c, dt, 0, src, w1, None, compact, None, mid, w2, None, None, dst, add_hw=(H, W))      # forward form has no compact operand
+    sub = torch.empty(B, H // 2, W // 2, c // 2, dtype=torch.uint8, device="cuda")
+    hip.rows_subsample2(B, H, W, c // 2, bits, sub)
+    torch.cuda.synchronize()
+    assert torch.equal(sub, bits.reshape(B, H, W, c // 2)[:, ::2, ::2])

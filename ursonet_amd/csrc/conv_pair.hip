@@ -31,6 +31,9 @@ struct PairArgs {
     uint32_t nar_bytes, wide_bytes, bits_bytes;      // [M][CM], [M][CW], [M][CW/8]
     int ntiles;
     int relu1;                                       // VAR != 0 (single layer): ReLU on the wide output or not
+    // SPARSE add (backward pair behind a stride-2 stage entry): `add` is the COMPACT gradient [B][sp_h/2][sp_w/2][CW] of a dense
+    // [B][sp_h][sp_w] pixel grid whose odd rows and columns are zero (only every second pixel of every second row fed the next stage)
+    int sp_h, sp_w; uint32_t add_bytes; float rcp_hw, rcp_w;
 };
 
 template <typename T> struct PrMma32;
@@ -77,8 +80,9 @@ using PairS3 = PairShape<128, 8, 32, 3>;
 // VAR 0: the pair.  VAR 1 / 2: ONLY the first layer (c -> 4c pointwise, MODE 0) with / without a residual operand -- the same input
 // pipeline, filters in registers and row-contiguous stores for the block-closing layers that have no partner (res2c/res3d_branch2c,
 // the stride-1 shortcut conv): urso_conv_igemm_ex sends them here.
-template <typename T, int MODE, bool EMIT, typename S, int VAR>
+template <typename T, int MODE, bool EMIT, typename S, int VAR, bool SPARSE = false>
 __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
+    static_assert(!SPARSE || (MODE == 1 && VAR == 0), "sparse add: backward pair only");
     static_assert(sizeof(T) == 2, "16-bit element types only");
     static_assert(VAR == 0 || MODE == 0, "single-layer variants are forward-form only");
     constexpr bool G2 = VAR == 0, HAS_ADD = VAR != 2;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     int tile = xcd * cpx + lb;
     if (tile >= t_end) return;
 
-    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc(a.add, a.wide_bytes);
+    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc(a.add, SPARSE ? a.add_bytes : a.wide_bytes);
     const __amdgpu_buffer_rsrc_t rmid = make_rsrc(a.mid, a.wide_bytes), rdst = make_rsrc(a.dst, a.nar_bytes);
     const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? a.bits : a.mid, a.bits ? a.bits_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rmk2 = make_rsrc(MODE == 1 ? a.mask2 : a.dst, MODE == 1 ? a.nar_bytes : 0u);
@@ -118,9 +122,25 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)(BM * RROW);
 #pragma unroll
         for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
-        if constexpr (HAS_ADD) {
+        if constexpr (HAS_ADD && !SPARSE) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + roff[i]);
+        }
+        if constexpr (SPARSE) {
+            // row -> pixel (b, y, x) of the dense grid; odd y or x: the gradient is zero there (out-of-range offset = zero fill),
+            // else the row comes from compact pixel (b, y/2, x/2)
+            const int hw = a.sp_h * a.sp_w, w2 = a.sp_w >> 1, hw4 = (a.sp_h >> 1) * w2;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int row = (1024 / RROW) * (wave + NW * i) + lane / (RROW / 16);
+                const int p = t * BM + row;
+                int b = (int)((float)p * a.rcp_hw), rem = p - b * hw;
+                { const bool lo = rem < 0, hi = rem >= hw; b += hi ? 1 : (lo ? -1 : 0); rem += hi ? -hw : (lo ? hw : 0); }
+                int y = (int)((float)rem * a.rcp_w), x = rem - y * a.sp_w;
+                { const bool lo = x < 0, hi = x >= a.sp_w; y += hi ? 1 : (lo ? -1 : 0); x += hi ? -a.sp_w : (lo ? a.sp_w : 0); }
+                const uint32_t off = (uint32_t)((b * hw4 + (y >> 1) * w2 + (x >> 1)) * RROW) + (roff[i] & (uint32_t)(RROW - 1));
+                pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, ((y | x) & 1) ? URSO_OOB_SHIFT : off);
+            }
         }
     };
     constexpr int NDMA = NA + (HAS_ADD ? NR : 0);
@@ -367,14 +387,17 @@ extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) 
 }
 
 template <typename S, int VAR>
-static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st) {
+static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st, bool sparse = false) {
     int bpx = ceil_div(a.ntiles, 8);
     const int cap = blocks_per_cu * pr_device_cus() / 8;
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(S::NW * 64);
     if constexpr (VAR == 0) {
-        if (dt == URSO_BF16) {
+        if (sparse && mode == 1) {
+            if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 0, true>), grid, blk, 0, st, a);
+        } else if (dt == URSO_BF16) {
             if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0>), grid, blk, 0, st, a);
             else if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, 0>), grid, blk, 0, st, a);
             else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, 0>), grid, blk, 0, st, a);
@@ -407,7 +430,7 @@ int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const voi
     const int cm = g->C, cw = g->N;
     PairArgs a;
     a.src = src; a.w1 = wgt; a.bias1 = bias; a.add = add ? add : dst; a.bits = bits_out; a.mid = dst; a.w2 = nullptr; a.bias2 = nullptr;
-    a.mask2 = nullptr; a.dst = dst; a.relu1 = relu;
+    a.mask2 = nullptr; a.dst = dst; a.relu1 = relu; a.sp_h = a.sp_w = 0; a.add_bytes = 0; a.rcp_hw = a.rcp_w = 0.f;
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
     if (cm == PairS2::CM) {
         a.ntiles = (int)(M / PairS2::BM);
@@ -421,7 +444,7 @@ int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const voi
 
 extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,
                               const void* add_d, void* bits_d, void* mid_d, const void* w2_d, const float* bias2_d, const void* mask2_d,
-                              void* dst_d, void* stream) {
+                              void* dst_d, int add_h, int add_w, void* stream) {
     const int cm = c_narrow, cw = 4 * c_narrow;
     if (!urso_conv_pair_ok(M, dt, cm, cw)) {
         urso_set_error("urso_conv_pair: needs 16-bit dt, (64, 256) channels with M %% 64 == 0 or (128, 512) with M %% 32 == 0, tensors < 2 GiB");
@@ -430,18 +453,24 @@ extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const
     if (!src_d || !w1_d || !add_d || !mid_d || !w2_d || !dst_d || (mode != 0 && mode != 1) || (mode == 1 && (!bits_d || !mask2_d))) {
         urso_set_error("urso_conv_pair: bad argument"); return URSO_EINVAL;
     }
+    const bool sparse = add_h > 0 || add_w > 0;
+    if (sparse && (mode != 1 || add_h <= 0 || add_w <= 0 || (add_h & 1) || (add_w & 1) || M % ((long long)add_h * add_w))) {
+        urso_set_error("urso_conv_pair: a compact add operand needs mode 1, even add_h / add_w and M = B * add_h * add_w"); return URSO_EINVAL;
+    }
     if ((((uintptr_t)src_d) | ((uintptr_t)w1_d) | ((uintptr_t)add_d) | ((uintptr_t)mid_d) | ((uintptr_t)w2_d) | ((uintptr_t)dst_d) |
          ((uintptr_t)bits_d) | ((uintptr_t)mask2_d)) & 15) { urso_set_error("urso_conv_pair: pointers must be 16-byte aligned"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     PairArgs a;
     a.src = src_d; a.w1 = w1_d; a.bias1 = bias1_d; a.add = add_d; a.bits = bits_d; a.mid = mid_d; a.w2 = w2_d; a.bias2 = bias2_d;
     a.mask2 = mask2_d; a.dst = dst_d; a.relu1 = 1;
+    a.sp_h = add_h; a.sp_w = add_w; a.add_bytes = (uint32_t)(M / 4 * cw * 2);
+    a.rcp_hw = sparse ? 1.0f / (float)(add_h * add_w) : 0.f; a.rcp_w = sparse ? 1.0f / (float)add_w : 0.f;
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
     const double flops = 2.0 * (double)M * cm * cw * 2.0;
-    const double bytes = (double)M * (2.0 * cm * 2 + 2.0 * cw * 2) + (double)M * (cw / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
+    const double bytes = (double)M * (2.0 * cm * 2 + (sparse ? 1.25 : 2.0) * cw * 2) + (double)M * (cw / 8) * ((mode == 1 || bits_d) ? 1 : 0) +
                          (mode == 1 ? (double)M * cm * 2 : 0.0) + 2.0 * cm * cw * 2;
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    if (cm == PairS2::CM) { a.ntiles = (int)(M / PairS2::BM); pr_launch<PairS2, 0>(a, dt, mode, bits_d != nullptr, 2, st); }
-    else { a.ntiles = (int)(M / PairS3::BM); pr_launch<PairS3, 0>(a, dt, mode, bits_d != nullptr, 1, st); }
+    if (cm == PairS2::CM) { a.ntiles = (int)(M / PairS2::BM); pr_launch<PairS2, 0>(a, dt, mode, bits_d != nullptr, 2, st, sparse); }
+    else { a.ntiles = (int)(M / PairS3::BM); pr_launch<PairS3, 0>(a, dt, mode, bits_d != nullptr, 1, st, sparse); }
     return urso_check_launch("urso_conv_pair");
 }

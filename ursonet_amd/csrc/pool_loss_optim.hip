@@ -90,6 +90,17 @@ __global__ void maxpool_bwd_kernel(int B, int H, int W, int C, const T* __restri
     }
 }
 
+// rows of a [B][H][W][row_bytes] byte array at even (y, x) -> [B][H/2][W/2][row_bytes] (16-byte vectors)
+__global__ void subsample2_kernel(int B, int H, int W, int rv, const i32x4_t* __restrict__ in, i32x4_t* __restrict__ out) {
+    const int OH = H / 2, OW = W / 2;
+    const uint32_t total = (uint32_t)B * OH * OW * rv;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int v = (int)(i % (uint32_t)rv); uint32_t p = i / (uint32_t)rv;
+        const int ox = (int)(p % (uint32_t)OW); p /= (uint32_t)OW; const int oy = (int)(p % (uint32_t)OH); const int b = (int)(p / (uint32_t)OH);
+        out[i] = in[(((size_t)b * H + 2 * oy) * W + 2 * ox) * rv + v];
+    }
+}
+
 static int pool_blocks(size_t total) { size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 extern "C" int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const void* x_d, void* y_d, uint8_t* argmax_d, void* stream) {
@@ -478,4 +489,16 @@ extern "C" int urso_quat_wavg_decode(int B, int K, const float* logits_d, const 
     ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 16);
     hipLaunchKernelGGL(quat_wavg_kernel, dim3(B), dim3(256), 0, st, K, logits_d, hquat_d, q_d, a_d);
     return urso_check_launch("urso_quat_wavg_decode");
+}
+
+// The ReLU bit mask (or any per-pixel byte rows) of the pixels a stride-2 pointwise layer samples: out[b][y/2][x/2][:] = in[b][y][x][:].
+extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
+    if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
+        ((((uintptr_t)in_d) | ((uintptr_t)out_d)) & 15)) { urso_set_error("urso_rows_subsample2: bad argument (even H, W; 16-byte rows)"); return URSO_EINVAL; }
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (row_bytes / 16);
+    if (total >= 0x7FFFFFFFull) { urso_set_error("urso_rows_subsample2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_POOL, 0, (double)total * 32);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
+    return urso_check_launch("urso_rows_subsample2");
 }

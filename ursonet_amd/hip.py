@@ -112,7 +112,8 @@ _SIGS = {
     "urso_comm_wait": (_i, [_vp, _vp]),
     "urso_comm_destroy": (_i, [_vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
-    "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
+    "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
+    "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -401,10 +402,17 @@ def conv_pair_ok(M, dt, c_narrow, c_wide):
     return bool(_lib.urso_conv_pair_ok(int(M), dt, int(c_narrow), int(c_wide)))
 
 
-def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, mask2, dst, stream=None):
-    """urso_conv_pair: two chained pointwise layers (c -> 4c (+add) -> c, c = 64 or 128) in one pass; mode 0 forward, 1 backward."""
+def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, mask2, dst, add_hw=None, stream=None):
+    """urso_conv_pair: two chained pointwise layers (c -> 4c (+add) -> c, c = 64 or 128) in one pass; mode 0 forward, 1 backward.
+    add_hw = (H, W): `add` is the compact [B, H/2, W/2, 4c] gradient of a dense grid that is zero at odd rows / columns."""
+    ah, aw = add_hw if add_hw else (0, 0)
     _chk(_lib.urso_conv_pair(int(M), int(c_narrow), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
-                             ptr(mask2), ptr(dst), stream_ptr(stream)), "urso_conv_pair")
+                             ptr(mask2), ptr(dst), int(ah), int(aw), stream_ptr(stream)), "urso_conv_pair")
+
+
+def rows_subsample2(B, H, W, row_bytes, src, dst, stream=None):
+    """urso_rows_subsample2: dst[b, y/2, x/2, :] = src[b, y, x, :] over per-pixel byte rows (ReLU bit masks)."""
+    _chk(_lib.urso_rows_subsample2(B, H, W, row_bytes, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rows_subsample2")
 
 
 def encode_loc(B, K, loc, hmap, sig2, out, stream=None):
