@@ -552,9 +552,9 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
             eng = Engine(cfg, "training", seed=5, randomize_bn=True)
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
-                    sorted(eng.pair_first)))
+                    sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l)))
     assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
-    assert res[1][0] - res[0][0] == 5 and res[1][1] - res[0][1] == 5
+    assert res[1][0] - res[0][0] == 5 and res[0][6] == 5 and res[1][6] == 0        # five fused launches forward, five backward
     tol_out = 2e-2 if dtype == "bfloat16" else 4e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])
@@ -606,3 +606,33 @@ def test_urso_comm_bucket_averaging_one_rank():
     finally:
         dist.destroy_process_group()
         comm.close()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_compact_stage_boundary_gradients_equal_the_dense_path(dtype, monkeypatch):
+    """The gradient of a stage's last block output is non-zero only at the pixels the next stage's stride-2 layers sample.  The engine
+    keeps it compact ([B, H/2, W/2, C]: Engine._plan_compact_gradients) and runs the strided data gradients as plain GEMMs, the
+    producer's weight gradient as a stride-2 weight gradient, its data gradient as a compact scatter and the residual hand-over through
+    urso_conv_pair's compact add operand.  Same step with the dense path (URSO_COMPACT_GRAD=0): same losses, activation and weight
+    gradients equal up to the fp32 summation order of the re-shaped kernels (a fraction of one storage rounding step)."""
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 128, 192, batch=2, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=33)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("URSO_COMPACT_GRAD", mode)
+        eng = Engine(cfg, "training", seed=5, randomize_bn=True)
+        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+        compact = sorted(c.name for c in eng.convs.values() if c.dst.compact is not None)
+        res.append((compact, eng.get_grads(), eng.losses(), {n: c.src.grad.float().clone() for n, c in eng.convs.items()
+                                                             if c.src.grad is not None and c.src.compact is None}))
+    assert res[0][0] == ["res2c_branch2c", "res3d_branch2c"] and res[1][0] == []          # stages with a fused backward pair
+    assert res[0][2] == res[1][2]
+    assert len(res[0][3]) >= 40
+    wa = max((float((gc - res[1][3][n]).norm() / (res[1][3][n].norm() + 1e-30)), n) for n, gc in res[0][3].items())
+    ww = max((_rel(res[0][1][ln][wn], res[1][1][ln][wn]), ln + "/" + wn) for ln in res[1][1] for wn in res[1][1][ln])
+    print("compact vs dense (%s): worst activation gradient (L2) %.2e at %s, worst weight gradient %.2e at %s" % (dtype, wa[0], wa[1], ww[0], ww[1]))
+    # not bit-identical: the compact-scatter data gradient and the stride-2 weight gradient sum in another order, and one fp32 ulp decides
+    # a 16-bit rounding here and there; the plans agree to a small fraction of a storage rounding step
+    tol = 4e-3 if dtype == "bfloat16" else 1e-3          # measured 1e-3 / 5e-4
+    assert wa[0] < tol and ww[0] < tol, (wa, ww)

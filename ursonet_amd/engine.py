@@ -13,6 +13,7 @@ buffers, so that the data-parallel all-reduce works on contiguous slices (ursone
 and the optimizer is two launches.
 """
 import math
+import os
 import re
 from collections import OrderedDict
 
@@ -42,6 +43,8 @@ class _Act(object):
         self.grad_written = False
         self.pending = None          # gradient tensor to be folded into the next dgrad into this tensor
         self.bits = None             # ReLU bit mask (1 byte per 8 elements), written by the producing conv's forward epilogue
+        self.compact = None          # (H, W): the gradient buffer holds only the even rows / columns of the pixel grid ([B, H/2, W/2, C])
+        self.pending_hw = None       # same, for a pending residual gradient
         self.eng = eng
 
     def grad_buf(self):
@@ -347,6 +350,7 @@ class Engine(object):
                 need[node.dst.id] = (own or (not node.stem and need.get(node.src.id, False)) or
                                      (node.residual is not None and need.get(node.residual.id, False)))
         self.grad_needed = need
+        self._plan_compact_gradients(need)
         for node in reversed(g.nodes):
             if not need[node.dst.id]:
                 continue                                   # nothing trainable at or below this node
@@ -364,7 +368,8 @@ class Engine(object):
                 continue
             c = self.convs[node.name]
             assert c.dst.grad_written or c.dst.grad is not None, "no gradient reaches %s" % node.name
-            G = c.dst.grad
+            G = c.dst.grad                             # compact tensors: [B, H/2, W/2, N] (see _plan_compact_gradients)
+            gf_w = getattr(c, "gf_compact", None) or c.gf
             tr = self.layer_trainable[node.name]
             bn_tr = self.layer_trainable[node.bn] if node.bn else False
             Gsum = G                                   # gradient w.r.t. (BN output + residual): what a residual branch receives
@@ -395,7 +400,7 @@ class Engine(object):
                 self.labels["bwd"].append("finalize:" + node.name)
             elif tr or bn_tr:
                 d = c.desc
-                c.wg_ws = torch.empty(hip.conv_wgrad_ws_bytes(c.gf, dt) // 4 + 64, dtype=torch.float32, device=dev)
+                c.wg_ws = torch.empty(hip.conv_wgrad_ws_bytes(gf_w, dt) // 4 + 64, dtype=torch.float32, device=dev)
                 n_part = c.splits * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
@@ -407,7 +412,7 @@ class Engine(object):
                 d.gb = hip.ptr(self.gview(node.name, "bias").reshape(-1)) if node.bias else None
                 d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
-                self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad_partial(c.gf, dt, c.src.data, G, c.wg_ws)))
+                self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.src.data, G, c.wg_ws)))
                 self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
                     k = last_of_group[node.name]
@@ -422,7 +427,9 @@ class Engine(object):
                     raise AssertionError("unexpected second residual consumer for %s" % node.name)
                 if R.spec.relu:
                     R.pending = Gsum
+                    R.pending_hw = c.dst.compact           # (H, W) when Gsum holds only the even rows / columns, else None
                 else:
+                    assert c.dst.compact is None
                     R.grad, R.grad_written = Gsum, True
             # -- data gradient into the conv input
             if getattr(c, "dgrad_done_by_pair", False):
@@ -430,19 +437,32 @@ class Engine(object):
             if not node.stem and need[c.src.spec.id]:
                 X = c.src
                 add = X.grad if X.grad_written else X.pending
+                if X.compact is not None:
+                    # stride-2 pointwise consumer of a block output whose gradient is kept compact: a plain pointwise GEMM over the
+                    # sampled pixels (no scatter, no zero fill of a dense tensor), masked with the sampled rows of X's ReLU bit mask
+                    if not X.grad_written:
+                        self.bwd_ops.append((None, lambda X=X: hip.rows_subsample2(B, X.compact[0], X.compact[1], X.spec.c // 8, X.bits, X.bits_compact)))
+                        self.labels["bwd"].append("bits_subsample")
+                    self.bwd_ops.append((None, lambda c=c, G=G, X=X, add=(X.grad if X.grad_written else None):
+                                         hip.conv_igemm_ex(c.gd_compact, dt, hip.EPI_MASK_BITS, G, c.wd, None, add, X.bits_compact, X.grad, None, None)))
+                    self.labels["bwd"].append("dgrad:" + node.name)
+                    X.grad_written = True
+                    continue
                 A = self.pair_first.get(node.name)         # this layer is the second of a fused forward pair (A = the block-closing 2c)
                 if (A is not None and X.spec.relu and X.bits is not None and X.pending is not None and not X.grad_written and
                         need[A.src.spec.id] and A.src.spec.relu and A.src.bits is None and not A.src.grad_written and A.src.pending is None):
                     # data gradient of this layer into X (+ residual gradient, ReLU bit mask) and, from the LDS copy of that result,
                     # the data gradient of layer A into ITS input: X.grad crosses HBM once (conv_pair.hip)
                     dstg, dst2 = X.grad_buf(), A.src.grad_buf()
-                    self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2:
-                                         hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2)))
+                    self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
+                                         hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2,
+                                                       add_hw=hw)))
                     self.labels["bwd"].append("dgrad:%s+%s" % (node.name, A.name))
                     X.grad_written, X.pending = True, None
                     A.src.grad_written = True
                     A.dgrad_done_by_pair = True
                     continue
+                assert X.pending_hw is None or X.grad_written, "compact residual gradient reached a non-fused data gradient (%s)" % node.name
                 dstg = X.grad_buf()
                 mask = (X.bits if X.bits is not None else X.data) if X.spec.relu else None
                 mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
@@ -594,6 +614,59 @@ class Engine(object):
         else:
             self.gt_ori = torch.zeros(B, nori, dtype=torch.float32, device=dev)
             self.loss_ops.append(lambda: hip.softmax_xent(B, nori, ori.data, self.gt_ori, wo, 1, dt, self.loss_buf[1:2], gz_ori, self.row_ws))
+
+    def _plan_compact_gradients(self, need):
+        """A block output X whose only consumers are the stride-2 pointwise layers of the next stage's first block (net.py:121-126:
+        branch2a and the shortcut conv) receives a gradient that is zero at three of every four pixels.  The dense tensor is never
+        materialised: X.grad is [B, H/2, W/2, C] (the sampled pixels), and everything that reads it runs on that form --
+          * the stride-2 layers' data gradients are plain pointwise GEMMs over the sampled pixels (no scatter, no 4x zero fill),
+            masked by the sampled rows of X's ReLU bit mask (urso_rows_subsample2);
+          * the weight gradient of X's producer is a stride-2 weight gradient (its forward input sampled at the same pixels);
+          * the producer's own data gradient is the compact-scatter form (GEMM over the sampled pixels, zeros elsewhere);
+          * the residual branch hands the compact tensor to the fused backward pair (urso_conv_pair, add_h / add_w).
+        Needs the fused backward pair on the residual side; anything else keeps the dense path (URSO_COMPACT_GRAD=0 switches it off)."""
+        g, dt, B, dev = self.graph, self.dt, self.B, self.device
+        if dt == hip.F32 or not self.pair_first or os.environ.get("URSO_COMPACT_GRAD", "1") == "0":
+            return
+        convs = list(self.convs.values())
+        for X in self.acts.values():
+            if X.bits is None or not X.spec.relu or X.spec.h % 2 or X.spec.w % 2 or not need.get(X.spec.id, False):
+                continue
+            prod = [c for c in convs if c.dst is X]
+            cons = [c for c in convs if c.src is X]
+            if len(prod) != 1 or not cons or any(c.res is X for c in convs) or any(n.op == "pool" and n.src.id == X.spec.id for n in g.nodes):
+                continue
+            A = prod[0]
+            n = A.node
+            if not (not n.stem and not n.dense and n.kh == 1 and n.kw == 1 and n.stride == 1 and A.res is not None and not A.batch_bn and
+                    A.npad == A.N and A.res.spec.relu and need.get(A.src.spec.id, False) and A.src.spec.relu and A.src.bits is None):
+                continue
+            if not all((not c.node.dense) and c.node.kh == 1 and c.node.kw == 1 and c.node.stride == 2 and not c.batch_bn and
+                       c.npad == c.N and tuple(c.node.pad) == (0, 0) for c in cons):
+                continue
+            # the residual gradient must land in a fused backward pair: the block's branch2a (consumer of A.res) is the second layer of
+            # a fused forward pair, and A.res has no other consumer
+            R = A.res
+            rc = [c for c in convs if c.src is R]
+            if len(rc) != 1 or self.pair_first.get(rc[0].name) is None or R.bits is None or sum(1 for c in convs if c.res is R) != 1:
+                continue
+            H, W = X.spec.h, X.spec.w
+            gd_ok = True
+            for c in cons:
+                c.gd_compact = hip.geom(B, H // 2, W // 2, c.npad, H // 2, W // 2, c.node.cin, 1, 1)
+                gd_ok = gd_ok and hip.conv_igemm_bits_ok(c.gd_compact, dt, 0, 0)
+            if not gd_ok:
+                continue
+            X.compact = (H, W)
+            X.grad = torch.empty(X.numel // 4, dtype=self.tdt, device=dev)
+            X.bits_compact = torch.empty(X.numel // 32, dtype=torch.uint8, device=dev)
+            # producer: stride-2 weight gradient, compact-scatter data gradient
+            A.gf_compact = hip.geom(B, H, W, n.cin, H // 2, W // 2, A.npad, 1, 1, 2, 2, 0, 0)
+            A.splits = hip.conv_wgrad_splits(A.gf_compact, dt)
+            A.desc.splits = max(A.splits, 1)
+            A.gd = hip.geom(B, H // 2, W // 2, A.npad, H // 2, W // 2, n.cin, 1, 1, FH=H, FW=W, OSH=2, OSW=2)
+            A.gd_scatter = True
+            A.ws_d = 0
 
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly
