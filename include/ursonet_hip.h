@@ -158,6 +158,9 @@ int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_
  *   colsum[n]            = sum_{b,oy,ox} dz[b,oy,ox,n]                     (fp32, optional)
  * `g` is the FORWARD geometry (src = x, dst = dz, D = 1).  Deterministic split over the
  * pixel dimension with fp32 partials in ws_d (no atomics).
+ * Scattered dz (16-bit dtypes, g->FH > 0): dz pixel (b, oy, ox) is read at (b, oy*OSH, ox*OSW) of a dense [B][FH][FW][N] tensor.
+ * Use: the gradient of a stride-1 layer that is non-zero only on a coarser grid (it came through stride-2 layers: the last block of
+ * a stage) -- its weight gradient then IS the weight gradient of the stride-OSH layer over those pixels; the zeros are never read.
  */
 #define URSO_WGRAD_PART_PAD 64   /* floats of padding between consecutive partial tensors: a power-of-two distance would put the
                                    same element of every partial on the same HBM channel */

@@ -866,3 +866,36 @@ def test_backward_pair_with_compact_add_operand(dt, c, shape):
     hip.rows_subsample2(B, H, W, c // 2, bits, sub)
     torch.cuda.synchronize()
     assert torch.equal(sub, bits.reshape(B, H, W, c // 2)[:, ::2, ::2])
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64, 64, 3), (2, 32, 40, 128, 128, 3), (3, 16, 16, 64, 256, 1), (4, 128, 160, 64, 64, 3)],
+                         ids=["c3x3_64", "c3x3_128", "pointwise_wide", "stage2_rows"])
+def test_weight_gradient_with_dz_on_a_coarser_grid(dt, shape):
+    """urso_conv_wgrad with a scattered dz operand (geometry FH / FW / OSH / OSW): the gradient tensor is dense [B, H, W, N] but
+    non-zero only at even rows / columns; the stride-2 geometry reading it in place must give exactly the weight gradient computed
+    from the gathered compact tensor, and (up to the summation order of a different split) the stride-1 weight gradient of the dense
+    tensor with its explicit zeros."""
+    hip = _hip()
+    B, H, W, Ci, N, k = shape
+    pad = k // 2
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(sum(shape) + dt)
+    x = dev(torch.randn(B, H, W, Ci), dt)
+    compact = dev(torch.randn(B, H // 2, W // 2, N), dt)
+    dense = torch.zeros(B, H, W, N, dtype=tdt, device="cuda")
+    dense[:, ::2, ::2] = compact
+
+    def wgrad(g, dz):
+        ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 64, dtype=torch.float32, device="cuda")
+        dw = torch.empty(k * k * Ci * N, dtype=torch.float32, device="cuda"); cs = torch.empty(N, dtype=torch.float32, device="cuda")
+        hip.conv_wgrad(g, dt, x, dz, ws, dw, cs)
+        torch.cuda.synchronize()
+        return dw, cs
+    g_compact = hip.geom(B, H, W, Ci, H // 2, W // 2, N, k, k, 2, 2, pad, pad)
+    g_scatter = hip.geom(B, H, W, Ci, H // 2, W // 2, N, k, k, 2, 2, pad, pad, FH=H, FW=W, OSH=2, OSW=2)
+    g_dense = hip.geom(B, H, W, Ci, H, W, N, k, k, 1, 1, pad, pad)
+    a, b, c = wgrad(g_compact, compact), wgrad(g_scatter, dense), wgrad(g_dense, dense)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert relerr(b[0], c[0]) < 2e-5 and relerr(b[1], c[1]) < 2e-5
+    assert float(b[0].abs().max()) > 0

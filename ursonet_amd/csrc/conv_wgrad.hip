@@ -26,6 +26,7 @@ struct WgradArgs {
     int dbg;
     int pointwise;             // 1x1 / stride 1 / no padding: source pixel == destination pixel
     float rcp_ohw, rcp_ow;
+    int zs, ZH, ZW, zsh, zsw;  // zs: dz pixel (b, oy, ox) lives at (b, oy*zsh, ox*zsw) of a [B][ZH][ZW][N] tensor (16-bit kernels)
 };
 
 // MODE 0: pointwise conv (source pixel == destination pixel); 1: wide rows (OW >= RM: carried coordinates, single
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
         for (int e = 0; e < ITEMS; ++e) {
             const int m = mcur + prow + 16 * e;
             const bool mvalid = m < m_end;
+            uint32_t zp = (uint32_t)m;                    // dz pixel index (scattered form: set below)
             uint32_t off; bool ok;
             if constexpr (MODE == 0) { off = (uint32_t)(m * a.C) * 2u + xc_off; ok = mvalid && kvalid; }
             else {
@@ -312,9 +314,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
                 const int iy = oy * a.SH - a.PH + ky, ix = ox * a.SW - a.PW + kx;
                 ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
                 off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off;
+                if (a.zs) zp = (uint32_t)((b * a.ZH + oy * a.zsh) * a.ZW + ox * a.zsw);
             }
             lds_dma16(rx, dx + e * 16 * 256, ok ? off : URSO_OOB_SHIFT);
-            const uint32_t zoff = (uint32_t)m * (uint32_t)a.N * 2u + z_off0;
+            const uint32_t zoff = zp * (uint32_t)a.N * 2u + z_off0;
             lds_dma16(rz, dz + e * 16 * 256, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
         }
         mcur += RM;
@@ -527,7 +530,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int mz = mcur + zrow + 32 * e;
-            const uint32_t zoff = (uint32_t)mz * (uint32_t)a.N * 2u + z_off0;
+            uint32_t zp = (uint32_t)mz;
+            if (a.zs) { int b, rem, oy, ox; divmod(mz, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); zp = (uint32_t)((b * a.ZH + oy * a.zsh) * a.ZW + ox * a.zsw); }
+            const uint32_t zoff = zp * (uint32_t)a.N * 2u + z_off0;
             lds_dma16(rz, dz + e * 32 * 128, (mz < m_end && nvalid) ? zoff : URSO_OOB_SHIFT);
         }
         mcur += RM;
@@ -730,7 +735,13 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     const size_t need = urso_conv_wgrad_ws_bytes(g, dt);
     if (ws_bytes < need) { urso_set_error("urso_conv_wgrad: workspace %zu < %zu", ws_bytes, need); return URSO_EWORKSPACE; }
     const size_t es = dt_size(dt);
-    const size_t x_bytes = (size_t)g->B * g->H * g->W * g->C * es, dz_bytes = (size_t)p.M * g->N * es;
+    const bool zscat = g->FH > 0;
+    if (zscat && (dt == URSO_F32 || g->FW <= 0 || g->OSH <= 0 || g->OSW <= 0 || (g->OH - 1) * g->OSH >= g->FH || (g->OW - 1) * g->OSW >= g->FW ||
+                  (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW))) {
+        urso_set_error("urso_conv_wgrad: scattered dz needs a 16-bit dtype, a non-pointwise geometry and a grid that fits [FH][FW]"); return URSO_EINVAL;
+    }
+    const size_t x_bytes = (size_t)g->B * g->H * g->W * g->C * es,
+                 dz_bytes = zscat ? (size_t)g->B * g->FH * g->FW * g->N * es : (size_t)p.M * g->N * es;
     if (x_bytes >= 0x7FFFFF00ull || dz_bytes >= 0x7FFFFF00ull) { urso_set_error("urso_conv_wgrad: tensor exceeds 2 GiB"); return URSO_EINVAL; }
     WgradArgs a;
     a.x = x_d; a.dz = dz_d; a.x_bytes = (uint32_t)x_bytes; a.dz_bytes = (uint32_t)dz_bytes;
@@ -743,13 +754,14 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     a.dbg = 0;
     a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW) ? 1 : 0;
     a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW;
+    a.zs = zscat ? 1 : 0; a.ZH = g->FH; a.ZW = g->FW; a.zsh = g->OSH; a.zsw = g->OSW;
     if ((size_t)g->B * g->OH * g->OW >= (1u << 24)) { urso_set_error("urso_conv_wgrad: more than 2^24 output pixels"); return URSO_EINVAL; }
     a.M = p.M; a.Cc = p.Cc; a.Kc = p.Kc; a.K = p.K; a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
     hipStream_t st = (hipStream_t)stream;
     double flops = 2.0 * p.M * (double)g->N * g->KH * g->KW * g->C;
     if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem (see urso_conv_igemm_ex)
     const double x_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? (double)p.M * g->C * es : (double)x_bytes;
-    double bytes = x_alg + (double)dz_bytes + (double)p.K * g->N * 4;
+    double bytes = x_alg + (double)p.M * g->N * es + (double)p.K * g->N * 4;
     ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
     dim3 grid(p.ktiles * p.ntiles, p.splits);
     const int rm = 128 / (int)dt_size(dt);

@@ -622,7 +622,8 @@ class Engine(object):
           * the stride-2 layers' data gradients are plain pointwise GEMMs over the sampled pixels (no scatter, no 4x zero fill),
             masked by the sampled rows of X's ReLU bit mask (urso_rows_subsample2);
           * the weight gradient of X's producer is a stride-2 weight gradient (its forward input sampled at the same pixels);
-          * the producer's own data gradient is the compact-scatter form (GEMM over the sampled pixels, zeros elsewhere);
+          * the producer's own data gradient is the compact-scatter form (GEMM over the sampled pixels, zeros elsewhere), and the 3x3
+            layer below it takes that tensor as a scattered dz operand: its weight gradient runs over the even pixels only;
           * the residual branch hands the compact tensor to the fused backward pair (urso_conv_pair, add_h / add_w).
         Needs the fused backward pair on the residual side; anything else keeps the dense path (URSO_COMPACT_GRAD=0 switches it off)."""
         g, dt, B, dev = self.graph, self.dt, self.B, self.device
@@ -667,6 +668,16 @@ class Engine(object):
             A.gd = hip.geom(B, H // 2, W // 2, A.npad, H // 2, W // 2, n.cin, 1, 1, FH=H, FW=W, OSH=2, OSW=2)
             A.gd_scatter = True
             A.ws_d = 0
+            # one layer further down: A's data gradient (dense tensor, zero off the even grid) is the dz of the layer that produced A's
+            # input -- its weight gradient is the stride-2 one over the even pixels, reading dz in place (scattered dz operand)
+            P = [c for c in convs if c.dst is A.src]
+            if len(P) == 1 and not P[0].batch_bn and not P[0].node.stem and not P[0].node.dense and P[0].node.stride == 1:
+                pn, Pc = P[0].node, P[0]
+                pt, pl = pn.pad
+                if pn.src.h == H and pn.src.w == W and (pn.kh > 1 or pn.kw > 1):
+                    Pc.gf_compact = hip.geom(B, H, W, pn.cin, H // 2, W // 2, Pc.npad, pn.kh, pn.kw, 2, 2, pt, pl, FH=H, FW=W, OSH=2, OSW=2)
+                    Pc.splits = hip.conv_wgrad_splits(Pc.gf_compact, dt)
+                    Pc.desc.splits = max(Pc.splits, 1)
 
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly
