@@ -147,6 +147,9 @@ int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_
  * zeros) is never written or read.  urso_rows_subsample2 gathers the matching rows of a per-pixel byte array (the ReLU bit mask the
  * stride-2 layers' data gradients need): out[b][y/2][x/2][:] = in[b][y][x][:], row_bytes % 16 == 0. */
 int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
+/* The inverse: out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere -- the dense form of a compact gradient for a
+ * consumer that cannot take the compact operand (stages whose residual hand-over is not a urso_conv_pair launch). */
+int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel). */

@@ -626,7 +626,7 @@ def test_compact_stage_boundary_gradients_equal_the_dense_path(dtype, monkeypatc
         compact = sorted(c.name for c in eng.convs.values() if c.dst.compact is not None)
         res.append((compact, eng.get_grads(), eng.losses(), {n: c.src.grad.float().clone() for n, c in eng.convs.items()
                                                              if c.src.grad is not None and c.src.compact is None}))
-    assert res[0][0] == ["res2c_branch2c", "res3d_branch2c"] and res[1][0] == []          # stages with a fused backward pair
+    assert res[0][0] == ["res2c_branch2c", "res3d_branch2c", "res4f_branch2c"] and res[1][0] == []      # the last block of stages 2-4
     assert res[0][2] == res[1][2]
     assert len(res[0][3]) >= 40
     wa = max((float((gc - res[1][3][n]).norm() / (res[1][3][n].norm() + 1e-30)), n) for n, gc in res[0][3].items())
@@ -634,5 +634,5 @@ def test_compact_stage_boundary_gradients_equal_the_dense_path(dtype, monkeypatc
     print("compact vs dense (%s): worst activation gradient (L2) %.2e at %s, worst weight gradient %.2e at %s" % (dtype, wa[0], wa[1], ww[0], ww[1]))
     # not bit-identical: the compact-scatter data gradient and the stride-2 weight gradient sum in another order, and one fp32 ulp decides
     # a 16-bit rounding here and there; the plans agree to a small fraction of a storage rounding step
-    tol = 4e-3 if dtype == "bfloat16" else 1e-3          # measured 1e-3 / 5e-4
+    tol = 4e-3 if dtype == "bfloat16" else 2e-3          # measured 1e-3 / 1e-3 at this tiny size (3e-7 at cfg2 size: only the summation order of six weight gradients differs)
     assert wa[0] < tol and ww[0] < tol, (wa, ww)

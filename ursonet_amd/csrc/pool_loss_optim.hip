@@ -491,6 +491,19 @@ extern "C" int urso_quat_wavg_decode(int B, int K, const float* logits_d, const 
     return urso_check_launch("urso_quat_wavg_decode");
 }
 
+// inverse of subsample2: out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere
+__global__ void expand2_kernel(int B, int H, int W, int rv, const i32x4_t* __restrict__ in, i32x4_t* __restrict__ out) {
+    const int OH = H / 2, OW = W / 2;
+    const uint32_t total = (uint32_t)B * H * W * rv;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int v = (int)(i % (uint32_t)rv); uint32_t p = i / (uint32_t)rv;
+        const int x = (int)(p % (uint32_t)W); p /= (uint32_t)W; const int y = (int)(p % (uint32_t)H); const int b = (int)(p / (uint32_t)H);
+        i32x4_t o = i32x4_t{0, 0, 0, 0};
+        if (!((x | y) & 1)) o = in[(((size_t)b * OH + (y >> 1)) * OW + (x >> 1)) * rv + v];
+        out[i] = o;
+    }
+}
+
 // The ReLU bit mask (or any per-pixel byte rows) of the pixels a stride-2 pointwise layer samples: out[b][y/2][x/2][:] = in[b][y][x][:].
 extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
     if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
@@ -501,4 +514,17 @@ extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const vo
     ProfScope ps(st, URSO_K_POOL, 0, (double)total * 32);
     hipLaunchKernelGGL(subsample2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
     return urso_check_launch("urso_rows_subsample2");
+}
+
+// out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere: the dense form of a gradient kept on the even pixel grid, for
+// a consumer that cannot take the compact form.
+extern "C" int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
+    if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
+        ((((uintptr_t)in_d) | ((uintptr_t)out_d)) & 15)) { urso_set_error("urso_rows_expand2: bad argument (even H, W; 16-byte rows)"); return URSO_EINVAL; }
+    const size_t total = (size_t)B * H * W * (row_bytes / 16);
+    if (total >= 0x7FFFFFFFull) { urso_set_error("urso_rows_expand2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_POOL, 0, (double)total * 16 * 1.25);
+    hipLaunchKernelGGL(expand2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
+    return urso_check_launch("urso_rows_expand2");
 }

@@ -425,7 +425,13 @@ class Engine(object):
                 R = c.res
                 if R.grad_written or R.pending is not None:
                     raise AssertionError("unexpected second residual consumer for %s" % node.name)
-                if R.spec.relu:
+                if R.spec.relu and c.dst.compact is not None and c.dst.residual_needs_dense:
+                    # no fused pair on the residual side: hand over the dense form (zeros written once, by the expansion)
+                    c.dst.grad_dense = torch.empty(c.dst.numel, dtype=self.tdt, device=dev)
+                    self.bwd_ops.append((None, lambda X=c.dst: hip.rows_expand2(B, X.compact[0], X.compact[1], X.spec.c * 2, X.grad, X.grad_dense)))
+                    self.labels["bwd"].append("expand:" + node.name)
+                    R.pending = c.dst.grad_dense
+                elif R.spec.relu:
                     R.pending = Gsum
                     R.pending_hw = c.dst.compact           # (H, W) when Gsum holds only the even rows / columns, else None
                 else:
@@ -625,9 +631,10 @@ class Engine(object):
           * the producer's own data gradient is the compact-scatter form (GEMM over the sampled pixels, zeros elsewhere), and the 3x3
             layer below it takes that tensor as a scattered dz operand: its weight gradient runs over the even pixels only;
           * the residual branch hands the compact tensor to the fused backward pair (urso_conv_pair, add_h / add_w).
-        Needs the fused backward pair on the residual side; anything else keeps the dense path (URSO_COMPACT_GRAD=0 switches it off)."""
+        Where the residual side is not a fused pair (stages 4-5, pair option off) the dense form is produced once by urso_rows_expand2.
+        URSO_COMPACT_GRAD=0 keeps the dense path everywhere."""
         g, dt, B, dev = self.graph, self.dt, self.B, self.device
-        if dt == hip.F32 or not self.pair_first or os.environ.get("URSO_COMPACT_GRAD", "1") == "0":
+        if dt == hip.F32 or os.environ.get("URSO_COMPACT_GRAD", "1") == "0":
             return
         convs = list(self.convs.values())
         for X in self.acts.values():
@@ -649,8 +656,9 @@ class Engine(object):
             # a fused forward pair, and A.res has no other consumer
             R = A.res
             rc = [c for c in convs if c.src is R]
-            if len(rc) != 1 or self.pair_first.get(rc[0].name) is None or R.bits is None or sum(1 for c in convs if c.res is R) != 1:
+            if len(rc) != 1 or sum(1 for c in convs if c.res is R) != 1:
                 continue
+            X.residual_needs_dense = self.pair_first.get(rc[0].name) is None or R.bits is None     # stages 4-5: expanded (urso_rows_expand2)
             H, W = X.spec.h, X.spec.w
             gd_ok = True
             for c in cons:

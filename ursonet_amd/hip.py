@@ -114,6 +114,7 @@ _SIGS = {
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "urso_rows_expand2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -408,6 +409,11 @@ def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, 
     ah, aw = add_hw if add_hw else (0, 0)
     _chk(_lib.urso_conv_pair(int(M), int(c_narrow), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
                              ptr(mask2), ptr(dst), int(ah), int(aw), stream_ptr(stream)), "urso_conv_pair")
+
+
+def rows_expand2(B, H, W, row_bytes, src, dst, stream=None):
+    """urso_rows_expand2: dst[b, y, x, :] = src[b, y/2, x/2, :] at even (y, x), zero elsewhere."""
+    _chk(_lib.urso_rows_expand2(B, H, W, row_bytes, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rows_expand2")
 
 
 def rows_subsample2(B, H, W, row_bytes, src, dst, stream=None):
