@@ -60,6 +60,7 @@ int         urso_abi_version(void);           /* bumped on any signature change 
  *                     0 never, 1 where its tile count fills the chip evenly (measured policy), 2 wherever it applies
  *   hconv_dbg (0)     kernel-development switches of that kernel; leave 0
  *   c3 (1)            register-resident-filter kernel (conv_c3.hip) for 3x3 stride-1 layers with 64 channels and 64 filters
+ *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
  *                     itself never fuses behind the caller's back)
  */

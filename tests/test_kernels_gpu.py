@@ -251,16 +251,18 @@ def test_igemm_out_f32_and_padded_head(dt):
 
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
-@pytest.mark.parametrize("size", [(2, 32, 48, 0), (2, 128, 160, 8), (4, 512, 640, 0)], ids=["small", "capped", "full"])
+@pytest.mark.parametrize("size", [(2, 32, 48, 0), (3, 36, 44, 0), (2, 128, 160, 8), (4, 512, 640, 0)], ids=["small", "ragged", "capped", "full"])
 def test_stem_pixel_pair_conv(dt, size):
     """conv1: ZeroPadding2D(3)+Conv2D 7x7 s2 (net.py:170-171) as a 7x4-tap conv on pixel pairs,
     forward + weight gradient (no data gradient: the image needs none).  'capped' / 'full': every block of the persistent
-    kernel walks several tiles (grid cap 8 on 80 tiles; 2560 tiles on the production grid)."""
+    kernel walks several tiles (grid cap 8 on 80 tiles; 2560 tiles on the production grid); 'ragged': output sizes that are not multiples
+    of the 8 x 32 tile of conv_stem.hip.  16-bit dtypes run conv_stem.hip (option stem, default) AND the DMA kernel's form (stem = 0)."""
     hip = _hip()
     B, H, W, cap = size
     N = 64
-    with hip.options(grid_cap=cap):
-        _stem_case(hip, dt, B, H, W, N)
+    for stem in ((1, 0) if dt else (1,)):
+        with hip.options(grid_cap=cap, stem=stem):
+            _stem_case(hip, dt, B, H, W, N)
 
 
 def _stem_case(hip, dt, B, H, W, N):

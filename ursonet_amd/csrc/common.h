@@ -28,6 +28,7 @@ struct UrsoOptions {
     int hconv = 1;           // conv_halo.hip (8-wave halo-tile kernel) for qualifying 3x3 layers
     int pair = 1;            // conv_pair.hip: fused pointwise pairs of stages 2-3 (read by the host plan, ursonet_amd/engine.py)
     int c3 = 1;              // conv_c3.hip (register-resident 3x3 filter) for 64-channel / 64-filter 3x3 layers
+    int stem = 1;            // conv_stem.hip (im2col on the LDS read side) for the packed 7x7 stem
     int hconv_dbg = 0;       // kernel-development switches of conv_halo.hip (0 in production)
 };
 extern UrsoOptions g_urso_opt;

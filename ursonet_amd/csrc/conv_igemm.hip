@@ -401,6 +401,8 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
 bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* mask);                                            // conv_pair.hip
 int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
                             void* dst, void* bits_out, hipStream_t st);
+bool urso_stem_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);                                // conv_stem.hip
+int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, void* dst, hipStream_t st);
 bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add);                                                      // conv_c3.hip
 int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* mask,
                    void* dst, hipStream_t st);
@@ -574,6 +576,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool taps_ok = (a.Cc & 7) == 0 && g->DH == 1 && g->DW == 1 && g->KH <= 3 && g->KW <= 3;     // whole-tap K-tiles, undilated, <= 3x3
         // the 7x7/s2 stem as packed by urso_stem_weight_pack: 7 x 4 taps of 8-channel pixel pairs, one tap per 16-byte chunk
         const bool stem_ok = a.Cc == 1 && g->KW == 4 && g->KH <= 8 && g->DH == 1 && g->DW == 1 && g->N <= 64 && !add_d && !mask_d;
+        if (fits && !wants_bits && urso_stem_fits(g, dt, flags, add_d, mask_d))       // the stem: im2col on the LDS read side (conv_stem.hip)
+            return urso_stem_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, dst_d, st);
         if (fits && !wants_bits && use_pw >= 3 && stem_ok)
             return urso_pw_launch(g, dt, 2, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
                                   src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, 0, nullptr, st);
