@@ -33,6 +33,8 @@ struct UrsoOptions {
 };
 extern UrsoOptions g_urso_opt;
 
+#define URSO_REDUCE_COLS 256   // float4 columns per block of the split-reduction kernels (conv_wgrad.hip) = its block size; prep.hip plans with it
+
 // profiler hooks (prof.cpp)
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);
 void urso_prof_after(hipStream_t s);

@@ -614,48 +614,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
     }
 }
 
-// Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block owns 16
-// float4 columns; its 256 threads are 16 columns x 16 split-lanes, each lane accumulating splits
-// sl, sl+16, ... with 4 loads in flight, then the 16 lanes are combined through LDS in lane order.
+// Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic): a thread owns ONE float4 column and adds the splits
+// 0, 1, 2, ... in order, sixteen 16-byte loads in flight; a block's 256 threads read 4 KiB contiguous per partial row.
 __device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ part, float* __restrict__ out, size_t count, int splits,
                                                      size_t pstride /* floats between partial tensors, multiple of 4 */) {
-    // a block owns 64 consecutive float4 columns (1 KiB per partial row); thread (col 0..15, split-lane sl 0..15) owns columns
-    // col, col+16, col+32, col+48 and the splits sl, sl+16, ...: eight 16-byte loads in flight per thread
-    __shared__ f32x4_t red[4][16][17];
-    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const size_t q0 = (size_t)bid * 64 + col;         // first float4 index of this thread
     const size_t nq = (count + 3) / 4;
     const bool vec = (count & 3) == 0;                // otherwise (tiny odd-sized tensors) the scalar tail below does everything
-    f32x4_t s[4][2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) s[c][0] = s[c][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (vec) {
+    const size_t q = (size_t)bid * URSO_REDUCE_COLS + threadIdx.x;
+    if (vec && q < nq) {
         const size_t stride = pstride / 4;
-        const f32x4_t* p = (const f32x4_t*)part;
-        int k = sl;
-        for (; k + 16 < splits; k += 32) {
+        const f32x4_t* p = (const f32x4_t*)part + q;
+        f32x4_t t = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 16 <= splits; k += 16) {
+            f32x4_t v[16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const size_t q = q0 + 16 * c;
-                if (q < nq) { s[c][0] += p[(size_t)k * stride + q]; s[c][1] += p[(size_t)(k + 16) * stride + q]; }
-            }
+            for (int i = 0; i < 16; ++i) v[i] = p[(size_t)(k + i) * stride];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += v[i];
         }
-        if (k < splits) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const size_t q = q0 + 16 * c; if (q < nq) s[c][0] += p[(size_t)k * stride + q]; }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) red[c][sl][col] = s[c][0] + s[c][1];
-    __syncthreads();
-    if (sl < 4) {                                      // split-lane c finishes column group c (fixed order over the 16 lanes)
-        const size_t q = q0 + 16 * sl;
-        if (vec && q < nq) {
-            f32x4_t t = red[sl][0][col];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) t += red[sl][i][col];
-            *((f32x4_t*)out + q) = t;
-        }
+        for (; k < splits; ++k) t += p[(size_t)k * stride];
+        *((f32x4_t*)out + q) = t;
     }
     if (!vec && threadIdx.x == 0 && bid == 0)
         for (size_t e = 0; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * pstride + e]; out[e] = t; }
@@ -670,7 +649,7 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const urso_p
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     const size_t cnt = (size_t)d.K * d.npad;
-    const int nb_dw = (int)(((cnt + 3) / 4 + 63) / 64);
+    const int nb_dw = (int)(((cnt + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS);
     if (local < nb_dw) reduce_partials_body(local, d.part, d.dw_raw, cnt, d.splits, cnt + URSO_WGRAD_PART_PAD);
     else reduce_partials_body(local - nb_dw, d.colpart, d.colsum, (size_t)d.npad, d.splits, (size_t)d.npad);
 }
@@ -784,9 +763,9 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     if (rc != URSO_OK) return rc;
     if (!direct && !keep_partials) {
         size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
-        int blocks = (int)(((cnt + 3) / 4 + 63) / 64);
+        int blocks = (int)(((cnt + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits, cnt + URSO_WGRAD_PART_PAD);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + 63) / 64)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;
