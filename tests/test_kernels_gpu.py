@@ -771,37 +771,49 @@ def test_fused_pointwise_pair_forward_and_backward(dt, shape, c):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
-@pytest.mark.parametrize("variant", ["add_relu_bits", "add_relu", "plain", "relu_only"])
+@pytest.mark.parametrize("c", [64, 128, 256], ids=["stage2", "stage3", "stage4"])
+@pytest.mark.parametrize("variant", ["add_relu_bits", "add_relu", "plain", "relu_only", "add_maskbits"])
 def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
-    """urso_conv_igemm_ex on a c -> 4c pointwise layer (res2c/res3d_branch2c, the stride-1 shortcut conv) runs the single-layer form
-    of conv_pair.hip (option pair, default on): against the CPU fp32 reference, against the DMA kernel (pair = 0) and, for the bit
-    mask, bit for bit against (stored output > 0); grid at production size and capped to 8 blocks (multi-tile stream)."""
+    """urso_conv_igemm_ex on a c -> 4c pointwise layer (res{2c,3d,4x}_branch2c, the stride-1 shortcut conv; stage 4 also the masked data
+    gradient of branch2a: 'add_maskbits') runs the single-layer form of conv_pair.hip (option pair, default on): against the CPU fp32
+    reference, against the DMA kernel (pair = 0) and, for an emitted bit mask, bit for bit against (stored output > 0); grid at
+    production size and capped to 8 blocks (multi-tile stream; stage 4: two block groups of 512 filters)."""
     hip = _hip()
+    if variant == "add_maskbits" and c != 256:
+        pytest.skip("stages 2-3 run that layer inside the fused backward pair")
     B, H, W = 3, 40, 48
     M = B * H * W
     tdt = hip.TORCH_DT[dt]
     torch.manual_seed(c + dt)
     x = dev(torch.randn(B, H, W, c), dt)
     w = torch.randn(1, 1, c, 4 * c) / c ** 0.5
+    mb = variant == "add_maskbits"
     wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(4 * c) * 0.2)
+    if mb:
+        biasf = None
     add = dev(torch.randn(B, H, W, 4 * c), dt) if variant.startswith("add") else None
-    relu = variant != "plain"
-    bits = torch.full((M * 4 * c // 8,), 0x55, dtype=torch.uint8, device="cuda") if variant.endswith("bits") else None
-    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_EMIT_BITS if bits is not None else 0)
+    relu = variant not in ("plain", "add_maskbits")
+    bits = torch.full((M * 4 * c // 8,), 0x55, dtype=torch.uint8, device="cuda") if variant.endswith("_bits") else None
+    mask = torch.randint(0, 256, (M * 4 * c // 8,), dtype=torch.uint8, device="cuda") if mb else None
+    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_EMIT_BITS if bits is not None else 0) | (hip.EPI_MASK_BITS if mb else 0)
     g = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1)
-    ref = x.float().cpu().reshape(M, c) @ wf.float().cpu().reshape(4 * c, c).T + biasf.cpu()
+    ref = x.float().cpu().reshape(M, c) @ wf.float().cpu().reshape(4 * c, c).T
+    if biasf is not None:
+        ref = ref + biasf.cpu()
     if add is not None:
         ref = ref + add.float().cpu().reshape(M, 4 * c)
     if relu:
         ref = torch.relu(ref)
+    if mb:
+        keep = ((mask.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, 4 * c).float()
+        ref = ref * keep
     outs = {}
     for pair, cap in ((1, 0), (1, 8), (0, 0)):
         y = torch.full((B, H, W, 4 * c), 5.0, device="cuda").to(tdt)
         if bits is not None:
             bits.fill_(0x55)
         with hip.options(pair=pair, grid_cap=cap):
-            hip.conv_igemm_ex(g, dt, flags, x, wf, biasf, add, None, y, bits)
+            hip.conv_igemm_ex(g, dt, flags, x, wf, biasf, add, mask, y, bits)
         torch.cuda.synchronize()
         assert relerr(y.reshape(M, 4 * c), ref) < (1.2e-2 if dt == 1 else 1.5e-3)
         if bits is not None:

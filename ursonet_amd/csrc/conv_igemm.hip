@@ -398,9 +398,9 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
                    uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st);      // conv_pw.hip
 
-bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* mask);                                            // conv_pair.hip
-int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
-                            void* dst, void* bits_out, hipStream_t st);
+bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);                         // conv_pair.hip
+int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
+                            const void* mask_bits, void* dst, void* bits_out, hipStream_t st);
 bool urso_stem_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);                                // conv_stem.hip
 int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, void* dst, hipStream_t st);
 bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add);                                                      // conv_c3.hip
@@ -563,8 +563,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool fits = dt != URSO_F32 && !(flags & URSO_EPI_OUT_F32) && bits_fit && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
         // 3x3 / stride-1 layers with >= 128 filters: the 8-wave halo-tile kernel (conv_halo.hip)
-        if (fits && urso_pair_single_fits(g, dt, flags, mask_d))      // c -> 4c pointwise layers of stages 2-3: filters in registers (conv_pair.hip)
-            return urso_pair_single_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, add_d, dst_d,
+        if (fits && urso_pair_single_fits(g, dt, flags, add_d, mask_d))   // wide pointwise layers of stages 2-4: filters in registers (conv_pair.hip)
+            return urso_pair_single_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d,
                                            (flags & URSO_EPI_EMIT_BITS) ? bits_out_d : nullptr, st);
         if (fits && urso_c3_fits(g, dt, flags, add_d))                // 3x3 with 64 channels and filters: filter in registers (conv_c3.hip)
             return urso_c3_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, mask_d, dst_d, st);

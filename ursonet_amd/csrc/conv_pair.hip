@@ -34,6 +34,9 @@ struct PairArgs {
     // SPARSE add (backward pair behind a stride-2 stage entry): `add` is the COMPACT gradient [B][sp_h/2][sp_w/2][CW] of a dense
     // [B][sp_h][sp_w] pixel grid whose odd rows and columns are zero (only every second pixel of every second row fed the next stage)
     int sp_h, sp_w; uint32_t add_bytes; float rcp_hw, rcp_w;
+    // wide tensors whose rows are longer than the tile (stage-4 single layers: 512 of the 1024 channels per block group = blockIdx.y):
+    // bytes per pixel row of add / mid and of the bit mask in memory, and what one group index adds to each pointer
+    uint32_t wide_pitch, bits_pitch, g_w1, g_bias, g_wide, g_bits;
 };
 
 template <typename T> struct PrMma32;
@@ -63,18 +66,21 @@ __device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 //   stage 2:  CM  64, CW 256, 4 waves, 64-pixel tiles, 2 LDS stages ( 80 KiB): two blocks per CU, inputs one tile ahead;
 //   stage 3:  CM 128, CW 512, 8 waves, 32-pixel tiles, 3 LDS stages (120 KiB): one block per CU (the filters take 128 VGPRs per lane,
 //             so only 8 waves fit), inputs TWO tiles ahead to keep the same ~80 KiB per CU in flight.
-template <int CM_, int NW_, int BM_, int NBUF_> struct PairShape {
-    static constexpr int CM = CM_, CW = 4 * CM_, NW = NW_, BM = BM_, NBUF = NBUF_, D = NBUF_ - 1;
+template <int CM_, int NW_, int BM_, int NBUF_, int CW_ = 4 * CM_> struct PairShape {
+    static constexpr int CM = CM_, CW = CW_, NW = NW_, BM = BM_, NBUF = NBUF_, D = NBUF_ - 1;
     static constexpr int AROW = CM * 2, RROW = CW * 2, BROW = CW / 8;         // bytes per pixel: narrow row, wide row, bit-mask row
     static constexpr int ABUF = BM * AROW, RBUF = BM * RROW, ROFF = NBUF * ABUF, LDS = NBUF * (ABUF + RBUF);
     static constexpr int NA = ABUF / (1024 * NW), NR = RBUF / (1024 * NW);     // DMA instructions per lane and tile
     static constexpr int PT1 = BM / 32, KS1 = CM / 16, PT2 = BM / 16, KS2 = CW / 32;
-    static_assert(CW / NW == 64 && CM / NW == 16 && NA >= 1 && NR >= 1 && PT1 >= 1, "wave roles");
-    // 16-byte slot swizzle of a narrow row: 128-byte rows pair up per 256-byte bank row, 256-byte rows fill one each
+    static_assert(CW / NW == 64 && NA >= 1 && NR >= 1 && PT1 >= 1, "wave roles");
+    // 16-byte slot swizzle of a narrow row: 128-byte rows pair up per 256-byte bank row, longer rows fill whole bank rows
     static __device__ __forceinline__ int aswz(int row) { return AROW == 128 ? ((row >> 1) & 7) : (row & 15); }
 };
 using PairS2 = PairShape<64, 4, 64, 2>;
 using PairS3 = PairShape<128, 8, 32, 3>;
+//   stage 4 (single layers only: 256 -> 1024 in two block groups of 512 filters): CM 256, 8 waves x 64 filters x 256 = 128 VGPRs of
+//             filter per lane, 32-pixel tiles, 3 LDS stages (144 KiB), one block per CU
+using PairS4 = PairShape<256, 8, 32, 3, 512>;
 
 // MODE 0 forward pair, 1 backward pair.  EMIT: forward also writes the ReLU bit mask of `mid`.
 // VAR 0: the pair.  VAR 1 / 2: ONLY the first layer (c -> 4c pointwise, MODE 0) with / without a residual operand -- the same input
@@ -84,8 +90,9 @@ template <typename T, int MODE, bool EMIT, typename S, int VAR, bool SPARSE = fa
 __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     static_assert(!SPARSE || (MODE == 1 && VAR == 0), "sparse add: backward pair only");
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    static_assert(VAR == 0 || MODE == 0, "single-layer variants are forward-form only");
     constexpr bool G2 = VAR == 0, HAS_ADD = VAR != 2;
+    static_assert(!G2 || (S::CM / S::NW == 16 && S::CW == 4 * S::CM), "pair: every wave owns 16 of the CM output channels of GEMM 2");
+    static_assert(VAR != 2 || MODE == 0, "the form without a residual operand is forward-only");
     constexpr int BM = S::BM, CM = S::CM, CW = S::CW, NW = S::NW, AROW = S::AROW, RROW = S::RROW, BROW = S::BROW;
     constexpr int NA = S::NA, NR = S::NR, PT1 = S::PT1, KS1 = S::KS1, PT2 = S::PT2, KS2 = S::KS2, D = S::D, NBUF = S::NBUF;
     __shared__ __attribute__((aligned(1024))) char smem[S::LDS];
@@ -100,9 +107,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     int tile = xcd * cpx + lb;
     if (tile >= t_end) return;
 
-    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc(a.add, SPARSE ? a.add_bytes : a.wide_bytes);
-    const __amdgpu_buffer_rsrc_t rmid = make_rsrc(a.mid, a.wide_bytes), rdst = make_rsrc(a.dst, a.nar_bytes);
-    const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? a.bits : a.mid, a.bits ? a.bits_bytes : 0u);
+    const uint32_t grp = blockIdx.y, gwide = grp * a.g_wide, gbits = grp * a.g_bits;
+    const uint32_t pitch = a.wide_pitch, bpitch = a.bits_pitch;
+    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc((const char*)a.add + gwide, (SPARSE ? a.add_bytes : a.wide_bytes) - gwide);
+    const __amdgpu_buffer_rsrc_t rmid = make_rsrc((char*)a.mid + gwide, a.wide_bytes - gwide), rdst = make_rsrc(a.dst, a.nar_bytes);
+    const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? (char*)a.bits + gbits : (char*)a.mid, a.bits ? a.bits_bytes - gbits : 0u);
     const __amdgpu_buffer_rsrc_t rmk2 = make_rsrc(MODE == 1 ? a.mask2 : a.dst, MODE == 1 ? a.nar_bytes : 0u);
 
     // ---- per-thread tile-relative byte offsets: instruction i of a wave moves 1024 contiguous LDS bytes (row-major rows of the tile);
@@ -118,13 +127,16 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         const int row = (1024 / RROW) * (wave + NW * i) + lane / (RROW / 16), p = lane % (RROW / 16);
         roff[i] = (uint32_t)(row * RROW + ((p ^ (row & 15)) << 4));
     }
+    uint32_t rgo[NR];                                          // the same vectors in memory: row pitch of the tensor, not of the tile
+#pragma unroll
+    for (int i = 0; i < NR; ++i) rgo[i] = (roff[i] / (uint32_t)RROW) * pitch + (roff[i] & (uint32_t)(RROW - 1));
     auto dma_tile = [&](int t, int buf) {
-        const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)(BM * RROW);
+        const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)BM * pitch;
 #pragma unroll
         for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
         if constexpr (HAS_ADD && !SPARSE) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + roff[i]);
+            for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + rgo[i]);
         }
         if constexpr (SPARSE) {
             // row -> pixel (b, y, x) of the dense grid; odd y or x: the gradient is zero there (out-of-range offset = zero fill),
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
             for (int j = 0; j < KS1; ++j)
-                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(64 * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
+                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + (size_t)grp * a.g_w1 + ((size_t)(64 * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
         // GEMM 2 row operand (16x16x32): row l15 of the wave's 16 output channels, k = 32 j + 8 g
         if constexpr (G2) {
 #pragma unroll
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[64 * wave + 32 * c2 + 16 * h + r] : 0.f;
+            for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[grp * a.g_bias + 64 * wave + 32 * c2 + 16 * h + r] : 0.f;
         if constexpr (G2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) b2[r] = a.bias2 ? a.bias2[16 * wave + 4 * g + r] : 0.f;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         e2[pt] = (uint32_t)(row * AROW + ((slot ^ S::aswz(row)) << 4) + 8 * (g & 1));
     }
     // bit-mask bytes of a pixel's 64 channels owned by this wave: [pixel][CW / 8] bytes, bytes 8 wave .. 8 wave + 7
-    const uint32_t bitoff = (uint32_t)(l31 * BROW + 8 * wave);
+    const uint32_t bitoff = (uint32_t)l31 * bpitch + 8u * wave;
 
     // vector-memory operations a tile issues after its requests for later tiles: the stores
     constexpr int NST = NR + (G2 ? NA : 0) + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
@@ -209,9 +221,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt)
-                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (uint32_t)(BM * BROW) + pt * 32u * BROW + bitoff, 0, 0));
+                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff, 0, 0));
+            if constexpr (G2) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (uint32_t)(BM * AROW) + aoff[i]);
+                for (int i = 0; i < NA; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (uint32_t)(BM * AROW) + aoff[i]);
+            }
         }
     };
 
@@ -237,8 +251,10 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < PT1; ++i) { cbits[i] = pbits[i]; asm volatile("" : "+v"(cbits[i])); }   // pin the consumption of the prefetched
+            if constexpr (G2) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { cm2[i] = pm2[i]; asm volatile("" : "+v"(cm2[i])); }           // vectors HERE, ahead of the new requests
+                for (int i = 0; i < NA; ++i) { cm2[i] = pm2[i]; asm volatile("" : "+v"(cm2[i])); }       // vectors HERE, ahead of the new requests
+            }
         }
         if (has_next) prefetch(tile + bpx);
         if (has_far) { int nb_ = buf + D; if (nb_ >= NBUF) nb_ -= NBUF; dma_tile(tile + D * bpx, nb_); }
@@ -300,18 +316,18 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
                 const uint32_t o0 = (uint32_t)__shfl_xor((int)keep[0], 32, 64), o1 = (uint32_t)__shfl_xor((int)keep[1], 32, 64);
                 const i32x2_t pk = i32x2_t{(int)(keep[0] | (o0 << 16)), (int)(keep[1] | (o1 << 16))};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, pk), rbit,
-                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (uint32_t)(BM * BROW) + pt * 32u * BROW + bitoff, 0, 0);
+                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff, 0, 0);
             }
         }
         pr_barrier();                                           // (2) mid complete in LDS
         // ---- mid -> HBM, row-contiguous (same slot map as the DMA that brought the add tile in)
         {
-            const uint32_t wb = (uint32_t)tile * (uint32_t)(BM * RROW);
+            const uint32_t wb = (uint32_t)tile * (uint32_t)BM * pitch;
             i32x4_t v[NR];
 #pragma unroll
             for (int i = 0; i < NR; ++i) v[i] = *(const i32x4_t*)(sR + (wave + NW * i) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + roff[i], v[i]);
+            for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + rgo[i], v[i]);
         }
         if constexpr (!G2) {
             if (!has_next) break;
@@ -387,12 +403,13 @@ extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) 
 }
 
 template <typename S, int VAR>
-static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st, bool sparse = false) {
+static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks_per_cu, hipStream_t st, bool sparse = false, int groups = 1) {
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = blocks_per_cu * pr_device_cus() / 8;
+    int cap = blocks_per_cu * pr_device_cus() / (8 * groups);
+    if (cap < 1) cap = 1;
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
-    const dim3 grid(8 * bpx), blk(S::NW * 64);
+    const dim3 grid(8 * bpx, groups), blk(S::NW * 64);
     if constexpr (VAR == 0) {
         if (sparse && mode == 1) {
             if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0, true>), grid, blk, 0, st, a);
@@ -407,7 +424,12 @@ static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks
             else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, 0>), grid, blk, 0, st, a);
         }
     } else {
-        if (dt == URSO_BF16) {
+        if (mode == 1) {                                     // add + bit-mask form of a single layer (VAR 1 only)
+            if constexpr (VAR == 1) {
+                if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 1>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 1>), grid, blk, 0, st, a);
+            }
+        } else if (dt == URSO_BF16) {
             if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR>), grid, blk, 0, st, a);
             else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR>), grid, blk, 0, st, a);
         } else {
@@ -417,27 +439,45 @@ static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks
     }
 }
 
-// The first layer alone (conv_igemm.hip dispatches here): dst[M][4c] = act(src[M][c] W^T + bias (+ add)), optional ReLU bit mask.
-bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* mask) {
-    if (!g_urso_opt.pair || mask || (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS))) return false;
-    if (g->KH != 1 || g->KW != 1 || g->SH != 1 || g->SW != 1 || g->PH || g->PW || g->DH != 1 || g->DW != 1 || g->FH > 0 || g->N != 4 * g->C ||
+// A single c -> N pointwise layer (conv_igemm.hip dispatches here): dst[M][N] = act(src[M][c] W^T + bias (+ add)), optional ReLU bit
+// mask out; or, with a bit mask IN (URSO_EPI_MASK_BITS, the data gradient into a block output): dst = (src W^T + add) where the bit is set.
+// Shapes: c = 64 / 128 with N = 4c (stages 2-3), c = 256 with N a multiple of 512 (stage 4: block groups of 512 filters).
+bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask) {
+    if (!g_urso_opt.pair || (flags & URSO_EPI_OUT_F32) || (dt != URSO_BF16 && dt != URSO_F16)) return false;
+    const bool mbits = (flags & URSO_EPI_MASK_BITS) != 0;
+    if (mask && !mbits) return false;                         // a 16-bit mask tensor: not here
+    if (mbits && (!mask || !add || (flags & (URSO_EPI_EMIT_BITS | URSO_EPI_RELU)))) return false;
+    if (g->KH != 1 || g->KW != 1 || g->SH != 1 || g->SW != 1 || g->PH || g->PW || g->DH != 1 || g->DW != 1 || g->FH > 0 ||
         g->OH != g->H || g->OW != g->W) return false;
-    return urso_conv_pair_ok((long long)g->B * g->OH * g->OW, dt, g->C, g->N) != 0;
+    const long long M = (long long)g->B * g->OH * g->OW;
+    if (M <= 0 || M * g->N * 2 >= 0x7FFFFF00ll) return false;
+    if (g->C == PairS4::CM) return g->N >= PairS4::CW && g->N % PairS4::CW == 0 && M % PairS4::BM == 0;
+    if (mbits) return false;                                  // stages 2-3 run that layer inside the fused backward pair
+    return g->N == 4 * g->C && urso_conv_pair_ok(M, dt, g->C, g->N) != 0;
 }
-int urso_pair_single_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
-                            void* dst, void* bits_out, hipStream_t st) {
+int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
+                            const void* mask_bits, void* dst, void* bits_out, hipStream_t st) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const int cm = g->C, cw = g->N;
+    const int mode = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;
     PairArgs a;
-    a.src = src; a.w1 = wgt; a.bias1 = bias; a.add = add ? add : dst; a.bits = bits_out; a.mid = dst; a.w2 = nullptr; a.bias2 = nullptr;
-    a.mask2 = nullptr; a.dst = dst; a.relu1 = relu; a.sp_h = a.sp_w = 0; a.add_bytes = 0; a.rcp_hw = a.rcp_w = 0.f;
+    a.src = src; a.w1 = wgt; a.bias1 = bias; a.add = add ? add : dst; a.bits = mode ? const_cast<void*>(mask_bits) : bits_out; a.mid = dst;
+    a.w2 = nullptr; a.bias2 = nullptr; a.mask2 = nullptr; a.dst = dst; a.relu1 = (flags & URSO_EPI_RELU) ? 1 : 0;
+    a.sp_h = a.sp_w = 0; a.add_bytes = 0; a.rcp_hw = a.rcp_w = 0.f;
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
-    if (cm == PairS2::CM) {
+    a.wide_pitch = (uint32_t)cw * 2u; a.bits_pitch = (uint32_t)cw / 8u; a.g_w1 = a.g_bias = a.g_wide = a.g_bits = 0;
+    const bool emit = !mode && bits_out != nullptr;
+    if (cm == PairS4::CM) {
+        const int groups = cw / PairS4::CW;
+        a.g_w1 = (uint32_t)PairS4::CW * cm * 2u; a.g_bias = PairS4::CW; a.g_wide = PairS4::CW * 2u; a.g_bits = PairS4::CW / 8u;
+        a.ntiles = (int)(M / PairS4::BM);
+        if (add) pr_launch<PairS4, 1>(a, dt, mode, emit, 1, st, false, groups); else pr_launch<PairS4, 2>(a, dt, 0, emit, 1, st, false, groups);
+    } else if (cm == PairS2::CM) {
         a.ntiles = (int)(M / PairS2::BM);
-        if (add) pr_launch<PairS2, 1>(a, dt, 0, bits_out != nullptr, 2, st); else pr_launch<PairS2, 2>(a, dt, 0, bits_out != nullptr, 2, st);
+        if (add) pr_launch<PairS2, 1>(a, dt, 0, emit, 2, st); else pr_launch<PairS2, 2>(a, dt, 0, emit, 2, st);
     } else {
         a.ntiles = (int)(M / PairS3::BM);
-        if (add) pr_launch<PairS3, 1>(a, dt, 0, bits_out != nullptr, 1, st); else pr_launch<PairS3, 2>(a, dt, 0, bits_out != nullptr, 1, st);
+        if (add) pr_launch<PairS3, 1>(a, dt, 0, emit, 1, st); else pr_launch<PairS3, 2>(a, dt, 0, emit, 1, st);
     }
     return urso_check_launch("urso_conv_igemm(wide pointwise)");
 }
@@ -464,6 +504,7 @@ extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const
     a.src = src_d; a.w1 = w1_d; a.bias1 = bias1_d; a.add = add_d; a.bits = bits_d; a.mid = mid_d; a.w2 = w2_d; a.bias2 = bias2_d;
     a.mask2 = mask2_d; a.dst = dst_d; a.relu1 = 1;
     a.sp_h = add_h; a.sp_w = add_w; a.add_bytes = (uint32_t)(M / 4 * cw * 2);
+    a.wide_pitch = (uint32_t)cw * 2u; a.bits_pitch = (uint32_t)cw / 8u; a.g_w1 = a.g_bias = a.g_wide = a.g_bits = 0;
     a.rcp_hw = sparse ? 1.0f / (float)(add_h * add_w) : 0.f; a.rcp_w = sparse ? 1.0f / (float)add_w : 0.f;
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
     const double flops = 2.0 * (double)M * cm * cw * 2.0;
