@@ -771,17 +771,17 @@ def test_fused_pointwise_pair_forward_and_backward(dt, shape, c):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("c", [64, 128, 256], ids=["stage2", "stage3", "stage4"])
+@pytest.mark.parametrize("c", [64, 128, 256, 512], ids=["stage2", "stage3", "stage4", "stage5"])
 @pytest.mark.parametrize("variant", ["add_relu_bits", "add_relu", "plain", "relu_only", "add_maskbits"])
 def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
     """urso_conv_igemm_ex on a c -> 4c pointwise layer (res{2c,3d,4x}_branch2c, the stride-1 shortcut conv; stage 4 also the masked data
     gradient of branch2a: 'add_maskbits') runs the single-layer form of conv_pair.hip (option pair, default on): against the CPU fp32
     reference, against the DMA kernel (pair = 0) and, for an emitted bit mask, bit for bit against (stored output > 0); grid at
-    production size and capped to 8 blocks (multi-tile stream; stage 4: two block groups of 512 filters)."""
+    production size and capped to 8 blocks (multi-tile stream; stage 4 / 5: two / eight block groups of 512 / 256 filters)."""
     hip = _hip()
-    if variant == "add_maskbits" and c != 256:
+    if variant == "add_maskbits" and c < 256:
         pytest.skip("stages 2-3 run that layer inside the fused backward pair")
-    B, H, W = 3, 40, 48
+    B, H, W = (3, 40, 48) if c < 512 else (2, 16, 24)
     M = B * H * W
     tdt = hip.TORCH_DT[dt]
     torch.manual_seed(c + dt)

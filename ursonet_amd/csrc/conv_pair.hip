@@ -72,7 +72,8 @@ template <int CM_, int NW_, int BM_, int NBUF_, int CW_ = 4 * CM_> struct PairSh
     static constexpr int ABUF = BM * AROW, RBUF = BM * RROW, ROFF = NBUF * ABUF, LDS = NBUF * (ABUF + RBUF);
     static constexpr int NA = ABUF / (1024 * NW), NR = RBUF / (1024 * NW);     // DMA instructions per lane and tile
     static constexpr int PT1 = BM / 32, KS1 = CM / 16, PT2 = BM / 16, KS2 = CW / 32;
-    static_assert(CW / NW == 64 && NA >= 1 && NR >= 1 && PT1 >= 1, "wave roles");
+    static constexpr int C2T = CW / (32 * NW);                                  // 32-filter sub-tiles of GEMM 1 per wave: 2, or 1 (stage 5)
+    static_assert((C2T == 1 || C2T == 2) && CW == 32 * C2T * NW && NA >= 1 && NR >= 1 && PT1 >= 1, "wave roles");
     // 16-byte slot swizzle of a narrow row: 128-byte rows pair up per 256-byte bank row, longer rows fill whole bank rows
     static __device__ __forceinline__ int aswz(int row) { return AROW == 128 ? ((row >> 1) & 7) : (row & 15); }
 };
@@ -81,6 +82,8 @@ using PairS3 = PairShape<128, 8, 32, 3>;
 //   stage 4 (single layers only: 256 -> 1024 in two block groups of 512 filters): CM 256, 8 waves x 64 filters x 256 = 128 VGPRs of
 //             filter per lane, 32-pixel tiles, 3 LDS stages (144 KiB), one block per CU
 using PairS4 = PairShape<256, 8, 32, 3, 512>;
+//   stage 5 (single layers only: 512 -> 2048 in eight block groups of 256 filters): CM 512, 8 waves x 32 filters x 512 = 128 VGPRs
+using PairS5 = PairShape<512, 8, 32, 3, 256>;
 
 // MODE 0 forward pair, 1 backward pair.  EMIT: forward also writes the ReLU bit mask of `mid`.
 // VAR 0: the pair.  VAR 1 / 2: ONLY the first layer (c -> 4c pointwise, MODE 0) with / without a residual operand -- the same input
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     static_assert(!G2 || (S::CM / S::NW == 16 && S::CW == 4 * S::CM), "pair: every wave owns 16 of the CM output channels of GEMM 2");
     static_assert(VAR != 2 || MODE == 0, "the form without a residual operand is forward-only");
     constexpr int BM = S::BM, CM = S::CM, CW = S::CW, NW = S::NW, AROW = S::AROW, RROW = S::RROW, BROW = S::BROW;
-    constexpr int NA = S::NA, NR = S::NR, PT1 = S::PT1, KS1 = S::KS1, PT2 = S::PT2, KS2 = S::KS2, D = S::D, NBUF = S::NBUF;
+    constexpr int NA = S::NA, NR = S::NR, PT1 = S::PT1, KS1 = S::KS1, PT2 = S::PT2, KS2 = S::KS2, D = S::D, NBUF = S::NBUF, C2T = S::C2T;
+    static_assert(!G2 || C2T == 2, "pair: every wave owns 64 of the wide channels");
     __shared__ __attribute__((aligned(1024))) char smem[S::LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,14 +163,14 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 
     // ---- filters -> registers.  GEMM 1 row operand: MFMA row rho = e + 8 q + 4 hh of the wave's 32-channel sub-tile c2 holds logical
     //      channel 16 hh + 4 q + e, so that a lane's 16 accumulators are channels 16 h .. 16 h + 15 (one pixel, 32 contiguous bytes).
-    i32x4_t w1f[2][KS1], w2f[KS2];
+    i32x4_t w1f[C2T][KS1], w2f[KS2];
     {
         const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+        for (int c2 = 0; c2 < C2T; ++c2)
 #pragma unroll
             for (int j = 0; j < KS1; ++j)
-                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + (size_t)grp * a.g_w1 + ((size_t)(64 * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
+                w1f[c2][j] = *(const i32x4_t*)((const char*)a.w1 + (size_t)grp * a.g_w1 + ((size_t)(32 * C2T * wave + 32 * c2 + lg) * CM + 16 * j + 8 * h) * 2);
         // GEMM 2 row operand (16x16x32): row l15 of the wave's 16 output channels, k = 32 j + 8 g
         if constexpr (G2) {
 #pragma unroll
@@ -174,12 +178,12 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
                 w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * wave + l15) * CW + 32 * j + 8 * g) * 2);
         }
     }
-    float b1[2][16], b2[4];
+    float b1[C2T][16], b2[4];
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+        for (int c2 = 0; c2 < C2T; ++c2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[grp * a.g_bias + 64 * wave + 32 * c2 + 16 * h + r] : 0.f;
+            for (int r = 0; r < 16; ++r) b1[c2][r] = a.bias1 ? a.bias1[grp * a.g_bias + 32 * C2T * wave + 32 * c2 + 16 * h + r] : 0.f;
         if constexpr (G2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) b2[r] = a.bias2 ? a.bias2[16 * wave + 4 * g + r] : 0.f;
@@ -194,12 +198,12 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         g1rd[pt][0] = (uint32_t)(row * AROW);                  // + ((2 j + h) ^ swz) << 4, formed per k-step (constant folding keeps it cheap)
         g1rd[pt][1] = (uint32_t)S::aswz(row);
     }
-    uint32_t e1[PT1][2];                                       // epilogue 1: add/mid row 32 pt + l31, slots 8 wave + 4 c2 + 2 h (+1: ^ 16)
+    uint32_t e1[PT1][C2T];                                     // epilogue 1: add/mid row 32 pt + l31, slots 4 C2T wave + 4 c2 + 2 h (+1: ^ 16)
 #pragma unroll
     for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-            e1[pt][c2] = (uint32_t)((32 * pt + l31) * RROW + (((8 * wave + 4 * c2 + 2 * h) ^ (l31 & 15)) << 4));
+        for (int c2 = 0; c2 < C2T; ++c2)
+            e1[pt][c2] = (uint32_t)((32 * pt + l31) * RROW + (((4 * C2T * wave + 4 * c2 + 2 * h) ^ (l31 & 15)) << 4));
     uint32_t g2rd[PT2];                                        // GEMM 2 pixel operand: mid row 16 pt + l15, slot 4 j + g  ->  g2rd[pt] ^ (j << 6)
 #pragma unroll
     for (int pt = 0; pt < PT2; ++pt) g2rd[pt] = (uint32_t)((16 * pt + l15) * RROW + ((g ^ l15) << 4));
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         e2[pt] = (uint32_t)(row * AROW + ((slot ^ S::aswz(row)) << 4) + 8 * (g & 1));
     }
     // bit-mask bytes of a pixel's 64 channels owned by this wave: [pixel][CW / 8] bytes, bytes 8 wave .. 8 wave + 7
-    const uint32_t bitoff = (uint32_t)l31 * bpitch + 8u * wave;
+    const uint32_t bitoff = (uint32_t)l31 * bpitch + 4u * C2T * wave;     // the wave's 32 C2T channels = 4 C2T mask bytes per pixel
 
     // vector-memory operations a tile issues after its requests for later tiles: the stores
     constexpr int NST = NR + (G2 ? NA : 0) + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
@@ -221,7 +225,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt)
-                pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, (uint32_t)t * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff, 0, 0));
+            {
+                const uint32_t bo = (uint32_t)t * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff;
+                if constexpr (C2T == 2) pbits[pt] = __builtin_bit_cast(i32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rbit, bo, 0, 0));
+                else pbits[pt] = i32x2_t{(int)__builtin_amdgcn_raw_buffer_load_b32(rbit, bo, 0, 0), 0};
+            }
             if constexpr (G2) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) pm2[i] = buf_load16(rmk2, (uint32_t)t * (uint32_t)(BM * AROW) + aoff[i]);
@@ -262,11 +270,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         char* sR = smem + S::ROFF + buf * S::RBUF;
 
         // ---- GEMM 1: [BM px] x [wave's 64 channels], K = CM
-        f32x16_t acc[PT1][2];
+        f32x16_t acc[PT1][C2T];
 #pragma unroll
         for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
+            for (int c2 = 0; c2 < C2T; ++c2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pt][c2][r] = (MODE == 0) ? b1[c2][r] : 0.f;
 #pragma unroll
@@ -277,14 +285,14 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) PrMma32<T>::run(w1f[c2][j], px[pt], acc[pt][c2]);
+                for (int c2 = 0; c2 < C2T; ++c2) PrMma32<T>::run(w1f[c2][j], px[pt], acc[pt][c2]);
         }
         // ---- epilogue 1, in place in the add tile: mid = act(acc + add)
 #pragma unroll
         for (int pt = 0; pt < PT1; ++pt) {
-            uint32_t keep[2];
+            uint32_t keep[2] = {0u, 0u};
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
+            for (int c2 = 0; c2 < C2T; ++c2) {
                 i32x4_t rv[2];
                 if constexpr (HAS_ADD) {
                     rv[0] = *(const i32x4_t*)(sR + e1[pt][c2]);
@@ -315,8 +323,9 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
                 // the pixel's 64 channels of this wave = 8 bytes: [c2 = 0: h = 0 | h = 1][c2 = 1: h = 0 | h = 1]; lane h = 0 stores them
                 const uint32_t o0 = (uint32_t)__shfl_xor((int)keep[0], 32, 64), o1 = (uint32_t)__shfl_xor((int)keep[1], 32, 64);
                 const i32x2_t pk = i32x2_t{(int)(keep[0] | (o0 << 16)), (int)(keep[1] | (o1 << 16))};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, pk), rbit,
-                                                      h ? URSO_OOB_SHIFT : (uint32_t)tile * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff, 0, 0);
+                const uint32_t bo = h ? URSO_OOB_SHIFT : (uint32_t)tile * (uint32_t)BM * bpitch + pt * 32u * bpitch + bitoff;
+                if constexpr (C2T == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, pk), rbit, bo, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(pk.x, rbit, bo, 0, 0);
             }
         }
         pr_barrier();                                           // (2) mid complete in LDS
@@ -452,6 +461,7 @@ bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const voi
     const long long M = (long long)g->B * g->OH * g->OW;
     if (M <= 0 || M * g->N * 2 >= 0x7FFFFF00ll) return false;
     if (g->C == PairS4::CM) return g->N >= PairS4::CW && g->N % PairS4::CW == 0 && M % PairS4::BM == 0;
+    if (g->C == PairS5::CM) return g->N >= PairS5::CW && g->N % PairS5::CW == 0 && M % PairS5::BM == 0;
     if (mbits) return false;                                  // stages 2-3 run that layer inside the fused backward pair
     return g->N == 4 * g->C && urso_conv_pair_ok(M, dt, g->C, g->N) != 0;
 }
@@ -472,6 +482,11 @@ int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const vo
         a.g_w1 = (uint32_t)PairS4::CW * cm * 2u; a.g_bias = PairS4::CW; a.g_wide = PairS4::CW * 2u; a.g_bits = PairS4::CW / 8u;
         a.ntiles = (int)(M / PairS4::BM);
         if (add) pr_launch<PairS4, 1>(a, dt, mode, emit, 1, st, false, groups); else pr_launch<PairS4, 2>(a, dt, 0, emit, 1, st, false, groups);
+    } else if (cm == PairS5::CM) {
+        const int groups = cw / PairS5::CW;
+        a.g_w1 = (uint32_t)PairS5::CW * cm * 2u; a.g_bias = PairS5::CW; a.g_wide = PairS5::CW * 2u; a.g_bits = PairS5::CW / 8u;
+        a.ntiles = (int)(M / PairS5::BM);
+        if (add) pr_launch<PairS5, 1>(a, dt, mode, emit, 1, st, false, groups); else pr_launch<PairS5, 2>(a, dt, 0, emit, 1, st, false, groups);
     } else if (cm == PairS2::CM) {
         a.ntiles = (int)(M / PairS2::BM);
         if (add) pr_launch<PairS2, 1>(a, dt, 0, emit, 2, st); else pr_launch<PairS2, 2>(a, dt, 0, emit, 2, st);
