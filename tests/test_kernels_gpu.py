@@ -174,6 +174,8 @@ BIG_CASES = [
     (8, 64, 80, 128, 128, 3, 1, (1, 1), "big_3x3_128"),           # res3x_branch2b
     (16, 32, 40, 256, 256, 3, 1, (1, 1), "big_3x3_256"),          # res4x_branch2b
     (16, 32, 40, 1024, 256, 1, 1, (0, 0), "big_1x1_1024_256"),    # res4x_branch2a / dgrad of branch2c
+    (16, 64, 80, 128, 512, 1, 1, (0, 0), "big_1x1_128_512"),      # res3x_branch2c: stage-3 shapes of conv_pair.hip / conv_pwgrad.hip
+    (16, 64, 80, 512, 128, 1, 1, (0, 0), "big_1x1_512_128"),      # res3x_branch2a
 ]
 CAP_CASES = [
     (2, 32, 40, 64, 256, 1, 1, (0, 0), "cap_1x1_64_256"),
