@@ -348,3 +348,22 @@ def test_bench_uses_oracle_only_in_cpu_baseline():
     uses = [m.start() for m in re.finditer(r"from oracle", src)]
     i0 = src.index("def cpu_baseline"); i1 = src.index("def main")
     assert uses and all(i0 < u < i1 for u in uses)
+
+
+def test_c_abi_header_is_plain_c99(tmp_path):
+    """include/ursonet_hip.h is the boundary for non-Python hosts: it must compile as strict C99 (no C++ or HIP types), and a C
+    translation unit that takes the address of every declared entry point must compile against it."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = open(os.path.join(ROOT, "include", "ursonet_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(urso_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 58
+    src = tmp_path / "abi.c"
+    src.write_text('#include "ursonet_hip.h"\n#include <stddef.h>\ntypedef void (*fn)(void);\nfn table[] = {\n' +
+                   "".join("    (fn)%s,\n" % n for n in names) + "};\nsize_t count(void) { return sizeof(table) / sizeof(table[0]); }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-Wno-pedantic", "-c", str(src), "-I", os.path.join(ROOT, "include"),
+                        "-o", str(tmp_path / "abi.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
