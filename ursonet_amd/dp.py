@@ -172,6 +172,11 @@ class DataParallelEngine(object):
             eng.restore_train_state(saved)
         torch.cuda.current_stream(eng.device).wait_stream(side)
         torch.cuda.synchronize(eng.device)
+        from .engine import _no_gc
+        with _no_gc():                       # no engine / graph may be garbage-collected while a stream is capturing
+            self._capture_graphs(eng, segs, last)
+
+    def _capture_graphs(self, eng, segs, last):
         graphs = []
         pool = None
         self._pre_graph = None

@@ -57,6 +57,24 @@ class _Conv(object):
     pass
 
 
+class _no_gc(object):
+    """Collect garbage now and keep the cyclic collector off inside the block.  An Engine is full of reference cycles (its op lists are
+    closures over itself), so an engine that went out of scope dies whenever the collector happens to run -- and if that is in the
+    middle of another engine's stream capture, destroying the old engine's hipGraph / events there aborts the process."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class Engine(object):
     def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False, grad_bucket_bytes=32 << 20):
         assert mode in ("training", "inference")
@@ -776,11 +794,12 @@ class Engine(object):
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            if self.mode == "training":
-                self.step_eager()
-            else:
-                self.run_prep(); self.run_forward()
+        with _no_gc():                                 # see _no_gc: nothing may be destroyed while the stream is capturing
+            with torch.cuda.graph(gr):
+                if self.mode == "training":
+                    self.step_eager()
+                else:
+                    self.run_prep(); self.run_forward()
         self._graphs = gr
         return gr
 
