@@ -33,7 +33,9 @@ struct UrsoOptions {
 };
 extern UrsoOptions g_urso_opt;
 
-#define URSO_REDUCE_COLS 256   // float4 columns per block of the split-reduction kernels (conv_wgrad.hip) = its block size; prep.hip plans with it
+#define URSO_REDUCE_COLS 256   // threads per block of the split-reduction kernels (conv_wgrad.hip): (256 / lanes) float4 columns x lanes; prep.hip plans with it
+// split-lanes of the reduction for a layer with `splits` partials (each lane adds <= ~48 splits in a row)
+static __host__ __device__ inline int urso_reduce_lanes(int splits) { return splits > 384 ? 16 : (splits > 192 ? 8 : (splits > 96 ? 4 : (splits > 48 ? 2 : 1))); }
 
 // profiler hooks (prof.cpp)
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);

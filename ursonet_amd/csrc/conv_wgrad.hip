@@ -614,30 +614,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr64_kernel(const WgradArgs a) {
     }
 }
 
-// Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic): a thread owns ONE float4 column and adds the splits
-// 0, 1, 2, ... in order, sixteen 16-byte loads in flight; a block's 256 threads read 4 KiB contiguous per partial row.
+// Sums `splits` partial tensors of `count` floats in a FIXED order (deterministic).  A block's 256 threads are (256 / SL) float4 columns x
+// SL split-lanes, SL = urso_reduce_lanes(splits): lane sl adds its contiguous run of splits in order with sixteen 16-byte loads in
+// flight, then the lanes are combined in lane order through LDS.  SL grows with the split count: a single lane walking 700 splits is a
+// serial chain of 45 memory round trips that the whole launch waits for (tools/probes/reduce_probe.hip: the access pattern itself
+// streams at 5.5-5.8 TB/s; the stage-2 layers with 256-732 splits were what held the batched launch at 2.4 TB/s).
 __device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ part, float* __restrict__ out, size_t count, int splits,
                                                      size_t pstride /* floats between partial tensors, multiple of 4 */) {
+    __shared__ f32x4_t red[256];
     const size_t nq = (count + 3) / 4;
     const bool vec = (count & 3) == 0;                // otherwise (tiny odd-sized tensors) the scalar tail below does everything
-    const size_t q = (size_t)bid * URSO_REDUCE_COLS + threadIdx.x;
+    const int SL = urso_reduce_lanes(splits), cols = URSO_REDUCE_COLS / SL;
+    const int col = threadIdx.x % cols, sl = threadIdx.x / cols;
+    const size_t q = (size_t)bid * cols + col;
+    f32x4_t t = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (vec && q < nq) {
         const size_t stride = pstride / 4;
         const f32x4_t* p = (const f32x4_t*)part + q;
-        f32x4_t t = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 16 <= splits; k += 16) {
+        const int per = (splits + SL - 1) / SL, k1 = min(splits, (sl + 1) * per);
+        int k = sl * per;
+        for (; k + 16 <= k1; k += 16) {
             f32x4_t v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = p[(size_t)(k + i) * stride];
 #pragma unroll
             for (int i = 0; i < 16; ++i) t += v[i];
         }
-        for (; k < splits; ++k) t += p[(size_t)k * stride];
-        *((f32x4_t*)out + q) = t;
+        for (; k < k1; ++k) t += p[(size_t)k * stride];
     }
+    if (SL > 1) {
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (sl == 0) {
+            t = red[col];
+            for (int i = 1; i < SL; ++i) t += red[i * cols + col];
+        }
+    }
+    if (vec && q < nq && sl == 0) *((f32x4_t*)out + q) = t;
     if (!vec && threadIdx.x == 0 && bid == 0)
-        for (size_t e = 0; e < count; ++e) { float t = 0.f; for (int i = 0; i < splits; ++i) t += part[(size_t)i * pstride + e]; out[e] = t; }
+        for (size_t e = 0; e < count; ++e) { float tt = 0.f; for (int i = 0; i < splits; ++i) tt += part[(size_t)i * pstride + e]; out[e] = tt; }
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int splits, size_t pstride) {
@@ -649,7 +664,8 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const urso_p
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     const size_t cnt = (size_t)d.K * d.npad;
-    const int nb_dw = (int)(((cnt + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS);
+    const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(d.splits);
+    const int nb_dw = (int)(((cnt + 3) / 4 + rcols - 1) / rcols);
     if (local < nb_dw) reduce_partials_body(local, d.part, d.dw_raw, cnt, d.splits, cnt + URSO_WGRAD_PART_PAD);
     else reduce_partials_body(local - nb_dw, d.colpart, d.colsum, (size_t)d.npad, d.splits, (size_t)d.npad);
 }
@@ -763,9 +779,10 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     if (rc != URSO_OK) return rc;
     if (!direct && !keep_partials) {
         size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
-        int blocks = (int)(((cnt + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS);
+        const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(p.splits);
+        int blocks = (int)(((cnt + 3) / 4 + rcols - 1) / rcols);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits, cnt + URSO_WGRAD_PART_PAD);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;

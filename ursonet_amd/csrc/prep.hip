@@ -337,7 +337,8 @@ static int batch_layer_blocks(int phase, const urso_param_desc& d) {
     case URSO_PB_REDUCE: {
         if (d.splits <= 1) return 0;
         const size_t cnt = (size_t)d.K * d.npad;
-        return (int)(((cnt + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS) + (int)(((size_t)(d.npad + 3) / 4 + URSO_REDUCE_COLS - 1) / URSO_REDUCE_COLS);
+        const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(d.splits);
+        return (int)(((cnt + 3) / 4 + rcols - 1) / rcols) + (int)(((size_t)(d.npad + 3) / 4 + rcols - 1) / rcols);
     }
     case URSO_PB_FINALIZE_MAT: return ceil_div(d.N, 64) * d.ks;
     case URSO_PB_FINALIZE_VEC: return ceil_div(d.N, 256);
