@@ -336,8 +336,9 @@ static int hc_device_cus() {
 
 // Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 128 == 0, N % 128 == 0, halo tile within the LDS
 // budget -- and a tile count that fills the 256 one-block-per-CU slots evenly: every block walks ceil(tiles / blocks) tiles, so e.g. 340
-// tiles cost as much as 512.  hconv = 1 (default) takes the layer only when that rounding loses < 25 % (measured on cfg2: stage 3 659
-// tiles 58.8 vs 62.6 us, stage 5 180 tiles 52.6 vs 55.6 us in favour; stage 4 340 tiles 59.7 vs 56.5 us against); hconv = 2 always.
+// tiles cost as much as 512.  hconv = 1 (default) takes the layer only when that rounding loses < 35 % (measured on cfg2: stage 3 659
+// tiles 58.8 vs 62.6 us, stage 5 180 tiles 52.6 vs 55.6 us in favour; stage 4 340 tiles = 66 % of two rounds: 59.7 vs 56.5 us against in
+// isolation, but inside the step the DMA kernel's stage-4 launches take 65 us and the step is 0.3 % faster with them here); hconv = 2 always.
 bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
     if (!g_urso_opt.hconv || dt == URSO_F32 || add) return false;          // a residual operand never occurs on these layers: left to conv_pw.hip
     if (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) return false;
@@ -349,7 +350,7 @@ bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add
     if (g_urso_opt.hconv == 1) {
         const int ntiles = ceil_div(g->B * (g->H + 1) * (g->W + 1), HC_BM) * (g->N / HC_BN), ncu = hc_device_cus();
         const int blocks = ntiles < ncu ? ntiles : ncu, rounds = ceil_div(ntiles, blocks);
-        if (ntiles * 4 < blocks * rounds * 3 && !(ntiles <= ncu && ntiles * 3 >= ncu * 2)) return false;   // < 75 % of the slots busy (one-round launches: 2/3)
+        if (ntiles * 20 < blocks * rounds * 13 && !(ntiles <= ncu && ntiles * 3 >= ncu * 2)) return false;   // < 65 % of the slots busy
     }
     return true;
 }
