@@ -652,7 +652,7 @@ class Engine(object):
         Where the residual side is not a fused pair (stages 4-5, pair option off) the dense form is produced once by urso_rows_expand2.
         URSO_COMPACT_GRAD=0 keeps the dense path everywhere."""
         g, dt, B, dev = self.graph, self.dt, self.B, self.device
-        if dt == hip.F32 or os.environ.get("URSO_COMPACT_GRAD", "1") == "0":
+        if dt == hip.F32 or not getattr(self.config, "COMPACT_GRADIENTS", True) or os.environ.get("URSO_COMPACT_GRAD", "1") == "0":
             return
         convs = list(self.convs.values())
         for X in self.acts.values():
