@@ -59,7 +59,8 @@ int         urso_abi_version(void);           /* bumped on any signature change 
  *   hconv (1)         8-wave halo-tile kernel (conv_halo.hip) for 3x3 stride-1 layers with >= 128 channels and filters:
  *                     0 never, 1 where its tile count fills the chip evenly (measured policy), 2 wherever it applies
  *   hconv_dbg (0)     kernel-development switches of that kernel; leave 0
- *   c3 (1)            register-resident-filter kernel (conv_c3.hip) for 3x3 stride-1 layers with 64 channels and 64 filters
+ *   c3 (1)            register-resident-filter kernels (conv_c3.hip) for 3x3 stride-1 layers: 64 channels / filters always, 128 / 128
+ *                     where the 4 x 32 tiles cover the image to >= 88 % (else the halo kernel); 2: only the 64-channel form, 3: both always
  *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
  *                     itself never fuses behind the caller's back)

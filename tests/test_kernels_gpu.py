@@ -826,6 +826,26 @@ def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
     assert float((outs[(1, 0)] - outs[(0, 0)]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[(0, 0)].abs().max())
 
 
+C3W_CASES = [
+    (1, 4, 32, 128, 128, 3, 1, (1, 1), "c3w_one_tile"),
+    (3, 17, 45, 128, 128, 3, 1, (1, 1), "c3w_ragged"),
+    (2, 64, 96, 128, 128, 3, 1, (1, 1), "c3w_multi_tile"),
+    (8, 64, 80, 128, 128, 3, 1, (1, 1), "c3w_stage3_rows"),
+]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("cap", [0, 8])
+@pytest.mark.parametrize("case", C3W_CASES, ids=[c[-1] for c in C3W_CASES])
+def test_3x3_128_channel_layers_register_filter_kernel(case, dt, cap):
+    """The 128-channel form of conv_c3.hip (8 waves, each 32 filters x one 64-channel half of the filter in registers; the reduction over
+    the two halves finished through LDS), forced on every shape (option c3 = 3: the default policy takes it only where its tiles fit the
+    image width): forward, data gradient with mask and weight gradient against the CPU fp32 reference; ragged sizes, capped grid."""
+    hip = _hip()
+    with hip.options(c3=3, grid_cap=cap):
+        test_conv_forward_and_gradients(case, dt)
+
+
 C3_CASES = [
     (1, 4, 32, 64, 64, 3, 1, (1, 1), "c3_one_tile"),
     (2, 12, 20, 64, 64, 3, 1, (1, 1), "c3_narrow_image"),        # W < tile width: partial tiles, right border inside the patch

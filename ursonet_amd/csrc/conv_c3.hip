@@ -203,6 +203,186 @@ __global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same idea for 128 channels and 128 filters (res3x_branch2b): the filter is 288 KiB -- exactly what 8 waves x 144 VGPRs hold.  Wave
+// (fq = wave & 3, ch = wave >> 2) keeps 32 filters x 9 taps x one 64-channel HALF; the reduction over the two channel halves is finished
+// through LDS at the end of a tile (the two waves of a filter quarter exchange two output rows each and add).  A wave computes all four
+// output rows of the tile, so a halo-row fragment feeds up to three of them: 72 ds_read_b128 per 144 MFMAs -- half the LDS bytes per MAC
+// of conv_halo.hip, whose 64 x 64 wave tiles keep the LDS port as busy as the matrix pipe.  The two channel halves of the halo patch are
+// separate [224][128 B] LDS tiles (same swizzle as above); LDS = 2 x 2 x 28 KiB patches + 8 KiB; exchange and output tile reuse the
+// patch buffers of the tile just finished.  512 threads, one block per CU.
+constexpr int C3W_PATCH = 2 * C3_ABUF;                                    // both channel halves of one tile's halo patch: 56 KiB
+constexpr int C3W_EOFF = 2 * C3W_PATCH, C3W_BOFF = C3W_EOFF + 8192, C3W_LDS = C3W_BOFF + 512;
+constexpr int C3W_NA = 7;                                                 // DMA instructions per lane: 8 waves x 7 >= 2 halves x 26 row blocks
+
+template <typename T, bool MASK>
+__global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    __shared__ __attribute__((aligned(1024))) char smem[C3W_LDS];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fq = wave & 3, ch = wave >> 2;
+    int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = c3_rsrc(a.src, a.bytes);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.bytes);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(MASK ? a.mask : a.dst, MASK ? a.bytes : 0u);
+
+    int lane_d = lane;
+    auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+        const int tx = t % a.tiles_x, q = t / a.tiles_x;
+        const int ty = q % a.tiles_y;
+        b = q / a.tiles_y; y0 = ty * C3_TH; x0 = tx * C3_TW;
+    };
+    // instruction ii = wave + 8 i fills 1 KiB = 8 halo rows of ONE channel half: half = ii / 26, row block = ii % 26
+    auto dma_tile = [&](int t, int buf) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        const int base = ((b * a.H + y0 - 1) * a.W + x0 - 1) * 256;
+        asm volatile("" : "+v"(lane_d));
+#pragma unroll
+        for (int i = 0; i < C3W_NA; ++i) {
+            const int ii = wave + 8 * i, half = ii >= 26 ? 1 : 0, rb = ii - 26 * half;
+            const int hr = 8 * rb + (lane_d >> 3);
+            const int hy = (hr * 241) >> 13, hx = hr - hy * C3_HW;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = ii < 52 && hr < C3_HROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + half * 128 + (((lane_d & 7) ^ ((hr >> 1) & 7)) << 4));
+            if (ii < 54) c3_dma16(rs, lds0 + buf * C3W_PATCH + half * C3_ABUF + rb * 1024, ok ? off : URSO_OOB_SHIFT);
+        }
+    };
+
+    i32x4_t wfr[9][4];
+    {
+        const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+        const char* wrow = (const char*)a.wgt + (size_t)(32 * fq + lg) * (9 * 128 * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wfr[t][j] = *(const i32x4_t*)(wrow + (t * 128 + 64 * ch + 16 * j + 8 * h) * 2);
+    }
+    if (tid < 128) *(float*)(smem + C3W_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
+
+    constexpr int NST = 4;                                     // 128 pixels x 16 slots = 2048 vectors / 512 threads
+    dma_tile(tile, 0);
+    int buf = 0;
+    bool first = true;
+    while (true) {
+        const bool has_next = tile + bpx < t_end;
+        if (first) c3_wait_vm<0>(); else c3_wait_vm<NST>();
+        first = false;
+        c3_barrier();                                          // (1)
+        if (has_next) dma_tile(tile + bpx, buf ^ 1);
+        const char* sA = smem + buf * C3W_PATCH + ch * C3_ABUF;
+
+        f32x16_t acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+        asm volatile("" : "+v"(l31));
+        // step s = (halo row hr of 6, column shift kx, 16-channel slice j): one fragment for the output rows r = hr - ky, ky = 0..2
+        i32x4_t f[4];
+        auto rd = [&](i32x4_t& fs, int s) {
+            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            fs = *(const i32x4_t*)(sA + c3_rd(hr * C3_HW + l31 + kx, h, j));
+        };
+        rd(f[0], 0);
+        rd(f[1], 1);
+        rd(f[2], 2);
+#pragma unroll
+        for (int s = 0; s < 72; ++s) {
+            if (s + 3 < 72) rd(f[(s + 3) & 3], s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ky = hr - r;
+                if (ky >= 0 && ky <= 2) C3Mma<T>::run(wfr[3 * ky + kx][j], f[s & 3], acc[r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- finish the reduction over the two channel halves: wave (fq, 0) keeps output rows 0, 1 and hands rows 2, 3 to (fq, 1), which
+        //      keeps 2, 3 and hands over 0, 1.  Exchange area: the patch buffers of THIS tile (56 KiB) + 8 KiB; lane-linear, conflict-free.
+        char* sX = smem + buf * C3W_PATCH;
+        auto xoff = [&](int w, int rr, int q) -> char* {       // 8 KiB per wave: [2 rows][4 register quads][64 lanes][16 B]
+            const uint32_t o = (uint32_t)(w * 8192 + ((rr * 4 + q) * 64 + lane) * 16);
+            return (o < (uint32_t)C3W_PATCH) ? sX + o : smem + C3W_EOFF + (o - C3W_PATCH);
+        };
+        c3_barrier();                                          // (2) every wave is done reading the patch
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const f32x16_t& v = (ch == 0) ? acc[2 + rr] : acc[rr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4_t*)xoff(wave, rr, q) = f32x4_t{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        c3_barrier();                                          // (3)
+        f32x16_t fin[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            fin[rr] = (ch == 0) ? acc[rr] : acc[2 + rr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t p = *(const f32x4_t*)xoff(wave ^ 4, rr, q);
+                fin[rr][4 * q] += p.x; fin[rr][4 * q + 1] += p.y; fin[rr][4 * q + 2] += p.z; fin[rr][4 * q + 3] += p.w;
+            }
+        }
+        c3_barrier();                                          // (4) the exchange area is free: the output tile goes over it
+        char* sO = sX;                                         // [128 pixels][256 B], slot ^ (pixel & 15)
+        {
+            const f32x4_t* bp = (const f32x4_t*)(smem + C3W_BOFF + (32 * fq + 16 * h) * 4);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int px = (2 * ch + rr) * 32 + l31;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const f32x4_t b0 = bp[2 * v], b1 = bp[2 * v + 1];
+                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    T o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float y = fin[rr][8 * v + e] + bb[e]; y = a.relu ? fmaxf(y, 0.f) : y; o[e] = Elem<T>::from_f(y); }
+                    i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+                    *(i32x4_t*)(sO + px * 256 + (((4 * fq + 2 * h + v) ^ (px & 15)) << 4)) = ov;
+                }
+            }
+        }
+        int b, y0, x0;
+        tile_origin(tile, b, y0, x0);
+        uint32_t so[NST];
+        i32x4_t mv[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int p = (wave + 8 * i) * 64 + lane, px = p >> 4;
+            const int y = y0 + (px >> 5), x = x0 + (px & 31);
+            so[i] = (y < a.H && x < a.W) ? (uint32_t)(((b * a.H + y) * a.W + x) * 256 + (((p & 15) ^ (px & 15)) << 4)) : URSO_OOB_SHIFT;
+            if constexpr (MASK) mv[i] = buf_load16(rmk, so[i]);
+        }
+        c3_barrier();                                          // (5)
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            i32x4_t v = *(const i32x4_t*)(sO + (wave + 8 * i) * 1024 + lane * 16);
+            if constexpr (MASK) {
+                T x[8], m[8];
+                __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &mv[i], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = Elem<T>::to_f(m[e]) > 0.f ? x[e] : Elem<T>::from_f(0.f);
+                __builtin_memcpy(&v, x, 16);
+            }
+            buf_store16(rds, so[i], v);
+        }
+        if (!has_next) break;
+        tile += bpx; buf ^= 1;
+    }
+}
+
 static int c3_device_cus() {
     static int ncu = 0;
     if (!ncu) {
@@ -213,12 +393,20 @@ static int c3_device_cus() {
     return ncu;
 }
 
-// conv_igemm.hip asks before choosing a kernel.  Policy option "c3": 0 never, 1 (default) wherever the shape qualifies.
+// conv_igemm.hip asks before choosing a kernel.  Policy option "c3": 0 never, 1 (default) 64-channel layers always and 128-channel layers where the tiles fit the image, 2 only the
+// 64-channel ones, 3 both always.
 bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
     if (!g_urso_opt.c3 || add || (dt != URSO_BF16 && dt != URSO_F16) || (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS))) return false;
     if (g->KH != 3 || g->KW != 3 || g->SH != 1 || g->SW != 1 || g->PH != 1 || g->PW != 1 || g->DH != 1 || g->DW != 1 || g->FH > 0) return false;
-    if (g->C != 64 || g->N != 64 || g->OH != g->H || g->OW != g->W) return false;
-    return (long long)g->B * g->H * g->W * 128 < 0x7FFFFF00ll;
+    if (!((g->C == 64 && g->N == 64) || (g->C == 128 && g->N == 128 && (g_urso_opt.c3 == 1 || g_urso_opt.c3 == 3))) || g->OH != g->H || g->OW != g->W) return false;
+    if (g->C == 128 && g_urso_opt.c3 == 1) {
+        // 128 channels: conv_halo.hip is the alternative.  The 4 x 32 tile wastes what the image width leaves of its last column of tiles
+        // (cfg2 stage 3: W = 80 -> 83 % useful, 58.9 us against 53.0 us; cfg5: W = 120 -> 94 %, 90.5 against 108 us): take the layer from
+        // 88 % upwards (c3 = 3 takes it always)
+        const int tx = ceil_div(g->W, C3_TW), ty = ceil_div(g->H, C3_TH);
+        if ((long long)g->W * g->H * 100 < (long long)tx * C3_TW * ty * C3_TH * 88) return false;
+    }
+    return (long long)g->B * g->H * g->W * g->C * 2 < 0x7FFFFF00ll;
 }
 
 int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* mask,
@@ -226,13 +414,19 @@ int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, c
     C3Args a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.mask = mask; a.dst = dst; a.relu = relu;
     a.B = g->B; a.H = g->H; a.W = g->W;
-    a.bytes = (uint32_t)((size_t)g->B * g->H * g->W * 128);
+    a.bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2);
     a.tiles_x = ceil_div(g->W, C3_TW); a.tiles_y = ceil_div(g->H, C3_TH); a.ntiles = g->B * a.tiles_y * a.tiles_x;
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = 2 * c3_device_cus() / 8;
+    const bool wide = g->C == 128;
+    const int cap = (wide ? 1 : 2) * c3_device_cus() / 8;
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
-    const dim3 grid(8 * bpx), blk(256);
+    const dim3 grid(8 * bpx), blk(wide ? 512 : 256);
+    if (wide) {
+        if (dt == URSO_BF16) { if (mask) hipLaunchKernelGGL((c3w_kernel<__bf16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((c3w_kernel<__bf16, false>), grid, blk, 0, st, a); }
+        else { if (mask) hipLaunchKernelGGL((c3w_kernel<_Float16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((c3w_kernel<_Float16, false>), grid, blk, 0, st, a); }
+        return urso_check_launch("urso_conv_igemm(3x3, 128 channels)");
+    }
     if (dt == URSO_BF16) {
         if (mask) hipLaunchKernelGGL((c3_kernel<__bf16, true>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((c3_kernel<__bf16, false>), grid, blk, 0, st, a);
