@@ -215,8 +215,13 @@ constexpr int C3W_PATCH = 2 * C3_ABUF;                                    // bot
 constexpr int C3W_EOFF = 2 * C3W_PATCH, C3W_BOFF = C3W_EOFF + 8192, C3W_LDS = C3W_BOFF + 512;
 constexpr int C3W_NA = 7;                                                 // DMA instructions per lane: 8 waves x 7 >= 2 halves x 26 row blocks
 
-template <typename T, bool MASK>
+// Two tile geometries: 4 rows x 32 pixels (an MFMA pixel tile = 32 consecutive pixels of one row) and 8 rows x 16 pixels (a pixel tile =
+// 16 pixels of two consecutive rows: lane & 15 is the column, lane >> 4 the row of the pair) for images whose width is nearer a multiple
+// of 16 than of 32 (cfg2 stage 3: W = 80).
+template <typename T, bool MASK, int TW>
 __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
+    constexpr int TH = 128 / TW, HW = TW + 2, HROWS = (TH + 2) * HW;       // 4 x 32: 6 x 34 = 204 halo pixels; 8 x 16: 10 x 18 = 180
+    static_assert(TW == 32 || TW == 16, "tile width");
     static_assert(sizeof(T) == 2, "16-bit element types only");
     __shared__ __attribute__((aligned(1024))) char smem[C3W_LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
     auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
         const int tx = t % a.tiles_x, q = t / a.tiles_x;
         const int ty = q % a.tiles_y;
-        b = q / a.tiles_y; y0 = ty * C3_TH; x0 = tx * C3_TW;
+        b = q / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
     };
     // instruction ii = wave + 8 i fills 1 KiB = 8 halo rows of ONE channel half: half = ii / 26, row block = ii % 26
     auto dma_tile = [&](int t, int buf) {
@@ -251,9 +256,9 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
         for (int i = 0; i < C3W_NA; ++i) {
             const int ii = wave + 8 * i, half = ii >= 26 ? 1 : 0, rb = ii - 26 * half;
             const int hr = 8 * rb + (lane_d >> 3);
-            const int hy = (hr * 241) >> 13, hx = hr - hy * C3_HW;
+            const int hy = TW == 32 ? ((hr * 241) >> 13) : ((hr * 3641) >> 16), hx = hr - hy * HW;     // hr / 34, hr / 18 for hr < 224
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = ii < 52 && hr < C3_HROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const bool ok = ii < 52 && hr < HROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
             const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + half * 128 + (((lane_d & 7) ^ ((hr >> 1) & 7)) << 4));
             if (ii < 54) c3_dma16(rs, lds0 + buf * C3W_PATCH + half * C3_ABUF + rb * 1024, ok ? off : URSO_OOB_SHIFT);
         }
@@ -288,26 +293,50 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
         asm volatile("" : "+v"(l31));
-        // step s = (halo row hr of 6, column shift kx, 16-channel slice j): one fragment for the output rows r = hr - ky, ky = 0..2
         i32x4_t f[4];
-        auto rd = [&](i32x4_t& fs, int s) {
-            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
-            fs = *(const i32x4_t*)(sA + c3_rd(hr * C3_HW + l31 + kx, h, j));
-        };
-        rd(f[0], 0);
-        rd(f[1], 1);
-        rd(f[2], 2);
+        if constexpr (TW == 32) {
+            // step s = (halo row hr of 6, column shift kx, 16-channel slice j): one fragment for the output rows r = hr - ky, ky = 0..2
+            auto rd = [&](i32x4_t& fs, int s) {
+                const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+                fs = *(const i32x4_t*)(sA + c3_rd(hr * HW + l31 + kx, h, j));
+            };
+            rd(f[0], 0);
+            rd(f[1], 1);
+            rd(f[2], 2);
 #pragma unroll
-        for (int s = 0; s < 72; ++s) {
-            if (s + 3 < 72) rd(f[(s + 3) & 3], s + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            for (int s = 0; s < 72; ++s) {
+                if (s + 3 < 72) rd(f[(s + 3) & 3], s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ky = hr - r;
-                if (ky >= 0 && ky <= 2) C3Mma<T>::run(wfr[3 * ky + kx][j], f[s & 3], acc[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int ky = hr - r;
+                    if (ky >= 0 && ky <= 2) C3Mma<T>::run(wfr[3 * ky + kx][j], f[s & 3], acc[r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // pixel tile m = output rows 2 m, 2 m + 1.  Step s = (first halo row rp of a row pair, 0..8; kx; j): the fragment of halo rows
+            // (rp, rp + 1) serves tile m with ky = rp - 2 m wherever 0 <= ky <= 2 (even rp: two tiles, odd rp: one): 108 reads per 144 MFMAs
+            const int prow = (l31 >> 4) * HW + (l31 & 15);
+            auto rd = [&](i32x4_t& fs, int s) {
+                const int rp = s / 12, kx = (s / 4) % 3, j = s & 3;
+                fs = *(const i32x4_t*)(sA + c3_rd(rp * HW + prow + kx, h, j));
+            };
+            rd(f[0], 0);
+            rd(f[1], 1);
+#pragma unroll
+            for (int s = 0; s < 108; ++s) {
+                if (s + 2 < 108) rd(f[(s + 2) % 3], s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int rp = s / 12, kx = (s / 4) % 3, j = s & 3;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ky = rp - 2 * m;
+                    if (ky >= 0 && ky <= 2) C3Mma<T>::run(wfr[3 * ky + kx][j], f[s % 3], acc[m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- finish the reduction over the two channel halves: wave (fq, 0) keeps output rows 0, 1 and hands rows 2, 3 to (fq, 1), which
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
             const f32x4_t* bp = (const f32x4_t*)(smem + C3W_BOFF + (32 * fq + 16 * h) * 4);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int px = (2 * ch + rr) * 32 + l31;
+                const int px = (2 * ch + rr) * 32 + l31;      // pixel tile 2 ch + rr: 32 pixels of the tile in row-major order for either geometry
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const f32x4_t b0 = bp[2 * v], b1 = bp[2 * v + 1];
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int p = (wave + 8 * i) * 64 + lane, px = p >> 4;
-            const int y = y0 + (px >> 5), x = x0 + (px & 31);
+            const int y = y0 + px / TW, x = x0 + px % TW;
             so[i] = (y < a.H && x < a.W) ? (uint32_t)(((b * a.H + y) * a.W + x) * 256 + (((p & 15) ^ (px & 15)) << 4)) : URSO_OOB_SHIFT;
             if constexpr (MASK) mv[i] = buf_load16(rmk, so[i]);
         }
@@ -393,6 +422,13 @@ static int c3_device_cus() {
     return ncu;
 }
 
+// 128-channel form: percentage of the tiles' pixels that lie inside the image, for the 4 x 32 (tw = 32) or 8 x 16 (tw = 16) geometry
+static int c3w_util(int H, int W, int tw) {
+    const int th = 128 / tw;
+    return (int)((long long)H * W * 100 / ((long long)ceil_div(H, th) * th * ceil_div(W, tw) * tw));
+}
+static int c3w_best_tw(int H, int W) { return c3w_util(H, W, 16) > c3w_util(H, W, 32) ? 16 : 32; }
+
 // conv_igemm.hip asks before choosing a kernel.  Policy option "c3": 0 never, 1 (default) 64-channel layers always and 128-channel layers where the tiles fit the image, 2 only the
 // 64-channel ones, 3 both always.
 bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
@@ -400,11 +436,10 @@ bool urso_c3_fits(const urso_conv_geom* g, int dt, int flags, const void* add) {
     if (g->KH != 3 || g->KW != 3 || g->SH != 1 || g->SW != 1 || g->PH != 1 || g->PW != 1 || g->DH != 1 || g->DW != 1 || g->FH > 0) return false;
     if (!((g->C == 64 && g->N == 64) || (g->C == 128 && g->N == 128 && (g_urso_opt.c3 == 1 || g_urso_opt.c3 == 3))) || g->OH != g->H || g->OW != g->W) return false;
     if (g->C == 128 && g_urso_opt.c3 == 1) {
-        // 128 channels: conv_halo.hip is the alternative.  The 4 x 32 tile wastes what the image width leaves of its last column of tiles
-        // (cfg2 stage 3: W = 80 -> 83 % useful, 58.9 us against 53.0 us; cfg5: W = 120 -> 94 %, 90.5 against 108 us): take the layer from
-        // 88 % upwards (c3 = 3 takes it always)
-        const int tx = ceil_div(g->W, C3_TW), ty = ceil_div(g->H, C3_TH);
-        if ((long long)g->W * g->H * 100 < (long long)tx * C3_TW * ty * C3_TH * 88) return false;
+        // 128 channels: conv_halo.hip is the alternative.  A tile geometry wastes what the image leaves of its last row / column of tiles
+        // (4 x 32 on cfg2 stage 3, W = 80: 83 % useful, 58.9 us against 53.0 us; cfg5, W = 120: 94 %, 90.5 against 108 us): the better of
+        // 4 x 32 and 8 x 16 must reach 88 % (c3 = 3 takes the layer always)
+        if (c3w_util(g->H, g->W, c3w_best_tw(g->H, g->W)) < 88) return false;
     }
     return (long long)g->B * g->H * g->W * g->C * 2 < 0x7FFFFF00ll;
 }
@@ -415,16 +450,20 @@ int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, c
     a.src = src; a.wgt = wgt; a.bias = bias; a.mask = mask; a.dst = dst; a.relu = relu;
     a.B = g->B; a.H = g->H; a.W = g->W;
     a.bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2);
-    a.tiles_x = ceil_div(g->W, C3_TW); a.tiles_y = ceil_div(g->H, C3_TH); a.ntiles = g->B * a.tiles_y * a.tiles_x;
-    int bpx = ceil_div(a.ntiles, 8);
     const bool wide = g->C == 128;
+    const int tw = wide ? c3w_best_tw(g->H, g->W) : C3_TW, th = 128 / tw;
+    a.tiles_x = ceil_div(g->W, tw); a.tiles_y = ceil_div(g->H, th); a.ntiles = g->B * a.tiles_y * a.tiles_x;
+    int bpx = ceil_div(a.ntiles, 8);
     const int cap = (wide ? 1 : 2) * c3_device_cus() / 8;
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(wide ? 512 : 256);
     if (wide) {
-        if (dt == URSO_BF16) { if (mask) hipLaunchKernelGGL((c3w_kernel<__bf16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((c3w_kernel<__bf16, false>), grid, blk, 0, st, a); }
-        else { if (mask) hipLaunchKernelGGL((c3w_kernel<_Float16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((c3w_kernel<_Float16, false>), grid, blk, 0, st, a); }
+#define URSO_C3W(TT, TWV) do { if (mask) hipLaunchKernelGGL((c3w_kernel<TT, true, TWV>), grid, blk, 0, st, a); \
+                               else hipLaunchKernelGGL((c3w_kernel<TT, false, TWV>), grid, blk, 0, st, a); } while (0)
+        if (dt == URSO_BF16) { if (tw == 32) URSO_C3W(__bf16, 32); else URSO_C3W(__bf16, 16); }
+        else { if (tw == 32) URSO_C3W(_Float16, 32); else URSO_C3W(_Float16, 16); }
+#undef URSO_C3W
         return urso_check_launch("urso_conv_igemm(3x3, 128 channels)");
     }
     if (dt == URSO_BF16) {
