@@ -195,6 +195,24 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3)
 
 
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 4e-3, 7e-3)])
+def test_training_step_parity_16bit_register_filter_3x3_everywhere(dtype, tol_out, tol_g):
+    """The same oracle comparison with the 128-channel register-filter 3x3 kernel forced onto every layer it can run (option c3 = 3;
+    the default policy only takes images its tiles cover to 88 %, which this small test image does not reach), so that its forward and
+    masked data-gradient forms, both tile geometries' border handling and the cross-wave reduction sit inside an oracle-compared step."""
+    import ursonet_amd.hip as hip
+    from oracle import graph_ref as G
+    cfg = make_config(dtype=dtype, backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=1)
+    with hip.options(c3=3):
+        eng, w0 = _run_engine(cfg, img, loc, ori)
+    q = G.StorageRounding(torch.bfloat16 if dtype == "bfloat16" else torch.float16)
+    dec = ReluDecisions(eng, tol=4 * tol_out)
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+    assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
+    _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3)
+
+
 def test_keypoint_mode_training_step_parity_fp32():
     """REGRESS_KEYPOINTS (net.py:312-316, 657-659): three Dense(3) heads on the loc trunk, three MSE losses (a13), no
     orientation branch.  One hipGraph step vs the oracle: outputs, the three losses, every gradient, post-step weights."""
