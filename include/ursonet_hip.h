@@ -63,7 +63,8 @@ int         urso_abi_version(void);           /* bumped on any signature change 
  *                     where the 4 x 32 tiles cover the image to >= 88 % (else the halo kernel); 2: only the 64-channel form, 3: both always
  *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
- *                     itself never fuses behind the caller's back)
+ *                     itself never fuses behind the caller's back); 1 also lets the stage-2 backward pair accumulate the block-closing
+ *                     layer's weight gradient (urso_conv_pair_wgrad), 2 keeps that weight gradient a launch of its own
  */
 int urso_set_option(const char* name, int value);
 int urso_get_option(const char* name, int* value);
@@ -149,6 +150,18 @@ int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_
  * zeros) is never written or read.  urso_rows_subsample2 gathers the matching rows of a per-pixel byte array (the ReLU bit mask the
  * stride-2 layers' data gradients need): out[b][y/2][x/2][:] = in[b][y][x][:], row_bytes % 16 == 0. */
 int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
+/* The stage-2 backward pair (mode 1, c_narrow = 64, M % 64 == 0) that ALSO accumulates the weight gradient of the block-closing
+ * 'res2x_branch2c' layer, whose two operands the launch holds on chip anyway (conv_pairw.hip):
+ *     dW[c][n] = sum_px u[px][c] mid[px][n],   colsum[n] = sum_px mid[px][n]        (u_d = that layer's input = urso_conv_pair's mask2_d)
+ * -- what urso_conv_wgrad_partial(x = u, dz = mid) produces, from the stored (rounded) `mid`, without reading the 256-channel gradient
+ * and u back from memory.  mid_d / dst_d are bit-identical to urso_conv_pair's.  The weight gradient leaves as fp32 partials, one
+ * per block: part_d[s][64][256] with part_stride floats between consecutive s (>= 64 * 256), colpart_d[s][256] (NULL: not wanted),
+ * s < urso_conv_pair_wgrad_splits(M, dt) (0: the shape does not qualify); the batched split reduction (urso_param_batch_run) or
+ * any sum over s finishes them.  add_h / add_w as in urso_conv_pair. */
+int urso_conv_pair_wgrad_splits(long long M, int dt);
+int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_d, const void* add_d, const void* bits_d, void* mid_d,
+                         const void* w2_d, const void* u_d, void* dst_d, int add_h, int add_w,
+                         float* part_d, float* colpart_d, size_t part_stride, void* stream);
 /* The inverse: out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere -- the dense form of a compact gradient for a
  * consumer that cannot take the compact operand (stages whose residual hand-over is not a urso_conv_pair launch). */
 int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);

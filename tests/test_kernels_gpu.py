@@ -905,6 +905,55 @@ def test_backward_pair_with_compact_add_operand(dt, c, shape):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("compact", [False, True], ids=["dense_add", "compact_add"])
+@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (2, 8, 24, 0), (4, 64, 80, 8), (8, 64, 80, 0), (32, 64, 80, 0)],
+                         ids=["one_tile", "few_tiles", "capped", "multi_tile", "chip"])
+def test_backward_pair_that_also_accumulates_the_weight_gradient(dt, shape, compact):
+    """urso_conv_pair_wgrad (conv_pairw.hip): mid / dst bit for bit those of urso_conv_pair mode 1 (dense and compact add operand);
+    the per-block fp32 partials summed over blocks against the fp32 product u^T mid of the STORED tensors (what urso_conv_wgrad
+    computes from them) and against urso_conv_wgrad itself; blocks without tiles ('one_tile', 'few_tiles') write zero partials;
+    'capped' / 'multi_tile' / 'chip' walk the three-stage input pipeline over several tiles per block."""
+    hip = _hip()
+    B, H, W, cap = shape
+    M, c = B * H * W, 64
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + dt + 7)
+    src, u = dev(torch.randn(M, c), dt), dev(torch.relu(torch.randn(M, c)), dt)
+    w1, w2 = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
+    if compact:
+        add, hw = dev(torch.randn(B, H // 2, W // 2, 4 * c), dt), (H, W)
+    else:
+        add, hw = dev(torch.randn(M, 4 * c), dt), None
+    bits = torch.randint(0, 256, (M, c // 2), dtype=torch.uint8, device="cuda")
+    mid0 = torch.empty(M, 4 * c, dtype=tdt, device="cuda"); dst0 = torch.empty(M, c, dtype=tdt, device="cuda")
+    mid = torch.full((M, 4 * c), 5.0, device="cuda").to(tdt); dst = torch.full((M, c), 5.0, device="cuda").to(tdt)
+    with hip.options(grid_cap=cap):
+        splits = hip.conv_pair_wgrad_splits(M, dt)
+        assert splits >= 8 and splits % 8 == 0 and hip.conv_pair_wgrad_splits(M + 1, dt) == 0 and hip.conv_pair_wgrad_splits(M, 0) == 0
+        stride = c * 4 * c + hip.WGRAD_PART_PAD
+        part = torch.full((splits * stride,), float("nan"), device="cuda"); colpart = torch.full((splits * 4 * c,), float("nan"), device="cuda")
+        hip.conv_pair(M, c, dt, 1, src, w1, None, add, bits, mid0, w2, None, u, dst0, add_hw=hw)
+        hip.conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst, part, colpart, stride, add_hw=hw)
+    torch.cuda.synchronize()
+    assert torch.equal(mid, mid0) and torch.equal(dst, dst0)
+    dw = part.reshape(splits, stride)[:, :c * 4 * c].double().sum(0).reshape(c, 4 * c)
+    cs = colpart.reshape(splits, 4 * c).double().sum(0)
+    ref_dw = u.double().T @ mid.double()
+    ref_cs = mid.double().sum(0)
+    assert float((dw - ref_dw).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+    assert float((cs - ref_cs).abs().max()) <= 2e-5 * float(ref_cs.abs().max()) + 1e-4
+    g = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1)
+    ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 64, dtype=torch.float32, device="cuda")
+    dw2 = torch.empty(c * 4 * c, dtype=torch.float32, device="cuda"); cs2 = torch.empty(4 * c, dtype=torch.float32, device="cuda")
+    hip.conv_wgrad(g, dt, u, mid, ws, dw2, cs2)
+    torch.cuda.synchronize()
+    assert float((dw - dw2.double().reshape(c, 4 * c)).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+    assert float((cs - cs2.double()).abs().max()) <= 2e-5 * float(ref_cs.abs().max()) + 1e-4
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst, part, colpart, c * 4 * c - 1, add_hw=hw)   # partials would overlap
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("shape", [(2, 16, 24, 64, 64, 3), (2, 32, 40, 128, 128, 3), (3, 16, 16, 64, 256, 1), (4, 128, 160, 64, 64, 3)],
                          ids=["c3x3_64", "c3x3_128", "pointwise_wide", "stage2_rows"])
 def test_weight_gradient_with_dz_on_a_coarser_grid(dt, shape):

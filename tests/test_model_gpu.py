@@ -584,6 +584,38 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
     assert eo <= tol_out and el <= tol_out
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
+    """Option pair = 1 (default) lets the stage-2 backward pairs also accumulate the weight gradient of res2{a,b}_branch2c
+    (urso_conv_pair_wgrad) into those layers' split workspaces; pair = 2 keeps the two weight-gradient launches.  Same forward plan,
+    bit-identical data gradients: every gradient is equal bit for bit except those two layers' (kernel, folded BatchNorm), which
+    differ by the fp32 summation order of a different pixel split only."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
+    img, loc, ori, _ = synthetic_batch(cfg, 4, seed=22)
+    res = []
+    for pair in (1, 2):
+        with hip.options(pair=pair):
+            eng = Engine(cfg, "training", seed=6, randomize_bn=True)
+        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+        res.append((eng.flat_g.clone(), dict(eng.slices), eng.losses(), [l for l in eng.labels["bwd"] if l and "+wgrad:" in l],
+                    sum(1 for l in eng.labels["bwd"] if l and l.startswith("wgrad:"))))
+    assert res[0][3] == ["dgrad:res2c_branch2a+res2b_branch2c+wgrad:res2b_branch2c", "dgrad:res2b_branch2a+res2a_branch2c+wgrad:res2a_branch2c"]
+    assert res[1][3] == [] and res[1][4] - res[0][4] == 2
+    assert res[0][2] == res[1][2]
+    seen = set()
+    for (ln, wn), (o, n, _) in res[0][1].items():
+        a, b = res[0][0][o:o + n], res[1][0][o:o + n]
+        if ln.endswith(("2a_branch2c", "2b_branch2c")):           # res2a_branch2c / bn2a_branch2c, res2b_branch2c / bn2b_branch2c
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, (ln, wn)
+            assert float(b.abs().max()) > 0
+            seen.add(ln)
+        else:
+            assert torch.equal(a, b), (ln, wn)
+    assert len(seen) == 4, seen
+
+
 def test_urso_comm_bucket_averaging_one_rank():
     """The C-ABI exchange step (urso_comm_*: RCCL bound at run time) with one rank: the average over one rank is the identity, the
     collective runs on the communicator's own stream ordered after the producer kernel, and urso_comm_wait orders the consumer

@@ -418,8 +418,11 @@ class Engine(object):
                 self.labels["bwd"].append("finalize:" + node.name)
             elif tr or bn_tr:
                 d = c.desc
-                c.wg_ws = torch.empty(hip.conv_wgrad_ws_bytes(gf_w, dt) // 4 + 64, dtype=torch.float32, device=dev)
                 n_part = c.splits * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
+                by_pair = getattr(c, "wgrad_by_pair", False)           # partials written by the fused backward pair of the layer above
+                c.wg_npart = n_part
+                c.wg_ws = torch.empty((n_part + c.splits * c.npad if by_pair else hip.conv_wgrad_ws_bytes(gf_w, dt) // 4) + 64,
+                                      dtype=torch.float32, device=dev)
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev) if c.splits > 1 else None
                 c.dotpart = torch.empty(d.ks * c.N + 16, dtype=torch.float32, device=dev)
@@ -430,8 +433,9 @@ class Engine(object):
                 d.gb = hip.ptr(self.gview(node.name, "bias").reshape(-1)) if node.bias else None
                 d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
-                self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.src.data, G, c.wg_ws)))
-                self.labels["bwd"].append("wgrad:" + node.name)
+                if not by_pair:
+                    self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.src.data, G, c.wg_ws)))
+                    self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
                     k = last_of_group[node.name]
                     pending_groups.append((k, tuple(groups[k]), len(self.bwd_ops)))
@@ -478,10 +482,23 @@ class Engine(object):
                     # data gradient of this layer into X (+ residual gradient, ReLU bit mask) and, from the LDS copy of that result,
                     # the data gradient of layer A into ITS input: X.grad crosses HBM once (conv_pair.hip)
                     dstg, dst2 = X.grad_buf(), A.src.grad_buf()
-                    self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
-                                         hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2,
-                                                       add_hw=hw)))
-                    self.labels["bwd"].append("dgrad:%s+%s" % (node.name, A.name))
+                    a_tr = self.layer_trainable[A.name] or bool(A.node.bn and not A.batch_bn and self.layer_trainable[A.node.bn])
+                    wsplits = hip.conv_pair_wgrad_splits(A.Mpix, dt) if (A.node.cin == 64 and hip.get_option("pair") == 1) else 0
+                    if a_tr and wsplits > 1 and getattr(A, "gf_compact", None) is None:
+                        # ... and, stage 2, the weight gradient of layer A as well: both of its operands (X.grad, A's input) are in
+                        # LDS in that launch (conv_pairw.hip); one fp32 partial per block lands in A's split workspace, allocated
+                        # when the loop reaches A -- its reduction and finalisation stay where they are
+                        A.splits = A.desc.splits = wsplits
+                        A.wgrad_by_pair = True
+                        self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
+                                             hip.conv_pair_wgrad(A.Mpix, dt, G, c.wd, add, X.bits, dstg, A.wd, A.src.data, dst2,
+                                                                 A.wg_ws, A.wg_ws[A.wg_npart:], A.K_raw * A.npad + hip.WGRAD_PART_PAD, add_hw=hw)))
+                        self.labels["bwd"].append("dgrad:%s+%s+wgrad:%s" % (node.name, A.name, A.name))
+                    else:
+                        self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
+                                             hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2,
+                                                           add_hw=hw)))
+                        self.labels["bwd"].append("dgrad:%s+%s" % (node.name, A.name))
                     X.grad_written, X.pending = True, None
                     A.src.grad_written = True
                     A.dgrad_done_by_pair = True

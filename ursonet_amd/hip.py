@@ -113,6 +113,8 @@ _SIGS = {
     "urso_comm_destroy": (_i, [_vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
+    "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
+    "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rows_expand2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
@@ -409,6 +411,18 @@ def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, 
     ah, aw = add_hw if add_hw else (0, 0)
     _chk(_lib.urso_conv_pair(int(M), int(c_narrow), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
                              ptr(mask2), ptr(dst), int(ah), int(aw), stream_ptr(stream)), "urso_conv_pair")
+
+
+def conv_pair_wgrad_splits(M, dt):
+    return int(_lib.urso_conv_pair_wgrad_splits(int(M), dt))
+
+
+def conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst, part, colpart, part_stride, add_hw=None, stream=None):
+    """urso_conv_pair_wgrad: the stage-2 backward pair + fp32 partials of dW[64][256] / colsum[256] of the block-closing layer
+    (x = u, dz = mid), one partial per block: part[s * part_stride + c * 256 + n], colpart[s * 256 + n]."""
+    ah, aw = add_hw if add_hw else (0, 0)
+    _chk(_lib.urso_conv_pair_wgrad(int(M), dt, ptr(src), ptr(w1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(u), ptr(dst), int(ah), int(aw),
+                                   ptr(part), ptr(colpart), int(part_stride), stream_ptr(stream)), "urso_conv_pair_wgrad")
 
 
 def rows_expand2(B, H, W, row_bytes, src, dst, stream=None):
