@@ -64,7 +64,8 @@ int         urso_abi_version(void);           /* bumped on any signature change 
  *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
  *                     itself never fuses behind the caller's back); 1 also lets the stage-2 backward pair accumulate the block-closing
- *                     layer's weight gradient (urso_conv_pair_wgrad), 2 keeps that weight gradient a launch of its own
+ *                     layer's weight gradient (urso_conv_pair_wgrad) and the first stage-2 forward pair take the projection shortcut in
+ *                     (urso_conv_pair_shortcut); 2: without the weight-gradient fold; 3: plain pairs only
  */
 int urso_set_option(const char* name, int value);
 int urso_get_option(const char* name, int* value);
@@ -159,6 +160,15 @@ int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, v
  * s < urso_conv_pair_wgrad_splits(M, dt) (0: the shape does not qualify); the batched split reduction (urso_param_batch_run) or
  * any sum over s finishes them.  add_h / add_w as in urso_conv_pair. */
 int urso_conv_pair_wgrad_splits(long long M, int dt);
+/* The stage-2 forward pair at the end of the stage's FIRST block with the projection shortcut computed in place (conv_pairs.hip):
+ *     mid = relu(src W1^T + bias1 + xin Ws^T + bias_s);   dst = relu(mid W2^T + bias2)
+ *     = 'res2a_branch2c' + BatchNorm, 'res2a_branch1' + BatchNorm, Add, ReLU (net.py:121-157), then 'res2b_branch2a' + BatchNorm + ReLU;
+ * xin_d = the block input [M][64] (the shortcut conv's input), ws_d / bias_s_d = the shortcut's filter [256][64] / bias [256] in the
+ * layouts of w1_d / bias1_d.  The shortcut's 256-channel output is never written or read (the sum is formed in the fp32 accumulator,
+ * i.e. with one rounding fewer than the two launches it replaces).  16-bit dtypes, M % 64 == 0; bits_d optional as in urso_conv_pair. */
+int urso_conv_pair_shortcut(long long M, int dt, const void* src_d, const void* w1_d, const float* bias1_d,
+                            const void* xin_d, const void* ws_d, const float* bias_s_d, void* bits_d, void* mid_d,
+                            const void* w2_d, const float* bias2_d, void* dst_d, void* stream);
 int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_d, const void* add_d, const void* bits_d, void* mid_d,
                          const void* w2_d, const void* u_d, void* dst_d, int add_h, int add_w,
                          float* part_d, float* colpart_d, size_t part_stride, void* stream);

@@ -905,6 +905,51 @@ def test_backward_pair_with_compact_add_operand(dt, c, shape):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0), (32, 32, 40, 0)],
+                         ids=["one_tile", "small", "capped", "multi_tile", "chip"])
+def test_forward_pair_with_the_projection_shortcut_inside(dt, shape):
+    """urso_conv_pair_shortcut (conv_pairs.hip): mid = relu(src W1^T + b1 + xin Ws^T + bs), dst = relu(mid W2^T + b2) against the CPU fp32
+    reference (mid rounded once; dst from the STORED mid), the emitted ReLU bit mask bit for bit against (stored mid > 0), the variant
+    without a bit mask, and against the two launches it replaces (shortcut conv, then urso_conv_pair), which round the shortcut's
+    output once more.  'capped' / 'multi_tile' / 'chip': several tiles per block through the three-stage input pipeline."""
+    hip = _hip()
+    B, H, W, cap = shape
+    M, c = B * H * W, 64
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + dt + 3)
+    src, xin = dev(torch.randn(M, c), dt), dev(torch.randn(M, c), dt)
+    w1, ws, w2 = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
+    b1, bs, b2 = torch.randn(4 * c, device="cuda") * 0.3, torch.randn(4 * c, device="cuda") * 0.3, torch.randn(c, device="cuda") * 0.3
+    rnd = lambda t: t.to(tdt).float()
+    f = lambda t: t.float().cpu()
+    tol = 1.2e-2 if dt == 1 else 1.5e-3
+    mid = torch.full((M, 4 * c), 9.0, device="cuda").to(tdt); dst = torch.full((M, c), 9.0, device="cuda").to(tdt)
+    bits = torch.full((M, c // 2), 0xAA, dtype=torch.uint8, device="cuda")
+    mid_nb, dst_nb = torch.empty_like(mid), torch.empty_like(dst)
+    with hip.options(grid_cap=cap):
+        hip.conv_pair_shortcut(M, dt, src, w1, b1, xin, ws, bs, bits, mid, w2, b2, dst)
+        hip.conv_pair_shortcut(M, dt, src, w1, b1, xin, ws, bs, None, mid_nb, w2, b2, dst_nb)
+    torch.cuda.synchronize()
+    assert torch.equal(mid, mid_nb) and torch.equal(dst, dst_nb)
+    ref_mid = rnd(torch.relu(f(src) @ f(w1).T + b1.cpu() + f(xin) @ f(ws).T + bs.cpu()))
+    assert float((f(mid) - ref_mid).abs().max()) <= tol * max(1.0, float(ref_mid.abs().max()))
+    ref_dst = rnd(torch.relu(f(mid) @ f(w2).T + b2.cpu()))
+    assert float((f(dst) - ref_dst).abs().max()) <= tol * max(1.0, float(ref_dst.abs().max()))
+    pos = (mid.float() > 0).reshape(-1, 8).to(torch.int32)
+    exp = (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits.reshape(-1), exp) and 0.2 < float(pos.float().mean()) < 0.8
+    g1 = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1)
+    sc, m2, d2 = torch.empty_like(mid), torch.empty_like(mid), torch.empty_like(dst)
+    hip.conv_igemm_ex(g1, dt, 0, xin, ws, bs, None, None, sc, None)
+    hip.conv_pair(M, c, dt, 0, src, w1, b1, sc, None, m2, w2, b2, None, d2)
+    torch.cuda.synchronize()
+    assert float((mid.float() - m2.float()).abs().max()) <= 2 * tol * float(m2.float().abs().max())
+    assert float((dst.float() - d2.float()).abs().max()) <= 3 * tol * float(d2.float().abs().max())
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_pair_shortcut(M + 1, dt, src, w1, b1, xin, ws, bs, None, mid, w2, b2, dst)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("compact", [False, True], ids=["dense_add", "compact_add"])
 @pytest.mark.parametrize("shape", [(1, 8, 8, 0), (2, 8, 24, 0), (4, 64, 80, 8), (8, 64, 80, 0), (32, 64, 80, 0)],
                          ids=["one_tile", "few_tiles", "capped", "multi_tile", "chip"])

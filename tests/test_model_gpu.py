@@ -558,8 +558,8 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
     """Engine plan with the stage-2 and stage-3 pointwise pairs fused (urso_conv_pair, default) against the plan with every layer
-    launched on its own (option pair=0): same outputs and losses up to the rounding flips of the fused layers' outputs, ten launches
-    fewer (five forward pairs, five backward pairs in ResNet-50)."""
+    launched on its own (option pair=0): same outputs and losses up to the rounding flips of the fused layers' outputs, eleven launches
+    fewer (five forward pairs -- the first with res2a_branch1 inside, urso_conv_pair_shortcut -- and five backward pairs in ResNet-50)."""
     from ursonet_amd import hip
     from ursonet_amd.engine import Engine
     cfg = make_config("resnet50", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
@@ -570,9 +570,10 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
             eng = Engine(cfg, "training", seed=5, randomize_bn=True)
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
-                    sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l)))
+                    sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l), list(eng.shortcut_folded)))
     assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
-    assert res[1][0] - res[0][0] == 5 and res[0][6] == 5 and res[1][6] == 0        # five fused launches forward, five backward
+    # five fused launches forward (plus the stage-2 projection shortcut, computed inside the first of them), five backward
+    assert res[1][0] - res[0][0] == 6 and res[0][6] == 5 and res[1][6] == 0 and res[0][7] == ["res2a_branch1"] and res[1][7] == []
     tol_out = 2e-2 if dtype == "bfloat16" else 4e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])

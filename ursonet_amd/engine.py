@@ -728,6 +728,7 @@ class Engine(object):
         the second layer reads it from LDS.  self.pair_first maps the second layer's name to the first layer's _Conv; the backward
         plan mirrors the fusion for the two data gradients.  URSO_OPT_PAIR=0 (hip.options(pair=0)) keeps the layers apart."""
         self.pair_first = {}
+        self.shortcut_folded = []          # projection shortcuts computed inside a fused forward pair (conv_pairs.hip)
         g, dt = self.graph, self.dt
         if dt == hip.F32 or not hip.get_option("pair"):
             return
@@ -747,9 +748,26 @@ class Engine(object):
             if not (a_node.cin == b_node.cout and hip.conv_pair_ok(M, dt, a_node.cin, a_node.cout)):
                 continue
             A.Mpix = M
-            self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc: hip.conv_pair(A.Mpix, A.node.cin, dt, 0, A.src.data, A.wf, A.biasf, A.res.data, A.dst.bits,
-                                                                         A.dst.data, Bc.wf, Bc.biasf, None, Bc.dst.data))
-            self.labels["fwd"][A.fwd_index] = "fwd:%s+%s" % (a_node.name, b_node.name)
+            # the residual operand of a stage's first block is its projection shortcut (a conv without activation, net.py:121-126): where
+            # that is a plain 64 -> 256 pointwise layer with no other reader (stage 2) it becomes 64 more columns of the pair's first
+            # GEMM (conv_pairs.hip) -- its own launch and its output tensor disappear; the backward plan never read that tensor
+            S = [self.convs[n.name] for n in convs if n.dst.id == a_node.residual.id]
+            readers = [n for n in g.nodes if (n.op == "pool" and n.src.id == a_node.residual.id) or
+                       (n.op != "pool" and (n.src.id == a_node.residual.id or (n.residual is not None and n.residual.id == a_node.residual.id)))]
+            if (len(S) == 1 and hip.get_option("pair") in (1, 2) and a_node.cin == 64 and M % 64 == 0 and len(readers) == 1 and
+                    (lambda n, c: not n.stem and not n.dense and n.kh == 1 and n.kw == 1 and n.stride == 1 and not n.relu and not n.out_f32 and
+                     n.residual is None and n.cin == 64 and n.cout == a_node.cout and not c.batch_bn and c.npad == c.N and
+                     hasattr(c, "fwd_index"))(S[0].node, S[0])):
+                Sc = S[0]
+                self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc, Sc=Sc: hip.conv_pair_shortcut(
+                    A.Mpix, dt, A.src.data, A.wf, A.biasf, Sc.src.data, Sc.wf, Sc.biasf, A.dst.bits, A.dst.data, Bc.wf, Bc.biasf, Bc.dst.data))
+                self.labels["fwd"][A.fwd_index] = "fwd:%s+%s+%s" % (a_node.name, Sc.name, b_node.name)
+                drop.append(Sc.fwd_index)
+                self.shortcut_folded.append(Sc.name)
+            else:
+                self.fwd_ops[A.fwd_index] = (lambda A=A, Bc=Bc: hip.conv_pair(A.Mpix, A.node.cin, dt, 0, A.src.data, A.wf, A.biasf, A.res.data, A.dst.bits,
+                                                                             A.dst.data, Bc.wf, Bc.biasf, None, Bc.dst.data))
+                self.labels["fwd"][A.fwd_index] = "fwd:%s+%s" % (a_node.name, b_node.name)
             drop.append(Bc.fwd_index)
             self.pair_first[b_node.name] = A
         for i in sorted(drop, reverse=True):

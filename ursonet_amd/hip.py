@@ -113,6 +113,7 @@ _SIGS = {
     "urso_comm_destroy": (_i, [_vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
+    "urso_conv_pair_shortcut": (_i, [C.c_longlong, _i, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _vp, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
@@ -411,6 +412,12 @@ def conv_pair(M, c_narrow, dt, mode, src, w1, bias1, add, bits, mid, w2, bias2, 
     ah, aw = add_hw if add_hw else (0, 0)
     _chk(_lib.urso_conv_pair(int(M), int(c_narrow), dt, int(mode), ptr(src), ptr(w1), ptr(bias1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(bias2),
                              ptr(mask2), ptr(dst), int(ah), int(aw), stream_ptr(stream)), "urso_conv_pair")
+
+
+def conv_pair_shortcut(M, dt, src, w1, bias1, xin, ws, bias_s, bits, mid, w2, bias2, dst, stream=None):
+    """urso_conv_pair_shortcut: mid = relu(src W1^T + bias1 + xin Ws^T + bias_s), dst = relu(mid W2^T + bias2) (64 / 256 channels)."""
+    _chk(_lib.urso_conv_pair_shortcut(int(M), dt, ptr(src), ptr(w1), ptr(bias1), ptr(xin), ptr(ws), ptr(bias_s), ptr(bits), ptr(mid), ptr(w2),
+                                      ptr(bias2), ptr(dst), stream_ptr(stream)), "urso_conv_pair_shortcut")
 
 
 def conv_pair_wgrad_splits(M, dt):
