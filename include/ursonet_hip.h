@@ -160,6 +160,12 @@ int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, v
  * s < urso_conv_pair_wgrad_splits(M, dt) (0: the shape does not qualify); the batched split reduction (urso_param_batch_run) or
  * any sum over s finishes them.  add_h / add_w as in urso_conv_pair. */
 int urso_conv_pair_wgrad_splits(long long M, int dt);
+/* One 64 -> 256 pointwise layer (stride 1), BOTH gradients from a single pass over its output gradient dz [M][256] (conv_pairw.hip,
+ * single-layer form): dx = dz Wd^T [M][64] (wd_d: the layer's data-gradient filter [64][256]; mask_by_x != 0: zero where x <= 0) and the
+ * per-block fp32 partials of dW[64][256] = x^T dz, colsum[256], in the layout / split count of urso_conv_pair_wgrad.  Replaces a
+ * urso_conv_igemm_ex + urso_conv_wgrad_partial pair that would each read dz (the stage-2 projection shortcut 'res2a_branch1'). */
+int urso_conv_dgrad_wgrad_pw(long long M, int dt, const void* dz_d, const void* wd_d, const void* x_d, int mask_by_x, void* dx_d,
+                             float* part_d, float* colpart_d, size_t part_stride, void* stream);
 /* The stage-2 forward pair at the end of the stage's FIRST block with the projection shortcut computed in place (conv_pairs.hip):
  *     mid = relu(src W1^T + bias1 + xin Ws^T + bias_s);   dst = relu(mid W2^T + bias2)
  *     = 'res2a_branch2c' + BatchNorm, 'res2a_branch1' + BatchNorm, Add, ReLU (net.py:121-157), then 'res2b_branch2a' + BatchNorm + ReLU;

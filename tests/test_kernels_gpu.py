@@ -996,6 +996,22 @@ def test_backward_pair_that_also_accumulates_the_weight_gradient(dt, shape, comp
     assert float((cs - cs2.double()).abs().max()) <= 2e-5 * float(ref_cs.abs().max()) + 1e-4
     with pytest.raises(hip.UrsoHipError):
         hip.conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst, part, colpart, c * 4 * c - 1, add_hw=hw)   # partials would overlap
+    if not compact:
+        # single-layer form: both gradients of a 64 -> 256 layer from one pass over dz (here dz = mid, x = u), masked and unmasked
+        for masked in (1, 0):
+            dx = torch.full((M, c), 5.0, device="cuda").to(tdt)
+            part.fill_(float("nan")); colpart.fill_(float("nan"))
+            with hip.options(grid_cap=cap):
+                hip.conv_dgrad_wgrad_pw(M, dt, mid, w2, u, masked, dx, part, colpart, stride)
+            g2 = hip.geom(B, H, W, 4 * c, H, W, c, 1, 1)
+            dx2 = torch.empty_like(dx)
+            hip.conv_igemm_ex(g2, dt, 0, mid, w2, None, None, u if masked else None, dx2)
+            torch.cuda.synchronize()
+            assert torch.equal(dx, dx2) and (not masked or torch.equal(dx, dst))
+            dw3 = part.reshape(splits, stride)[:, :c * 4 * c].double().sum(0).reshape(c, 4 * c)
+            cs3 = colpart.reshape(splits, 4 * c).double().sum(0)
+            assert float((dw3 - ref_dw).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+            assert float((cs3 - ref_cs).abs().max()) <= 2e-5 * float(ref_cs.abs().max()) + 1e-4
 
 
 @pytest.mark.parametrize("dt", [1, 2])

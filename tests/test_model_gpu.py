@@ -588,7 +588,8 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
     """Option pair = 1 (default) lets the stage-2 backward pairs also accumulate the weight gradient of res2{a,b}_branch2c
-    (urso_conv_pair_wgrad) into those layers' split workspaces; pair = 2 keeps the two weight-gradient launches.  Same forward plan,
+    (urso_conv_pair_wgrad) into those layers' split workspaces, and the projection shortcut res2a_branch1 take both of its gradients from
+    one pass over its output gradient (urso_conv_dgrad_wgrad_pw); pair = 2 keeps the three weight-gradient launches.  Same forward plan,
     bit-identical data gradients: every gradient is equal bit for bit except those two layers' (kernel, folded BatchNorm), which
     differ by the fp32 summation order of a different pixel split only."""
     from ursonet_amd import hip
@@ -600,21 +601,21 @@ def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
         with hip.options(pair=pair):
             eng = Engine(cfg, "training", seed=6, randomize_bn=True)
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
-        res.append((eng.flat_g.clone(), dict(eng.slices), eng.losses(), [l for l in eng.labels["bwd"] if l and "+wgrad:" in l],
-                    sum(1 for l in eng.labels["bwd"] if l and l.startswith("wgrad:"))))
+        res.append((eng.flat_g.clone(), dict(eng.slices), eng.losses(), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+wgrad:" in l],
+                    sum(1 for l in eng.labels["bwd"] if l and l.startswith("wgrad:")), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad+wgrad:")]))
     assert res[0][3] == ["dgrad:res2c_branch2a+res2b_branch2c+wgrad:res2b_branch2c", "dgrad:res2b_branch2a+res2a_branch2c+wgrad:res2a_branch2c"]
-    assert res[1][3] == [] and res[1][4] - res[0][4] == 2
+    assert res[1][3] == [] and res[1][4] - res[0][4] == 3 and res[0][5] == ["dgrad+wgrad:res2a_branch1"] and res[1][5] == []
     assert res[0][2] == res[1][2]
     seen = set()
     for (ln, wn), (o, n, _) in res[0][1].items():
         a, b = res[0][0][o:o + n], res[1][0][o:o + n]
-        if ln.endswith(("2a_branch2c", "2b_branch2c")):           # res2a_branch2c / bn2a_branch2c, res2b_branch2c / bn2b_branch2c
+        if ln.endswith(("2a_branch2c", "2b_branch2c", "2a_branch1")):        # res2a_branch2c / bn2a_branch2c, res2b_..., res2a_branch1 / bn2a_branch1
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, (ln, wn)
             assert float(b.abs().max()) > 0
             seen.add(ln)
         else:
             assert torch.equal(a, b), (ln, wn)
-    assert len(seen) == 4, seen
+    assert len(seen) == 6, seen
 
 
 def test_urso_comm_bucket_averaging_one_rank():

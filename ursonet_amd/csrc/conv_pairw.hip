@@ -24,6 +24,7 @@ struct PairwArgs {
     uint32_t nar_bytes, wide_bytes, bits_bytes, add_bytes;
     int ntiles;
     int sp_h, sp_w; float rcp_hw, rcp_w;
+    int masked;                                      // SOLO: mask dst by u > 0
 };
 
 constexpr int PW_BM = 64, PW_NW = 8, PW_NBUF = 3;
@@ -55,8 +56,11 @@ __device__ __forceinline__ i32x4_t pw_rsrc(const void* p, uint32_t bytes) {
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void pw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename T, bool SPARSE>
+// SOLO: the data gradient and the weight gradient of ONE 64 -> 256 pointwise layer from a single pass over its output gradient (no
+// GEMM 1: `add` IS the 256-channel gradient dz, u the layer's input): dst = dz W2^T (masked by u > 0 if a.masked), dW += u^T dz.
+template <typename T, bool SPARSE, bool SOLO = false>
 __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
+    static_assert(!(SOLO && SPARSE), "the single-layer form takes a dense gradient");
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = PW_BM, NW = PW_NW, NBUF = PW_NBUF;
     __shared__ __attribute__((aligned(1024))) char smem[PW_LDS];
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
     }
     auto dma_tile = [&](int t, int buf) {
         const uint32_t nb = (uint32_t)t * (BM * 128u), wb = (uint32_t)t * (BM * 512u), sb = lds0 + buf * PW_STAGE;
-        pw_dma16(rs, sb + PW_A + wave * 1024, nb + noff);
+        if constexpr (!SOLO) pw_dma16(rs, sb + PW_A + wave * 1024, nb + noff);
         pw_dma16(ru, sb + PW_U + wave * 1024, nb + noff);
         if constexpr (!SPARSE) {
 #pragma unroll
@@ -107,14 +111,16 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
             }
         }
     };
-    constexpr int NDMA = 6, NST = 5, NPRE = 2;
+    constexpr int NDMA = SOLO ? 5 : 6, NST = SOLO ? 1 : 5;
 
     // ---- filters -> registers
     i32x4_t w1f[4], w2f[8];
     {
         const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);        // MFMA row -> channel: a lane's 16 accumulators = 16 consecutive channels
+        if constexpr (!SOLO) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w1f[j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(32 * wave + lg) * 64 + 16 * j + 8 * h) * 2);
+            for (int j = 0; j < 4; ++j) w1f[j] = *(const i32x4_t*)((const char*)a.w1 + ((size_t)(32 * wave + lg) * 64 + 16 * j + 8 * h) * 2);
+        }
         const int mt = wave & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w2f[j] = *(const i32x4_t*)((const char*)a.w2 + ((size_t)(16 * mt + l15) * 256 + 32 * j + 8 * g) * 2);
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
 
     uint32_t pbits[2];
     auto prefetch = [&](int t) {
+        if constexpr (!SOLO)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) pbits[pt] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rbit, (uint32_t)t * (BM * 32u) + pt * 1024u + bitoff, 0, 0);
     };
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
             char* st = smem + buf * PW_STAGE;
 
             // ---- GEMM 1 + epilogue 1 (in place in the add tile): mid = (acc + add) where the bit is set
-            {
+            if constexpr (!SOLO) {
                 f32x16_t acc[2];
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt)
@@ -220,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
                     *(i32x4_t*)(st + (e1[pt] ^ 16u)) = rv[1];
                 }
             }
-            pw_barrier();                                      // (2) mid complete in LDS
-            {   // mid -> HBM, row-contiguous
+            if constexpr (!SOLO) pw_barrier();                 // (2) mid complete in LDS
+            if constexpr (!SOLO) {   // mid -> HBM, row-contiguous
                 const uint32_t wb = (uint32_t)tile * (BM * 512u);
                 i32x4_t v[4];
 #pragma unroll
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
                 T x[8], m[8];
                 __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &m4, 16);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = Elem<T>::to_f(m[e]) > 0.f ? x[e] : Elem<T>::from_f(0.f);
+                for (int e = 0; e < 8; ++e) x[e] = (Elem<T>::to_f(m[e]) > 0.f || (SOLO && !a.masked)) ? x[e] : Elem<T>::from_f(0.f);
                 __builtin_memcpy(&v, x, 16);
                 buf_store16(rdst, (uint32_t)tile * (BM * 128u) + noff, v);
             }
@@ -333,6 +340,7 @@ extern "C" int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, cons
     a.part = part_d; a.colpart = colpart_d; a.part_stride = part_stride;
     a.nar_bytes = (uint32_t)(M * 128); a.wide_bytes = (uint32_t)(M * 512); a.bits_bytes = (uint32_t)(M * 32); a.add_bytes = (uint32_t)(M / 4 * 512);
     a.ntiles = (int)(M / PW_BM);
+    a.masked = 1;
     a.sp_h = add_h; a.sp_w = add_w; a.rcp_hw = sparse ? 1.0f / (float)(add_h * add_w) : 0.f; a.rcp_w = sparse ? 1.0f / (float)add_w : 0.f;
     const double flops = 2.0 * (double)M * 64 * 256 * 3.0;
     const double bytes = (double)M * (3.0 * 128 + (sparse ? 1.25 : 2.0) * 512 + 32);
@@ -341,4 +349,28 @@ extern "C" int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, cons
     if (dt == URSO_BF16) { if (sparse) hipLaunchKernelGGL((pairw_kernel<__bf16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairw_kernel<__bf16, false>), grid, blk, 0, st, a); }
     else { if (sparse) hipLaunchKernelGGL((pairw_kernel<_Float16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairw_kernel<_Float16, false>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_conv_pair_wgrad");
+}
+
+// One 64 -> 256 pointwise layer, both gradients from one pass over dz [M][256]: dx = dz Wd^T (optionally masked by x > 0) and the
+// per-block fp32 partials of dW[64][256] = x^T dz and colsum[256] (layout and split count of urso_conv_pair_wgrad).
+extern "C" int urso_conv_dgrad_wgrad_pw(long long M, int dt, const void* dz_d, const void* wd_d, const void* x_d, int mask_by_x, void* dx_d,
+                                        float* part_d, float* colpart_d, size_t part_stride, void* stream) {
+    const int splits = urso_conv_pair_wgrad_splits(M, dt);
+    if (!splits) { urso_set_error("urso_conv_dgrad_wgrad_pw: needs a 16-bit dt, M %% 64 == 0, tensors < 2 GiB"); return URSO_EINVAL; }
+    if (!dz_d || !wd_d || !x_d || !dx_d || !part_d || part_stride < 64 * 256 ||
+        ((((uintptr_t)dz_d) | ((uintptr_t)wd_d) | ((uintptr_t)x_d) | ((uintptr_t)dx_d)) & 15)) {
+        urso_set_error("urso_conv_dgrad_wgrad_pw: bad argument"); return URSO_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    PairwArgs a;
+    a.src = x_d; a.w1 = wd_d; a.add = dz_d; a.bits = dz_d; a.mid = dx_d; a.w2 = wd_d; a.u = x_d; a.dst = dx_d;
+    a.part = part_d; a.colpart = colpart_d; a.part_stride = part_stride;
+    a.nar_bytes = (uint32_t)(M * 128); a.wide_bytes = (uint32_t)(M * 512); a.bits_bytes = 0; a.add_bytes = 0;
+    a.ntiles = (int)(M / PW_BM);
+    a.sp_h = a.sp_w = 0; a.rcp_hw = a.rcp_w = 0.f; a.masked = mask_by_x ? 1 : 0;
+    ProfScope ps(st, URSO_K_IGEMM, 2.0 * (double)M * 64 * 256 * 2.0, (double)M * (2.0 * 128 + 512));
+    const dim3 grid(splits), blk(512);
+    if (dt == URSO_BF16) hipLaunchKernelGGL((pairw_kernel<__bf16, false, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((pairw_kernel<_Float16, false, true>), grid, blk, 0, st, a);
+    return urso_check_launch("urso_conv_dgrad_wgrad_pw");
 }

@@ -418,8 +418,20 @@ class Engine(object):
                 self.labels["bwd"].append("finalize:" + node.name)
             elif tr or bn_tr:
                 d = c.desc
+                # a 64 -> 256 pointwise layer outside the pairs (the stage-2 projection shortcut) whose data gradient is the first
+                # contribution to its input's gradient: both gradients in one pass over dz (urso_conv_dgrad_wgrad_pw)
+                Xs = c.src
+                Ms = B * node.dst.h * node.dst.w
+                c.solo = (hip.get_option("pair") == 1 and dt != hip.F32 and not node.dense and node.kh == 1 and node.kw == 1 and node.stride == 1 and
+                          node.cin == 64 and c.npad == 256 and c.N == 256 and not c.batch_bn and need[Xs.spec.id] and
+                          not getattr(c, "wgrad_by_pair", False) and not getattr(c, "dgrad_done_by_pair", False) and
+                          getattr(c, "gf_compact", None) is None and c.dst.compact is None and Xs.compact is None and not getattr(c, "gd_scatter", False) and
+                          not Xs.grad_written and Xs.pending is None and self.pair_first.get(node.name) is None and node.name not in last_of_group and
+                          hip.conv_pair_wgrad_splits(Ms, dt) > 1)
+                if c.solo:
+                    c.splits = c.desc.splits = hip.conv_pair_wgrad_splits(Ms, dt)
                 n_part = c.splits * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
-                by_pair = getattr(c, "wgrad_by_pair", False)           # partials written by the fused backward pair of the layer above
+                by_pair = getattr(c, "wgrad_by_pair", False) or c.solo   # partials written by a fused launch (the pair of the layer above / below)
                 c.wg_npart = n_part
                 c.wg_ws = torch.empty((n_part + c.splits * c.npad if by_pair else hip.conv_wgrad_ws_bytes(gf_w, dt) // 4) + 64,
                                       dtype=torch.float32, device=dev)
@@ -465,6 +477,15 @@ class Engine(object):
             if not node.stem and need[c.src.spec.id]:
                 X = c.src
                 add = X.grad if X.grad_written else X.pending
+                if getattr(c, "solo", False):
+                    assert add is None
+                    dstg = X.grad_buf()
+                    self.bwd_ops.append((node.name, lambda c=c, G=G, X=X, dstg=dstg, Ms=B * node.dst.h * node.dst.w:
+                                         hip.conv_dgrad_wgrad_pw(Ms, dt, G, c.wd, X.data, X.spec.relu, dstg, c.wg_ws, c.wg_ws[c.wg_npart:],
+                                                                 c.K_raw * c.npad + hip.WGRAD_PART_PAD)))
+                    self.labels["bwd"].append("dgrad+wgrad:" + node.name)
+                    X.grad_written = True
+                    continue
                 if X.compact is not None:
                     # stride-2 pointwise consumer of a block output whose gradient is kept compact: a plain pointwise GEMM over the
                     # sampled pixels (no scatter, no zero fill of a dense tensor), masked with the sampled rows of X's ReLU bit mask

@@ -114,6 +114,7 @@ _SIGS = {
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
     "urso_conv_pair_shortcut": (_i, [C.c_longlong, _i, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _vp, _vp]),
+    "urso_conv_dgrad_wgrad_pw": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _fp, _fp, _sz, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
@@ -418,6 +419,12 @@ def conv_pair_shortcut(M, dt, src, w1, bias1, xin, ws, bias_s, bits, mid, w2, bi
     """urso_conv_pair_shortcut: mid = relu(src W1^T + bias1 + xin Ws^T + bias_s), dst = relu(mid W2^T + bias2) (64 / 256 channels)."""
     _chk(_lib.urso_conv_pair_shortcut(int(M), dt, ptr(src), ptr(w1), ptr(bias1), ptr(xin), ptr(ws), ptr(bias_s), ptr(bits), ptr(mid), ptr(w2),
                                       ptr(bias2), ptr(dst), stream_ptr(stream)), "urso_conv_pair_shortcut")
+
+
+def conv_dgrad_wgrad_pw(M, dt, dz, wd, x, mask_by_x, dx, part, colpart, part_stride, stream=None):
+    """urso_conv_dgrad_wgrad_pw: dx = dz Wd^T (optionally masked by x > 0) and the split partials of dW = x^T dz, colsum (64 -> 256 layer)."""
+    _chk(_lib.urso_conv_dgrad_wgrad_pw(int(M), dt, ptr(dz), ptr(wd), ptr(x), int(bool(mask_by_x)), ptr(dx), ptr(part), ptr(colpart),
+                                       int(part_stride), stream_ptr(stream)), "urso_conv_dgrad_wgrad_pw")
 
 
 def conv_pair_wgrad_splits(M, dt):
