@@ -183,8 +183,15 @@ int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_
 int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
- * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel). */
+ * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel).  Given a workspace of
+ * urso_conv_igemm_halo_ws_bytes() through ws_d, that kernel balances the chip where whole tiles do not (e.g. 340 tiles on 256 CUs):
+ * the (tile, 64-channel chunk) units of the layer are dealt to one block per CU in equal contiguous runs ("stream-K"); a tile cut by
+ * a run boundary is finished by the block that holds its first chunk, the other pieces hand over fp32 accumulators, added in a
+ * fixed order (deterministic, reproducible from launch to launch).  CONTRACT: the first 4 KiB of that workspace are hand-over flags
+ * -- zero on entry, left zero on return; a workspace shared with other entry points must be re-zeroed before the call.  Without a
+ * workspace every block walks whole tiles. */
 int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_add);
+size_t urso_conv_igemm_halo_ws_bytes(void);
 
 /*
  * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):

@@ -216,6 +216,52 @@ def test_halo_conv_kernel_forced(case, dt, cap):
         test_conv_forward_and_gradients(case, dt)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(8, 64, 80, 128, 128, 0), (16, 32, 40, 256, 256, 0), (32, 16, 20, 512, 512, 0), (2, 32, 40, 128, 256, 8),
+                                   (3, 19, 23, 128, 128, 24), (32, 32, 40, 256, 256, 0), (4, 16, 20, 512, 128, 40)])
+def test_halo_conv_stream_k_schedule(shape, dt):
+    """conv_halo.hip with its hand-over workspace (urso_conv_igemm_ws + urso_conv_igemm_halo_ws_bytes): the layer's (tile, 64-channel
+    chunk) units are dealt to the blocks in equal contiguous runs, tiles cut by a run boundary are completed from fp32 partial
+    accumulators in a fixed order.  Against the CPU fp32 conv at the kernel tolerance, against the whole-tile schedule of the same
+    kernel (which differs only in where the fp32 sum is split), twice in a row on the same workspace (the flags must come back zero),
+    forward with ReLU and data-gradient form with a mask.  Shapes: tiles spanning 2 and 3 runs, runs spanning several tiles, several
+    filter tiles per pixel tile, ragged sizes, capped grids; hconv_dbg = 8 engages the schedule also where the policy would keep whole
+    tiles, the stage-4 / stage-5 shapes of cfg2 (16 / 32 x ... x 256 / 512) engage it by policy."""
+    hip = _hip()
+    B, H, W, Ci, N, cap = shape
+    torch.manual_seed(B * 7 + H + Ci)
+    tdt = hip.TORCH_DT[dt]
+    x = rnd(torch.randn(B, H, W, Ci), dt)
+    w = torch.randn(3, 3, Ci, N) / np.sqrt(9 * Ci)
+    bias = torch.randn(N) * 0.1
+    msk = rnd(torch.randn(B, H, W, N), dt)
+    wf, wd, biasf, _ = prep_weights(w, dt, bias, None)
+    g = hip.geom(B, H, W, Ci, H, W, N, 3, 3, 1, 1, 1, 1)
+    z = _ref_conv(x, rnd(w, dt), 1, (1, 1), H, W) + bias
+    ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, dtype=torch.float32, device="cuda")
+    xd, md = dev(x, dt), dev(msk, dt)
+    with hip.options(hconv=2, grid_cap=cap, c3=0):
+        assert hip.conv_igemm_halo_ok(g, dt, hip.EPI_RELU)
+        y0 = torch.empty(B, H, W, N, dtype=tdt, device="cuda")
+        hip.conv_igemm(g, dt, hip.EPI_RELU, xd, wf, biasf, None, None, y0)                       # whole tiles per block
+        outs = []
+        for force in (8, 8, 0):
+            with hip.options(hconv_dbg=force):
+                y = torch.full((B, H, W, N), 3.0, dtype=tdt, device="cuda")
+                hip.conv_igemm_ws(g, dt, hip.EPI_RELU, xd, wf, biasf, None, None, y, ws)       # stream-K (forced, forced again, by policy)
+                torch.cuda.synchronize()
+            assert int(ws[:1024].view(torch.int32).abs().max()) == 0, "hand-over flags not left zero"
+            outs.append(y)
+        ym = torch.empty_like(y0)
+        with hip.options(hconv_dbg=8):
+            hip.conv_igemm_ws(g, dt, 0, xd, wf, biasf, None, md, ym, ws)                        # no ReLU, mask
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), "stream-K result is not reproducible"
+    assert relerr(outs[0], F.relu(z)) < TOL[dt] and relerr(outs[2], F.relu(z)) < TOL[dt]
+    assert relerr(outs[0], y0.float()) < 0.5 * TOL[dt]
+    assert relerr(ym, z * (msk > 0)) < TOL[dt]
+
+
 def test_wgrad_split_plan_reaches_its_resident_block_target():
     """The 16-bit weight-gradient kernels split the pixel dimension over one resident wave of blocks (512, x1.5 for the
     narrow tile): the full-size cases above must actually run with hundreds of splits ('wgrad at splits == 512')."""

@@ -40,7 +40,13 @@ struct HcArgs {
     int krow;                  // bytes per filter row (9 * C * 2)
     float rcp_vw, rcp_vh;
     int relu;
-    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop
+    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop, bit 2 whole tiles only, bit 3 stream-K whenever a workspace is given
+    // schedule: every block owns a contiguous run of (tile, 64-channel chunk) units, run b = [floor(b units / G), ...).  Without a
+    // hand-over workspace (flags == NULL) the units are whole tiles; with one ("stream-K") a tile cut by a run boundary is finished by
+    // the block that holds its chunk 0, the other pieces hand their fp32 accumulators over through `part` in run order
+    int units;
+    unsigned int* flags;       // [gridDim.x] hand-over flags, zero on entry and on exit
+    float* part;               // [gridDim.x][512 threads][64] fp32 partial accumulators
 };
 
 template <typename T> struct Mma32;
@@ -80,6 +86,7 @@ __device__ __forceinline__ int hc_perm(int rho) {
 
 constexpr int HC_BM = 256, HC_BN = 128, HC_BSLOT = HC_BN * 128, HC_AROWS = 424, HC_ABUF = HC_AROWS * 128;
 constexpr int HC_AOFF = 3 * HC_BSLOT, HC_XOFF = HC_AOFF + 2 * HC_ABUF, HC_LDS = 163840, HC_MAXN = (HC_LDS - HC_XOFF) / 4;
+constexpr int HC_SC = 17;                                   // buffer cache policy sc0 | sc1: system-coherent (through the L2s to memory)
 constexpr int HC_NST = 8;                                  // vector-memory stores per lane of one epilogue
 
 __device__ __forceinline__ void hc_sbarrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -98,8 +105,13 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     // ---- this block's contiguous run of tiles; logical ids are XCD-contiguous so that neighbouring runs (which share halo rows and,
     //      with several filter tiles per pixel tile, the whole pixel tile) meet in one L2
     const int G = gridDim.x, lid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int t_begin = (int)(((long long)lid * a.ntiles) / G), t_end = (int)(((long long)(lid + 1) * a.ntiles) / G);
-    if (t_begin >= t_end) return;
+    auto run_begin = [&](int b) -> int {                       // in (tile, chunk) units; floor(b units / G): long and short runs alternate,
+        const int u = (int)(((long long)b * a.units) / G);    // so that no XCD (logical ids are XCD-contiguous) collects the long ones
+        return a.flags ? u : u * a.nchunks;
+    };
+    const int g0 = run_begin(lid), g1 = run_begin(lid + 1);
+    if (g0 >= g1) return;
+    const int t_begin = g0 / a.nchunks, c_begin = g0 - t_begin * a.nchunks;
 
     const i32x4_t rs = hc_rsrc(a.src, a.src_bytes), rw = hc_rsrc(a.wgt, a.wgt_bytes);
     const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? a.dst_bytes : 0u);
@@ -173,9 +185,9 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     {   // ---- block prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
         const int n0 = (tile % a.tilesN) * BN;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) dma_a(j, 0, 0);
-        dma_b(n0, 0, 0, 0);
-        dma_b(n0, 0, 1, 1);
+        for (int j = 0; j < 7; ++j) dma_a(j, c_begin, 0);
+        dma_b(n0, c_begin, 0, 0);
+        dma_b(n0, c_begin, 1, 1);
         hc_wait_vm<0>();
         hc_barrier();                                         // also publishes the bias written above
     }
@@ -189,8 +201,13 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     };
     rd(fw0, fp0, 0, AOFF, 0, 0);                              // step 0, k = 0
 
+    int gcur = g0;
+    bool stores_pending = false;                               // the previous part ended with a normal epilogue (HC_NST stores in flight)
     while (true) {
-        const bool has_next = tile + 1 < t_end;
+        // this part of the run: chunks [cbeg, cend) of `tile`; only a run's first part can start past chunk 0, only its last can stop early
+        const int cbeg = gcur - tile * a.nchunks;
+        const int cend = min(a.nchunks, cbeg + (g1 - gcur));
+        const bool has_next = gcur + (cend - cbeg) < g1;
         const int p0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
         const int n0n = ((tile + 1) % a.tilesN) * BN;
         f32x16_t acc[2][2];
@@ -201,13 +218,13 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int cc = 0; cc < ((a.dbg & 2) ? 0 : a.nchunks); ++cc) {
-            const bool last = cc + 1 == a.nchunks;
+        for (int cc = cbeg; cc < ((a.dbg & 2) ? cbeg : cend); ++cc) {
+            const bool last = cc + 1 == cend;
             if (last && has_next) set_arow(tile + 1);          // from here on the halo copies target the next tile's chunk 0
             const bool more_a = !last || has_next;
             const int cca = last ? 0 : cc + 1;
             const uint32_t abase = AOFF + buf * ABUF, abase_n = AOFF + (buf ^ 1) * ABUF;
-            const bool first_wait_after_epilogue = cc == 0 && tile != t_begin && !(a.dbg & 1);
+            const bool first_wait_after_epilogue = cc == cbeg && stores_pending && !(a.dbg & 1);
             // the read addresses are functions of (lane, tap) only: keep the compiler from hoisting all 9 x 2 x 4 of them out of the
             // chunk loop into registers (it then spills the accumulators)
             asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(boff[0]), "+v"(boff[1]));
@@ -266,7 +283,62 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
         // ---- epilogue: + bias -> ReLU -> 16-bit, transposed through LDS (this wave's 4 KiB of the halo buffer that has just been
         //      retired: nothing is copied into it before the next mid-step barrier) so that every store instruction writes whole
         //      128-byte lines; the mask is applied after the transposition, read with the same coalesced addresses
-        if (!(a.dbg & 1)) {
+        const bool head = cbeg == 0, tile_done = cend == a.nchunks;
+        stores_pending = false;
+        // lane-derived values of the hand-over code are re-materialised behind an opaque asm: it is loop-invariant address arithmetic
+        // that the compiler would otherwise hoist out of the step loop and keep in registers next to the accumulators (spills)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        if (!head) {
+            // ---- a later piece of a tile that an earlier run finishes: hand the accumulators over (plain stores -> every wave drains
+            //      them -> one lane: agent-scope release, relaxed flag store)
+            //      The payload goes out with sc0 sc1 (write-through to memory) and is read back with sc0 sc1 (the reader's L2 -- another
+            //      XCD's -- is bypassed): no release / acquire fence, which at agent scope would write back and invalidate a whole L2
+            //      that every other block of the XCD is working out of (measured: the fenced form ate the whole gain)
+            const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.part + (size_t)lid * (512 * 64), 512 * 64 * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t v = f32x4_t{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rp, (uint32_t)((((i * 2 + j) * 4 + q) * 512 + tid_e) * 16), 0, HC_SC);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid_e == 0) __hip_atomic_store(a.flags + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!tile_done) {
+            // ---- the tile continues in the following run(s): add their accumulators in run order (fixed order: deterministic).  Those
+            //      runs BEGIN with their piece of this tile, this run ENDS with its own: the wait is short.  The spin is bounded so that
+            //      a scheduling accident shows up as a wrong result in the tests, never as a hung device
+            const int fin = (tile + 1) * a.nchunks;
+            for (int b = lid + 1; b < G && run_begin(b) < fin; ++b) {
+                if (run_begin(b) == run_begin(b + 1)) continue;              // an empty run hands nothing over
+                if (tid_e == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(a.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
+                        __builtin_amdgcn_s_sleep(8);
+                }
+                __syncthreads();
+                const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.part + (size_t)b * (512 * 64), 512 * 64 * 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp, (uint32_t)((((i * 2 + j) * 4 + q) * 512 + tid_e) * 16), 0, HC_SC));
+                            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                            if (q & 1) __builtin_amdgcn_sched_barrier(0);      // 8 registers of loads in flight at a time, not 64
+                        }
+                    }
+                __syncthreads();
+                if (tid_e == 0) __hip_atomic_store(a.flags + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+            }
+        }
+        if (head && !(a.dbg & 1)) {
+            stores_pending = true;
             const uint32_t sbase = AOFF + (buf ^ 1) * ABUF + wave * 4096;
             int vx, vy, vb;                                   // virtual coordinates of this lane's first store pixel
             {
@@ -320,6 +392,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
             }
         }
         if (!has_next) break;
+        gcur += cend - cbeg;
         ++tile;
     }
 }
@@ -355,8 +428,12 @@ bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add
     return true;
 }
 
+// hand-over workspace of the stream-K schedule: 4 KiB of flags (zero on entry, left zero) + one 128 KiB accumulator slab per block
+size_t urso_hconv_ws_bytes() { return 4096 + (size_t)hc_device_cus() * 512 * 64 * sizeof(float); }
+
 int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
-                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st) {
+                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
     (void)add;
     HcArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
@@ -374,6 +451,15 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);
+    // stream-K needs every block resident (a finishing block waits for the pieces of the runs that follow it): one block per CU, never
+    // more blocks than CUs (and than flags); it is used where it shortens the longest run: ceil(tiles x chunks / blocks) chunk units
+    // against ceil(tiles / blocks) whole tiles (cfg2: stage 4 6 vs 8, stage 5 6 vs 8, stage 3 6 vs 6 -> whole tiles)
+    const int G = (int)grid.x;
+    const bool can = ws && ws_bytes >= urso_hconv_ws_bytes() && G <= hc_device_cus() && G <= 1024 && !(a.dbg & 4);
+    const bool streamk = can && ((a.dbg & 8) || ceil_div(a.ntiles * a.nchunks, G) < ceil_div(a.ntiles, G) * a.nchunks);      // hconv_dbg bit 3: whenever a workspace is given (tests)
+    a.flags = streamk ? (unsigned int*)ws : nullptr;
+    a.part = streamk ? (float*)((char*)ws + 4096) : nullptr;
+    a.units = streamk ? a.ntiles * a.nchunks : a.ntiles;
     if (dt == URSO_BF16) hipLaunchKernelGGL((hconv_kernel<__bf16>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((hconv_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(halo)");

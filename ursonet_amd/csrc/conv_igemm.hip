@@ -408,7 +408,9 @@ int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, c
                    void* dst, hipStream_t st);
 bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add);                                                   // conv_halo.hip
 int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
-                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);
+                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
+                      hipStream_t st);
+size_t urso_hconv_ws_bytes();
 
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
@@ -479,6 +481,8 @@ static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* 
 extern "C" int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_add) {
     return (g && urso_hconv_fits(g, dt, flags, has_add ? (const void*)g : nullptr)) ? 1 : 0;
 }
+
+extern "C" size_t urso_conv_igemm_halo_ws_bytes(void) { return urso_hconv_ws_bytes(); }
 
 extern "C" size_t urso_conv_igemm_ws_bytes(const urso_conv_geom* g, int dt) {
     if (!g || g->FH > 0 || (g->N & 3)) return 0;
@@ -570,7 +574,7 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
             return urso_c3_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, mask_d, dst_d, st);
         if (fits && urso_hconv_fits(g, dt, flags, add_d))
             return urso_hconv_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, add_d, mask_d, dst_d,
-                                     a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
+                                     a.src_bytes, a.wgt_bytes, a.dst_bytes, ws_d, ws_bytes, st);
         const int mbits = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;
         void* bout = (flags & URSO_EPI_EMIT_BITS) ? bits_out_d : nullptr;
         const bool taps_ok = (a.Cc & 7) == 0 && g->DH == 1 && g->DW == 1 && g->KH <= 3 && g->KW <= 3;     // whole-tap K-tiles, undilated, <= 3x3

@@ -299,6 +299,12 @@ class Engine(object):
             c.ws_d = hip.conv_igemm_ws_bytes(c.gd, dt) if (c.gd is not None and training) else 0
             max_igemm_ws = max(max_igemm_ws, c.ws_f, c.ws_d)
             c.fwd_flags = flags
+            # 3x3 layers taken by the halo-tile kernel get its stream-K hand-over workspace (dedicated: its first 4 KiB are flags that
+            # must stay zero between launches, include/ursonet_hip.h)
+            c.halo_f = (not c.batch_bn) and dt != hip.F32 and hip.conv_igemm_halo_ok(c.gf, dt, flags, c.res is not None)
+            c.halo_d = bool(c.gd is not None and training and dt != hip.F32 and hip.conv_igemm_halo_ok(c.gd, dt, 0, False))
+            if (c.halo_f or c.halo_d) and getattr(self, "halo_ws", None) is None:
+                self.halo_ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, dtype=torch.float32, device=dev)
             if c.batch_bn:
                 self.fwd_ops.append(lambda c=c: hip.conv_igemm_ex(c.gf, dt, 0, c.src.data, c.wf, c.biasf, None, None, c.z, None,
                                                                   self.igemm_ws if c.ws_f else None))
@@ -313,7 +319,8 @@ class Engine(object):
                 c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
                     c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
-                    c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits, self.igemm_ws if c.ws_f else None))
+                    c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits,
+                    self.halo_ws if c.halo_f else (self.igemm_ws if c.ws_f else None)))
                 self.labels["fwd"].append("fwd:" + node.name)
             if training and node.stem:
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
@@ -535,7 +542,8 @@ class Engine(object):
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg, mflag=mflag:
-                                     hip.conv_igemm_ex(c.gd, dt, mflag, G, c.wd, None, add, mask, dstg, None, self.igemm_ws if c.ws_d else None)))
+                                     hip.conv_igemm_ex(c.gd, dt, mflag, G, c.wd, None, add, mask, dstg, None,
+                                                       self.halo_ws if (c.halo_d and add is None and not mflag) else (self.igemm_ws if c.ws_d else None))))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders

@@ -70,6 +70,7 @@ _SIGS = {
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_igemm_bits_ok": (_i, [_gp, _i, _i, _sz]),
     "urso_conv_igemm_halo_ok": (_i, [_gp, _i, _i, _i]),
+    "urso_conv_igemm_halo_ws_bytes": (_sz, []),
     "urso_conv_igemm_ex": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_wgrad": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
@@ -216,6 +217,11 @@ def conv_igemm_ws(g, dt, flags, src, wgt, bias, add, mask, dst, ws, stream=None)
 
 def conv_igemm_bits_ok(g, dt, flags, ws_bytes=0):
     return bool(_lib.urso_conv_igemm_bits_ok(C.byref(g), dt, flags, ws_bytes))
+
+
+def conv_igemm_halo_ws_bytes():
+    """Hand-over workspace of the halo-tile kernel's stream-K schedule; its first 4 KiB (flags) must be zero on entry (left zero)."""
+    return int(_lib.urso_conv_igemm_halo_ws_bytes())
 
 
 def conv_igemm_halo_ok(g, dt, flags, has_add=False):
