@@ -560,7 +560,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
         const int use_pw = g_urso_opt.pw_kernel;     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
-        const bool split = ws_d && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
+        const bool halo_layer = dt != URSO_F32 && urso_hconv_fits(g, dt, flags, add_d);      // its workspace is the hand-over one, never split-K's
+        const bool split = ws_d && !halo_layer && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool wants_bits = (flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) != 0;
         const bool bits_fit = !wants_bits || (a.pointwise && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&
                                               !((flags & URSO_EPI_MASK_BITS) && (!mask_d || (g->N % 32))) && !((flags & URSO_EPI_EMIT_BITS) && !bits_out_d));
