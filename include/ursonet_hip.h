@@ -321,9 +321,11 @@ int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, cons
                      int dt, void* dst_d, void* stream);
 
 /* MaxPooling2D((3,3), strides=(2,2), padding="same") (net.py:176,258), H,W even.
- * fwd also stores the arg-max tap (first maximum in row-major window order, 0..8).
+ * fwd also stores one byte per output element: the arg-max tap (first maximum in row-major window order, 0..8) in bits 0-3 and,
+ * in bit 4, whether the window maximum is <= 0.
  * bwd: dx[b,iy,ix,c] = sum over windows whose arg-max is (iy,ix) of dy; with relu_mask=1 windows
- * whose maximum is <= 0 contribute nothing (the ReLU in front of the pool, net.py:173). */
+ * whose maximum is <= 0 contribute nothing (the ReLU in front of the pool, net.py:173) -- read from bit 4 of the arg-max byte:
+ * y_d is not read (kept in the signature; may be NULL). */
 int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const void* x_d, void* y_d,
                           uint8_t* argmax_d, void* stream);
 int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const void* y_d, const void* dy_d,

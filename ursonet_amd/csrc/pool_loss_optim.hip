@@ -29,7 +29,7 @@ __global__ void maxpool_fwd_kernel(int B, int H, int W, int C, const T* __restri
         }
         T o[VE]; uint8_t ab[VE];
 #pragma unroll
-        for (int q = 0; q < VE; ++q) { o[q] = Elem<T>::from_f(best[q]); ab[q] = (uint8_t)arg[q]; }
+        for (int q = 0; q < VE; ++q) { o[q] = Elem<T>::from_f(best[q]); ab[q] = (uint8_t)(arg[q] | (best[q] > 0.f ? 0 : 16)); }   // bit 4: window maximum <= 0
         i32x4_t ov; __builtin_memcpy(&ov, o, 16);
         const size_t ob = (((size_t)b * OH + oy) * OW + ox) * C + cv * VE;
         *(i32x4_t*)(y + ob) = ov;
@@ -65,14 +65,13 @@ __global__ void maxpool_bwd_kernel(int B, int H, int W, int C, const T* __restri
                 const size_t ob = (((size_t)b * OH + woy) * OW + wox) * C + cv * VE;
                 uint8_t ab[VE]; __builtin_memcpy(ab, am + ob, VE);
                 i32x4_t rd = *(const i32x4_t*)(dy + ob); T ed[VE]; __builtin_memcpy(ed, &rd, 16);
-                T ey[VE];
-                if (relu_mask) { i32x4_t ry = *(const i32x4_t*)(y + ob); __builtin_memcpy(ey, &ry, 16); }
+
                 // window row ky lands on block row r when 2*woy + ky == 2*oy + r: this window (wy) sees block rows
                 // r = ky - 2*wy, i.e. wy = 0: ky = 0,1 -> r = 0,1;  wy = 1: ky = 2 -> r = 0.  Same for columns.
 #pragma unroll
                 for (int q = 0; q < VE; ++q) {
-                    const float d = (!relu_mask || Elem<T>::to_f(ey[q]) > 0.f) ? Elem<T>::to_f(ed[q]) : 0.f;
-                    const int ky = ab[q] / 3, kx = ab[q] - ky * 3;
+                    const float d = (!relu_mask || !(ab[q] & 16)) ? Elem<T>::to_f(ed[q]) : 0.f;     // the pooled tensor itself is not read
+                    const int tap = ab[q] & 15, ky = tap / 3, kx = tap - ky * 3;
                     const int r = ky - 2 * wy, c = kx - 2 * wx;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g[k][q] += (r == (k >> 1) && c == (k & 1)) ? d : 0.f;
@@ -119,11 +118,11 @@ extern "C" int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const v
 extern "C" int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const void* y_d, const void* dy_d,
                                      const uint8_t* argmax_d, int relu_mask, void* dx_d, void* stream) {
     const int VE = 16 / (int)dt_size(dt);
-    if (!dy_d || !argmax_d || !dx_d || (relu_mask && !y_d) || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_bwd: bad argument"); return URSO_EINVAL; }
+    if (!dy_d || !argmax_d || !dx_d || B <= 0 || (H & 1) || (W & 1) || C % VE) { urso_set_error("urso_maxpool3x3s2_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
     if (total >= 0x7FFFFFFFull) { urso_set_error("urso_maxpool3x3s2_bwd: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
-    ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.5 + (double)B * H * W * C / 4);
+    ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.25 + (double)B * H * W * C / 4);       // dx written, dy + arg-max bytes read
     if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)y_d, (const float*)dy_d, argmax_d, relu_mask, (float*)dx_d);
     else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)y_d, (const __bf16*)dy_d, argmax_d, relu_mask, (__bf16*)dx_d);
     else hipLaunchKernelGGL((maxpool_bwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)y_d, (const _Float16*)dy_d, argmax_d, relu_mask, (_Float16*)dx_d);
