@@ -166,6 +166,15 @@ int urso_conv_pair_wgrad_splits(long long M, int dt);
  * urso_conv_igemm_ex + urso_conv_wgrad_partial pair that would each read dz (the stage-2 projection shortcut 'res2a_branch1'). */
 int urso_conv_dgrad_wgrad_pw(long long M, int dt, const void* dz_d, const void* wd_d, const void* x_d, int mask_by_x, void* dx_d,
                              float* part_d, float* colpart_d, size_t part_stride, void* stream);
+/* The backward pass across the boundary behind stage 2's FIRST block in one launch (conv_pairx.hip): urso_conv_pair_wgrad (mode-1 pair +
+ * weight gradient of 'res2a_branch2c') AND urso_conv_dgrad_wgrad_pw of the projection shortcut 'res2a_branch1' (dxin = mid Ws_d^T, mask_by_xin;
+ * dWs = xin^T mid), where mid -- the gradient w.r.t. the block output -- exists only on chip: it is neither written nor read back (no
+ * mid_d).  ws_d: the shortcut's data-gradient filter [64][256]; xin_d / dxin_d: the block input and its gradient [M][64]; part_s_d /
+ * colpart_s_d: the shortcut's split partials (same layout, stride and split count as part_d / colpart_d).  dst_d / dxin_d are
+ * bit-identical to the two-launch form.  Dense add operand only. */
+int urso_conv_pair_wgrad_entry(long long M, int dt, const void* src_d, const void* w1_d, const void* add_d, const void* bits_d,
+                               const void* w2_d, const void* u_d, void* dst_d, const void* ws_d, const void* xin_d, int mask_by_xin, void* dxin_d,
+                               float* part_d, float* colpart_d, float* part_s_d, float* colpart_s_d, size_t part_stride, void* stream);
 /* The stage-2 forward pair at the end of the stage's FIRST block with the projection shortcut computed in place (conv_pairs.hip):
  *     mid = relu(src W1^T + bias1 + xin Ws^T + bias_s);   dst = relu(mid W2^T + bias2)
  *     = 'res2a_branch2c' + BatchNorm, 'res2a_branch1' + BatchNorm, Add, ReLU (net.py:121-157), then 'res2b_branch2a' + BatchNorm + ReLU;

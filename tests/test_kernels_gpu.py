@@ -1061,6 +1061,51 @@ def test_backward_pair_that_also_accumulates_the_weight_gradient(dt, shape, comp
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (2, 8, 24, 0), (4, 64, 80, 8), (8, 64, 80, 0), (32, 64, 80, 0)],
+                         ids=["one_tile", "few_tiles", "capped", "multi_tile", "chip"])
+def test_backward_pair_of_the_stage_entry_block(dt, shape):
+    """urso_conv_pair_wgrad_entry (conv_pairx.hip) against the two launches it replaces -- urso_conv_pair_wgrad (which writes mid) and
+    urso_conv_dgrad_wgrad_pw on that mid: dst and dxin bit for bit, both layers' summed partials and column sums against the fp64
+    products of the stored tensors; blocks without tiles write zero partials; several tiles per block through the 3-stage / 2-stage
+    input rings ('capped', 'multi_tile', 'chip')."""
+    hip = _hip()
+    B, H, W, cap = shape
+    M, c = B * H * W, 64
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + dt + 11)
+    src, u, xin = dev(torch.randn(M, c), dt), dev(torch.relu(torch.randn(M, c)), dt), dev(torch.relu(torch.randn(M, c)), dt)
+    w1, w2, ws = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
+    add = dev(torch.randn(M, 4 * c), dt)
+    bits = torch.randint(0, 256, (M, c // 2), dtype=torch.uint8, device="cuda")
+    mid = torch.empty(M, 4 * c, dtype=tdt, device="cuda")
+    dst0, dx0 = torch.empty(M, c, dtype=tdt, device="cuda"), torch.empty(M, c, dtype=tdt, device="cuda")
+    dst, dx = torch.full((M, c), 5.0, device="cuda").to(tdt), torch.full((M, c), 5.0, device="cuda").to(tdt)
+    with hip.options(grid_cap=cap):
+        splits = hip.conv_pair_wgrad_splits(M, dt)
+        stride = c * 4 * c + hip.WGRAD_PART_PAD
+        mk = lambda n: torch.full((n,), float("nan"), device="cuda")
+        part0, col0, ps0, cs0 = mk(splits * stride), mk(splits * 4 * c), mk(splits * stride), mk(splits * 4 * c)
+        part, col, ps, cs = mk(splits * stride), mk(splits * 4 * c), mk(splits * stride), mk(splits * 4 * c)
+        hip.conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst0, part0, col0, stride)
+        for masked in (1, 0):
+            hip.conv_dgrad_wgrad_pw(M, dt, mid, ws, xin, masked, dx0, ps0, cs0, stride)
+            hip.conv_pair_wgrad_entry(M, dt, src, w1, add, bits, w2, u, dst, ws, xin, masked, dx, part, col, ps, cs, stride)
+            torch.cuda.synchronize()
+            assert torch.equal(dst, dst0) and torch.equal(dx, dx0)
+            assert masked == 0 or float((dx.float() == 0).float().mean()) > 0.3
+    summed = lambda t: t.reshape(splits, stride)[:, :c * 4 * c].double().sum(0).reshape(c, 4 * c)
+    ref_dw, ref_ds, ref_cs = u.double().T @ mid.double(), xin.double().T @ mid.double(), mid.double().sum(0)
+    assert float((summed(part) - ref_dw).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+    assert float((summed(ps) - ref_ds).abs().max()) <= 2e-5 * float(ref_ds.abs().max())
+    assert float((summed(part) - summed(part0)).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+    assert float((summed(ps) - summed(ps0)).abs().max()) <= 2e-5 * float(ref_ds.abs().max())
+    for cc in (col, cs):
+        assert float((cc.reshape(splits, 4 * c).double().sum(0) - ref_cs).abs().max()) <= 2e-5 * float(ref_cs.abs().max()) + 1e-4
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_pair_wgrad_entry(M, dt, src, w1, add, bits, w2, u, dst, ws, xin, 0, dx, part, col, ps, cs, c * 4 * c - 1)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("shape", [(2, 16, 24, 64, 64, 3), (2, 32, 40, 128, 128, 3), (3, 16, 16, 64, 256, 1), (4, 128, 160, 64, 64, 3)],
                          ids=["c3x3_64", "c3x3_128", "pointwise_wide", "stage2_rows"])
 def test_weight_gradient_with_dz_on_a_coarser_grid(dt, shape):

@@ -588,8 +588,9 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
     """Option pair = 1 (default) lets the stage-2 backward pairs also accumulate the weight gradient of res2{a,b}_branch2c
-    (urso_conv_pair_wgrad) into those layers' split workspaces, and the projection shortcut res2a_branch1 take both of its gradients from
-    one pass over its output gradient (urso_conv_dgrad_wgrad_pw); pair = 2 keeps the three weight-gradient launches.  Same forward plan,
+    (urso_conv_pair_wgrad) into those layers' split workspaces, and the pair behind the stage's first block take the projection shortcut
+    res2a_branch1's data and weight gradient along (urso_conv_pair_wgrad_entry: the block-output gradient stays on chip); pair = 2 keeps
+    the three weight-gradient launches.  Same forward plan,
     bit-identical data gradients: every gradient is equal bit for bit except those two layers' (kernel, folded BatchNorm), which
     differ by the fp32 summation order of a different pixel split only."""
     from ursonet_amd import hip
@@ -603,8 +604,9 @@ def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((eng.flat_g.clone(), dict(eng.slices), eng.losses(), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+wgrad:" in l],
                     sum(1 for l in eng.labels["bwd"] if l and l.startswith("wgrad:")), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad+wgrad:")]))
-    assert res[0][3] == ["dgrad:res2c_branch2a+res2b_branch2c+wgrad:res2b_branch2c", "dgrad:res2b_branch2a+res2a_branch2c+wgrad:res2a_branch2c"]
-    assert res[1][3] == [] and res[1][4] - res[0][4] == 3 and res[0][5] == ["dgrad+wgrad:res2a_branch1"] and res[1][5] == []
+    assert res[0][3] == ["dgrad:res2c_branch2a+res2b_branch2c+wgrad:res2b_branch2c",
+                         "dgrad:res2b_branch2a+res2a_branch2c+res2a_branch1+wgrad:res2a_branch2c+res2a_branch1"]
+    assert res[1][3] == [] and res[1][4] - res[0][4] == 3 and res[0][5] == [] and res[1][5] == []
     assert res[0][2] == res[1][2]
     seen = set()
     for (ln, wn), (o, n, _) in res[0][1].items():

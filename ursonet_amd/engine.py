@@ -518,10 +518,32 @@ class Engine(object):
                         # when the loop reaches A -- its reduction and finalisation stay where they are
                         A.splits = A.desc.splits = wsplits
                         A.wgrad_by_pair = True
-                        self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
-                                             hip.conv_pair_wgrad(A.Mpix, dt, G, c.wd, add, X.bits, dstg, A.wd, A.src.data, dst2,
-                                                                 A.wg_ws, A.wg_ws[A.wg_npart:], A.K_raw * A.npad + hip.WGRAD_PART_PAD, add_hw=hw)))
-                        self.labels["bwd"].append("dgrad:%s+%s+wgrad:%s" % (node.name, A.name, A.name))
+                        # the stage's first block: X's gradient is read by nothing but this pair and the projection shortcut (A's residual
+                        # operand, a conv without activation): its data and weight gradient join the launch and dL/dX stays on chip
+                        S = [cc for cc in self.convs.values() if A.res is not None and cc.dst is A.res]
+                        Sc = S[0] if len(S) == 1 else None
+                        sn = Sc.node if Sc is not None else None
+                        entry = (Sc is not None and X.pending_hw is None and not sn.stem and not sn.dense and sn.kh == 1 and sn.kw == 1 and
+                                 sn.stride == 1 and sn.cin == 64 and Sc.npad == 256 and Sc.N == 256 and not Sc.batch_bn and not sn.relu and
+                                 (self.layer_trainable[sn.name] or bool(sn.bn and self.layer_trainable[sn.bn])) and
+                                 need[Sc.src.spec.id] and Sc.src.compact is None and not getattr(Sc, "gd_scatter", False) and
+                                 getattr(Sc, "gf_compact", None) is None and not Sc.src.grad_written and Sc.src.pending is None and
+                                 sn.name not in last_of_group and self.pair_first.get(sn.name) is None)
+                        if entry:
+                            Sc.splits = Sc.desc.splits = wsplits
+                            Sc.wgrad_by_pair = Sc.dgrad_done_by_pair = True
+                            dxin = Sc.src.grad_buf()
+                            Sc.src.grad_written = True
+                            self.bwd_ops.append((None, lambda c=c, A=A, Sc=Sc, G=G, add=add, X=X, dst2=dst2, dxin=dxin:
+                                                 hip.conv_pair_wgrad_entry(A.Mpix, dt, G, c.wd, add, X.bits, A.wd, A.src.data, dst2, Sc.wd, Sc.src.data, Sc.src.spec.relu, dxin,
+                                                                           A.wg_ws, A.wg_ws[A.wg_npart:], Sc.wg_ws, Sc.wg_ws[Sc.wg_npart:],
+                                                                           A.K_raw * A.npad + hip.WGRAD_PART_PAD)))
+                            self.labels["bwd"].append("dgrad:%s+%s+%s+wgrad:%s+%s" % (node.name, A.name, sn.name, A.name, sn.name))
+                        else:
+                            self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
+                                                 hip.conv_pair_wgrad(A.Mpix, dt, G, c.wd, add, X.bits, dstg, A.wd, A.src.data, dst2,
+                                                                     A.wg_ws, A.wg_ws[A.wg_npart:], A.K_raw * A.npad + hip.WGRAD_PART_PAD, add_hw=hw)))
+                            self.labels["bwd"].append("dgrad:%s+%s+wgrad:%s" % (node.name, A.name, A.name))
                     else:
                         self.bwd_ops.append((None, lambda c=c, A=A, G=G, add=add, X=X, dstg=dstg, dst2=dst2, hw=X.pending_hw:
                                              hip.conv_pair(A.Mpix, A.node.cin, dt, 1, G, c.wd, None, add, X.bits, dstg, A.wd, None, A.src.data, dst2,

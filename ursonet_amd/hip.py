@@ -116,6 +116,7 @@ _SIGS = {
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
     "urso_conv_pair_shortcut": (_i, [C.c_longlong, _i, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _vp, _vp]),
     "urso_conv_dgrad_wgrad_pw": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _fp, _fp, _sz, _vp]),
+    "urso_conv_pair_wgrad_entry": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _fp, _fp, _fp, _fp, _sz, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
@@ -431,6 +432,14 @@ def conv_dgrad_wgrad_pw(M, dt, dz, wd, x, mask_by_x, dx, part, colpart, part_str
     """urso_conv_dgrad_wgrad_pw: dx = dz Wd^T (optionally masked by x > 0) and the split partials of dW = x^T dz, colsum (64 -> 256 layer)."""
     _chk(_lib.urso_conv_dgrad_wgrad_pw(int(M), dt, ptr(dz), ptr(wd), ptr(x), int(bool(mask_by_x)), ptr(dx), ptr(part), ptr(colpart),
                                        int(part_stride), stream_ptr(stream)), "urso_conv_dgrad_wgrad_pw")
+
+
+def conv_pair_wgrad_entry(M, dt, src, w1, add, bits, w2, u, dst, ws, xin, mask_by_xin, dxin, part, colpart, part_s, colpart_s, part_stride, stream=None):
+    """urso_conv_pair_wgrad_entry: backward pair + weight gradient of the block-closing layer + both gradients of the projection
+    shortcut (dxin = mid Ws^T, dWs = xin^T mid); the 256-channel gradient mid never leaves the chip."""
+    _chk(_lib.urso_conv_pair_wgrad_entry(int(M), dt, ptr(src), ptr(w1), ptr(add), ptr(bits), ptr(w2), ptr(u), ptr(dst), ptr(ws), ptr(xin), int(bool(mask_by_xin)), ptr(dxin),
+                                         ptr(part), ptr(colpart), ptr(part_s), ptr(colpart_s), int(part_stride), stream_ptr(stream)),
+         "urso_conv_pair_wgrad_entry")
 
 
 def conv_pair_wgrad_splits(M, dt):
