@@ -6,7 +6,7 @@ import csv, json, sys
 def load(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "pw_kernel", "hconv_kernel", "pair_kernel", "pairw_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "stem_kernel")) and r["Counter_Name"] == counter:
+        if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "pw_kernel", "hconv_kernel", "pair_kernel", "pairw_kernel", "pairx_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "stem_kernel")) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"]); n += 1
     return tot, n
 f, nf = load(sys.argv[1], "FETCH_SIZE")
