@@ -708,8 +708,18 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     return URSO_OK;
 }
 
+// conv_stemw.hip: the packed 7x7 stem has a kernel of its own (one partial per block)
+bool urso_stemw_fits(const urso_conv_geom* g, int dt);
+int urso_stemw_splits(const urso_conv_geom* g);
+int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
+
 extern "C" size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt) {
     WgradPlan p;
+    if (g && urso_stemw_fits(g, dt)) {
+        const size_t stem = (size_t)urso_stemw_splits(g) * ((size_t)224 * 64 + URSO_WGRAD_PART_PAD + 64) * sizeof(float) + 256;
+        const size_t gen = plan_wgrad(g, dt, p) == URSO_OK ? (p.part_elems + p.col_elems) * sizeof(float) + 256 : 0;
+        return stem > gen ? stem : gen;                    // either kernel may run (option "stem")
+    }
     if (!g || plan_wgrad(g, dt, p) != URSO_OK) return 0;
     return (p.part_elems + p.col_elems) * sizeof(float) + 256;
 }
@@ -738,6 +748,20 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     const size_t x_bytes = (size_t)g->B * g->H * g->W * g->C * es,
                  dz_bytes = zscat ? (size_t)g->B * g->FH * g->FW * g->N * es : (size_t)p.M * g->N * es;
     if (x_bytes >= 0x7FFFFF00ull || dz_bytes >= 0x7FFFFF00ull) { urso_set_error("urso_conv_wgrad: tensor exceeds 2 GiB"); return URSO_EINVAL; }
+    if (urso_stemw_fits(g, dt) && !keep_partials && !zscat) {
+        // the stem: im2col on the LDS read side (conv_stemw.hip), one partial per block, then the same fixed-order reduction
+        hipStream_t st = (hipStream_t)stream;
+        const int splits = urso_stemw_splits(g);
+        const size_t cnt = (size_t)224 * 64, pstride = cnt + URSO_WGRAD_PART_PAD;
+        float* part = (float*)ws_d; float* colpart = part + (size_t)splits * pstride;
+        ProfScope ps(st, URSO_K_WGRAD, 2.0 * p.M * 64.0 * 147.0, (double)x_bytes + (double)p.M * 128 + (double)cnt * 4);
+        int rc = urso_stemw_launch(g, dt, x_d, dz_d, part, colsum_d ? colpart : nullptr, pstride, st);
+        if (rc != URSO_OK) return rc;
+        const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(splits);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
+        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
+        return urso_check_launch("urso_conv_wgrad(stem reduce)");
+    }
     WgradArgs a;
     a.x = x_d; a.dz = dz_d; a.x_bytes = (uint32_t)x_bytes; a.dz_bytes = (uint32_t)dz_bytes;
     float* part = (float*)ws_d; float* colpart = part + p.part_elems;
