@@ -329,6 +329,13 @@ int urso_bn_backward(int M, int N, int dt, const void* g_d, const void* z_d, con
 int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,
                      int dt, void* dst_d, void* stream);
 
+/* The stem's weight gradient taken straight from the gradient of the max-pool output behind it (conv_stemw.hip): g is the packed stem
+ * geometry of urso_conv_igemm / urso_conv_wgrad (net.py:170-176), x_d the molded input, dpool_d the gradient w.r.t. the pool OUTPUT
+ * [B][OH/2][OW/2][64] and argmax_d the bytes urso_maxpool3x3s2_fwd stored.  Result = urso_maxpool3x3s2_bwd(relu_mask = 1) followed by
+ * urso_conv_wgrad (the rebuilt gradient tiles are bit-identical to that kernel's output), but the gradient of conv1's output is never
+ * written or read.  16-bit dtypes; workspace: urso_conv_wgrad_ws_bytes(g, dt). */
+int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const void* x_d, const void* dpool_d, const uint8_t* argmax_d,
+                           void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream);
 /* MaxPooling2D((3,3), strides=(2,2), padding="same") (net.py:176,258), H,W even.
  * fwd also stores one byte per output element: the arg-max tap (first maximum in row-major window order, 0..8) in bits 0-3 and,
  * in bit 4, whether the window maximum is <= 0.

@@ -348,6 +348,24 @@ def _stem_case(hip, dt, B, H, W, N):
     torch.cuda.synchronize()
     assert relerr(dw, w_fold.grad) < TOL[dt]
     assert relerr(cs, dz.sum((0, 1, 2))) < max(TOL[dt] * 1e-2, 2e-5)          # column sums of the (already rounded) gradient: fp32 sums
+    if dt and hip.get_option("stem"):
+        # the same weight gradient from the gradient of a max-pool behind the conv (urso_stem_wgrad_pooled) against
+        # urso_maxpool3x3s2_bwd + urso_conv_wgrad
+        PH, PW = OH // 2, OW // 2
+        pooled = torch.empty(B, PH, PW, N, dtype=hip.TORCH_DT[dt], device="cuda")
+        am = torch.empty(B, PH, PW, N, dtype=torch.uint8, device="cuda")
+        hip.maxpool_fwd(B, OH, OW, N, dt, y, pooled, am)
+        dpool = dev(rnd(torch.randn(B, PH, PW, N), dt), dt)
+        dzp = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
+        hip.maxpool_bwd(B, OH, OW, N, dt, pooled, dpool, am, 1, dzp)
+        dw1, cs1 = torch.empty_like(dwp), torch.empty_like(cs)
+        hip.conv_wgrad(g, dt, molded, dzp, ws, dw1, cs1)
+        torch.cuda.synchronize()
+        dw2, cs2 = torch.full_like(dwp, float("nan")), torch.full_like(cs, float("nan"))
+        hip.stem_wgrad_pooled(g, dt, molded, dpool, am, ws, dw2, cs2)
+        torch.cuda.synchronize()
+        assert float((dw2 - dw1).abs().max()) <= 2e-5 * float(dw1.abs().max()) and float((cs2 - cs1).abs().max()) <= 2e-5 * float(cs1.abs().max()) + 1e-5
+        assert float(dw1.abs().max()) > 0 and 0.02 < float((dzp.float() != 0).float().mean()) < 0.3
 
 
 @pytest.mark.parametrize("dt", [0, 1])

@@ -15,6 +15,13 @@
 // with 3 also carry the column sums: an all-ones A operand) -- 64 persistent accumulator registers, never reset: a block walks its
 // tiles and writes ONE fp32 partial [224][64] (+ [64]) at the end; the partials are summed in a fixed order by reduce_partials_kernel.
 // 44 KiB of LDS, single-buffered: three blocks per CU overlap each other's loads.
+//
+// POOLED form: dz is not read but rebuilt per tile from the gradient of the MAX-POOL output that follows conv1 (net.py:176: 3x3 / s2 /
+// 'same') and the pool's arg-max bytes (urso_maxpool3x3s2_fwd: tap in bits 0-3, bit 4 = window maximum <= 0, i.e. the ReLU in between):
+// the 5 x 17 pooled pixels whose windows touch the tile arrive by LDS-DMA (16 KiB instead of the 32 KiB dz tile), every thread routes
+// the windows of two 2 x 2 pixel blocks x 8 channels to their arg-max positions in urso_maxpool3x3s2_bwd's order and rounding -- the dz
+// tile in LDS is bit for bit what that kernel would have written -- and the weight gradient proceeds as above.  The gradient of conv1's
+// output (335 MB at cfg2) is then neither written by the pool's backward pass nor read here, and that launch disappears.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -22,6 +29,7 @@ typedef short sw_s16x4_t __attribute__((ext_vector_type(4)));
 
 struct StemwArgs {
     const void* x; const void* dz; float* part; float* colpart;
+    const void* dpool; const uint8_t* am; uint32_t dpool_bytes, am_bytes;   // POOLED: gradient of the pool output [B][OH/2][OW/2][64], arg-max bytes
     uint32_t x_bytes, dz_bytes;
     int B, H, W, OH, OW, tiles_x, tiles_y, ntiles;       // H, W in pixels
     size_t part_stride;
@@ -30,6 +38,8 @@ struct StemwArgs {
 constexpr int SW_TH = 8, SW_TW = 32, SW_PROWS = 2 * SW_TH + 5, SW_PPIX = 2 * SW_TW + 8, SW_PROW_B = SW_PPIX * 8;     // 21 rows x 576 B
 constexpr int SW_PIECES = SW_PROWS * (SW_PROW_B / 16);                                                                 // 756 16-byte pieces
 constexpr int SW_PATCH = 12288, SW_ZOFF = SW_PATCH, SW_LDS = SW_ZOFF + 32768;
+constexpr int SW_PR = SW_TH / 2 + 1, SW_PC = SW_TW / 2 + 1, SW_PP = SW_PR * SW_PC;           // 5 x 17 pooled pixels touch a tile
+constexpr int SW_DPOFF = SW_LDS, SW_AMOFF = SW_DPOFF + 12288, SW_LDS_POOLED = SW_AMOFF + 8192;   // 85 x 128 B, 85 x 64 B; sized for the whole DMA instructions (the lanes past pixel 84 write zeros)
 
 template <typename T> struct SwMma;
 template <> struct SwMma<__bf16> {
@@ -55,10 +65,10 @@ __device__ __forceinline__ i32x4_t sw_rsrc(const void* p, uint32_t bytes) {
     return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void stemw_kernel(const StemwArgs a) {
+template <typename T, bool POOLED>
+__global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ __attribute__((aligned(1024))) char smem[SW_LDS];
+    __shared__ __attribute__((aligned(1024))) char smem[POOLED ? SW_LDS_POOLED : SW_LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nh = wave & 1, ks = wave >> 1;
@@ -68,7 +78,8 @@ __global__ __launch_bounds__(256, 3) void stemw_kernel(const StemwArgs a) {
     const int cpx = ceil_div(a.ntiles, 8);
     const int t_end = min((xcd + 1) * cpx, a.ntiles);
 
-    const i32x4_t rx = sw_rsrc(a.x, a.x_bytes), rz = sw_rsrc(a.dz, a.dz_bytes);
+    const i32x4_t rx = sw_rsrc(a.x, a.x_bytes), rz = sw_rsrc(POOLED ? a.dpool : a.dz, POOLED ? a.dpool_bytes : a.dz_bytes);
+    const i32x4_t ram = sw_rsrc(POOLED ? (const void*)a.am : a.x, POOLED ? a.am_bytes : 0u);
 
     // transposing fragment reads (conv_pairw.hip): a 16-lane group g reads 4 "rows" x 16 elements; lane l15 supplies row l15 >> 2, 8-byte
     // piece l15 & 3 and receives element-column l15 of the 4 rows.  Group g: (g & 1) = which 16 of the operand's 32 rows / columns,
@@ -106,16 +117,87 @@ __global__ __launch_bounds__(256, 3) void stemw_kernel(const StemwArgs a) {
                 sw_dma16(rx, lds0 + (wave + 4 * i) * 1024, ok ? (uint32_t)(((b * a.H + iy) * a.W + ix) * 8) : URSO_OOB_SHIFT);
             }
         }
-        // ---- dz tile: row = 32 ry + cx; instruction i covers rows 8 (wave + 4 i) + (lane >> 3)
+        if constexpr (!POOLED) {
+            // ---- dz tile: row = 32 ry + cx; instruction i covers rows 8 (wave + 4 i) + (lane >> 3)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 8 * (wave + 4 * i) + (lane >> 3);
-            const int oy = oy0 + (row >> 5), ox = ox0 + (row & 31);
-            const uint32_t so = (oy < a.OH && ox < a.OW) ? (uint32_t)(((b * a.OH + oy) * a.OW + ox) * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) : URSO_OOB_SHIFT;
-            sw_dma16(rz, lds0 + SW_ZOFF + (wave + 4 * i) * 1024, so);
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * (wave + 4 * i) + (lane >> 3);
+                const int oy = oy0 + (row >> 5), ox = ox0 + (row & 31);
+                const uint32_t so = (oy < a.OH && ox < a.OW) ? (uint32_t)(((b * a.OH + oy) * a.OW + ox) * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) : URSO_OOB_SHIFT;
+                sw_dma16(rz, lds0 + SW_ZOFF + (wave + 4 * i) * 1024, so);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            // ---- pooled pixels (py0 - 1 .. py0 + 3) x (px0 - 1 .. px0 + 15), py0 = oy0 / 2, px0 = ox0 / 2: gradient rows of 128 B (8 pieces)
+            //      and arg-max rows of 64 B (4 pieces), linear [r * 17 + c]; windows that do not exist = out-of-range offsets = zeros
+            const int PH = a.OH >> 1, PW = a.OW >> 1, py0 = (oy0 >> 1) - 1, px0 = (ox0 >> 1) - 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int p = 64 * (wave + 4 * i) + lane, pp = p >> 3;
+                const int r = (pp * 3856) >> 16, c = pp - 17 * r;                         // pp / 17 for pp < 96
+                const int py = py0 + r, px = px0 + c;
+                const bool ok = pp < SW_PP && py >= 0 && py < PH && px >= 0 && px < PW;
+                sw_dma16(rz, lds0 + SW_DPOFF + (wave + 4 * i) * 1024, ok ? (uint32_t)(((b * PH + py) * PW + px) * 128 + (p & 7) * 16) : URSO_OOB_SHIFT);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = 64 * (wave + 4 * i) + lane, pp = p >> 2;
+                const int r = (pp * 3856) >> 16, c = pp - 17 * r;
+                const int py = py0 + r, px = px0 + c;
+                const bool ok = pp < SW_PP && py >= 0 && py < PH && px >= 0 && px < PW;
+                sw_dma16(ram, lds0 + SW_AMOFF + (wave + 4 * i) * 1024, ok ? (uint32_t)(((b * PH + py) * PW + px) * 64 + (p & 3) * 16) : URSO_OOB_SHIFT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- un-pool into the dz tile (urso_maxpool3x3s2_bwd, relu_mask = 1): item = (2 x 2 pixel block (by, bx), 8-channel vector cv)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = tid + 256 * it, cv = item & 7, bx = (item >> 3) & 15, by = item >> 7;
+                float gsum[4][8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) gsum[k][q] = 0.f;
+                // window (wy, wx) relative to the block reaches block pixel (r, c) = (ky - 2 wy, kx - 2 wx) of its tap (ky, kx) = tap / 3, tap % 3:
+                //   (0,0): taps 0, 1, 3, 4 -> pixels 0, 1, 2, 3     (0,1): taps 2, 5 -> pixels 0, 2     (1,0): taps 6, 7 -> pixels 0, 1     (1,1): tap 8 -> pixel 0
+                // written out per class (the generic form costs 2.6x the VALU work); the sums run in urso_maxpool3x3s2_bwd's window order
+#pragma unroll
+                for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                    for (int wx = 0; wx < 2; ++wx) {
+                        const int pp = (by + 1 - wy) * SW_PC + (bx + 1 - wx);
+                        const i32x4_t rd = *(const i32x4_t*)(smem + SW_DPOFF + pp * 128 + cv * 16);
+                        const i32x2_t ra = *(const i32x2_t*)(smem + SW_AMOFF + pp * 64 + cv * 8);
+                        T ed[8];
+                        __builtin_memcpy(ed, &rd, 16);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t ab = ((uint32_t)(q < 4 ? ra.x : ra.y) >> (8 * (q & 3))) & 31u;     // tap | dead bit: >= 16 matches no tap
+                            const float d = Elem<T>::to_f(ed[q]);
+                            if (wy == 0 && wx == 0) {
+                                gsum[0][q] += ab == 0u ? d : 0.f; gsum[1][q] += ab == 1u ? d : 0.f; gsum[2][q] += ab == 3u ? d : 0.f; gsum[3][q] += ab == 4u ? d : 0.f;
+                            } else if (wy == 0) {
+                                gsum[0][q] += ab == 2u ? d : 0.f; gsum[2][q] += ab == 5u ? d : 0.f;
+                            } else if (wx == 0) {
+                                gsum[0][q] += ab == 6u ? d : 0.f; gsum[1][q] += ab == 7u ? d : 0.f;
+                            } else {
+                                gsum[0][q] += ab == 8u ? d : 0.f;
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    T o[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = Elem<T>::from_f(gsum[k][q]);
+                    i32x4_t ov; __builtin_memcpy(&ov, o, 16);
+                    const int row = (2 * by + (k >> 1)) * 32 + 2 * bx + (k & 1);
+                    *(i32x4_t*)(smem + SW_ZOFF + row * 128 + ((cv ^ ((row >> 1) & 7)) << 4)) = ov;
+                }
+            }
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
 #pragma unroll 2
         for (int st = 0; st < 16; ++st) {                      // reduction step: tile row ry = st >> 1, pixels 16 (st & 1) .. + 15
             const int ry = st >> 1, hs = st & 1;
@@ -165,22 +247,28 @@ bool urso_stemw_fits(const urso_conv_geom* g, int dt) {
     if (g->N != 64 || (g->H & 1) || g->OH != g->H / 2 || g->OW != g->W) return false;
     return (long long)g->B * g->H * g->W * 16 < 0x7FFFFF00ll && (long long)g->B * g->OH * g->OW * 128 < 0x7FFFFF00ll;
 }
-int urso_stemw_splits(const urso_conv_geom* g) {
+int urso_stemw_splits(const urso_conv_geom* g, bool pooled) {
     const int ntiles = g->B * ceil_div(g->OH, SW_TH) * ceil_div(g->OW, SW_TW);
     int bpx = ceil_div(ntiles, 8);
-    const int cap = 3 * sw_device_cus() / 8;
+    const int cap = (pooled ? 2 : 3) * sw_device_cus() / 8;       // resident blocks per CU of the two forms
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     return 8 * bpx;
 }
-int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st) {
+int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, const void* dpool, const uint8_t* am,
+                      float* part, float* colpart, size_t part_stride, hipStream_t st) {
     StemwArgs a;
     a.x = x; a.dz = dz; a.part = part; a.colpart = colpart; a.part_stride = part_stride;
+    a.dpool = dpool; a.am = am;
+    a.dpool_bytes = (uint32_t)((size_t)g->B * (g->OH / 2) * (g->OW / 2) * 128); a.am_bytes = a.dpool_bytes / 2;
     a.B = g->B; a.H = g->H; a.W = 2 * g->W; a.OH = g->OH; a.OW = g->OW;                 // g->W counts pixel pairs
     a.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * 8); a.dz_bytes = (uint32_t)((size_t)a.B * a.OH * a.OW * 128);
     a.tiles_x = ceil_div(a.OW, SW_TW); a.tiles_y = ceil_div(a.OH, SW_TH); a.ntiles = a.B * a.tiles_y * a.tiles_x;
-    const dim3 grid(urso_stemw_splits(g)), blk(256);
-    if (dt == URSO_BF16) hipLaunchKernelGGL((stemw_kernel<__bf16>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((stemw_kernel<_Float16>), grid, blk, 0, st, a);
+    const dim3 grid(urso_stemw_splits(g, dpool != nullptr)), blk(256);
+    if (dpool) {
+        if (dt == URSO_BF16) hipLaunchKernelGGL((stemw_kernel<__bf16, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((stemw_kernel<_Float16, true>), grid, blk, 0, st, a);
+    } else if (dt == URSO_BF16) hipLaunchKernelGGL((stemw_kernel<__bf16, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((stemw_kernel<_Float16, false>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_wgrad(stem)");
 }

@@ -710,13 +710,14 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
 
 // conv_stemw.hip: the packed 7x7 stem has a kernel of its own (one partial per block)
 bool urso_stemw_fits(const urso_conv_geom* g, int dt);
-int urso_stemw_splits(const urso_conv_geom* g);
-int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
+int urso_stemw_splits(const urso_conv_geom* g, bool pooled);
+int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, const void* dpool, const uint8_t* am,
+                      float* part, float* colpart, size_t part_stride, hipStream_t st);
 
 extern "C" size_t urso_conv_wgrad_ws_bytes(const urso_conv_geom* g, int dt) {
     WgradPlan p;
     if (g && urso_stemw_fits(g, dt)) {
-        const size_t stem = (size_t)urso_stemw_splits(g) * ((size_t)224 * 64 + URSO_WGRAD_PART_PAD + 64) * sizeof(float) + 256;
+        const size_t stem = (size_t)urso_stemw_splits(g, false) * ((size_t)224 * 64 + URSO_WGRAD_PART_PAD + 64) * sizeof(float) + 256;
         const size_t gen = plan_wgrad(g, dt, p) == URSO_OK ? (p.part_elems + p.col_elems) * sizeof(float) + 256 : 0;
         return stem > gen ? stem : gen;                    // either kernel may run (option "stem")
     }
@@ -751,11 +752,11 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     if (urso_stemw_fits(g, dt) && !keep_partials && !zscat) {
         // the stem: im2col on the LDS read side (conv_stemw.hip), one partial per block, then the same fixed-order reduction
         hipStream_t st = (hipStream_t)stream;
-        const int splits = urso_stemw_splits(g);
+        const int splits = urso_stemw_splits(g, false);
         const size_t cnt = (size_t)224 * 64, pstride = cnt + URSO_WGRAD_PART_PAD;
         float* part = (float*)ws_d; float* colpart = part + (size_t)splits * pstride;
         ProfScope ps(st, URSO_K_WGRAD, 2.0 * p.M * 64.0 * 147.0, (double)x_bytes + (double)p.M * 128 + (double)cnt * 4);
-        int rc = urso_stemw_launch(g, dt, x_d, dz_d, part, colsum_d ? colpart : nullptr, pstride, st);
+        int rc = urso_stemw_launch(g, dt, x_d, dz_d, nullptr, nullptr, part, colsum_d ? colpart : nullptr, pstride, st);
         if (rc != URSO_OK) return rc;
         const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(splits);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
@@ -822,4 +823,26 @@ extern "C" int urso_conv_wgrad(const urso_conv_geom* g, int dt, const void* x_d,
 extern "C" int urso_conv_wgrad_partial(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
                                        void* ws_d, size_t ws_bytes, void* stream) {
     return wgrad_impl(g, dt, x_d, dz_d, ws_d, ws_bytes, nullptr, nullptr, true, stream);
+}
+
+// The stem's weight gradient taken straight from the gradient of the max-pool output behind it (conv_stemw.hip, POOLED form): what
+// urso_maxpool3x3s2_bwd(relu_mask = 1) followed by urso_conv_wgrad computes, without the gradient of conv1's output in memory.
+extern "C" int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const void* x_d, const void* dpool_d, const uint8_t* argmax_d,
+                                      void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream) {
+    if (!g || !x_d || !dpool_d || !argmax_d || !ws_d || !dw_raw_d) { urso_set_error("urso_stem_wgrad_pooled: null argument"); return URSO_EINVAL; }
+    if (!urso_stemw_fits(g, dt) || (g->OH & 1) || (g->OW & 1)) { urso_set_error("urso_stem_wgrad_pooled: not the packed 16-bit stem geometry"); return URSO_EINVAL; }
+    if (ws_bytes < urso_conv_wgrad_ws_bytes(g, dt)) { urso_set_error("urso_stem_wgrad_pooled: workspace too small"); return URSO_EWORKSPACE; }
+    if ((((uintptr_t)x_d) | ((uintptr_t)dpool_d) | ((uintptr_t)argmax_d)) & 15) { urso_set_error("urso_stem_wgrad_pooled: pointers must be 16-byte aligned"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = urso_stemw_splits(g, true);
+    const size_t cnt = (size_t)224 * 64, pstride = cnt + URSO_WGRAD_PART_PAD;
+    float* part = (float*)ws_d; float* colpart = part + (size_t)splits * pstride;
+    const double M = (double)g->B * g->OH * g->OW;
+    ProfScope ps(st, URSO_K_WGRAD, 2.0 * M * 64.0 * 147.0, (double)g->B * g->H * g->W * 16 + M / 4 * (128 + 64) + (double)cnt * 4);
+    int rc = urso_stemw_launch(g, dt, x_d, nullptr, dpool_d, argmax_d, part, colsum_d ? colpart : nullptr, pstride, st);
+    if (rc != URSO_OK) return rc;
+    const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(splits);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
+    if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
+    return urso_check_launch("urso_stem_wgrad_pooled(reduce)");
 }

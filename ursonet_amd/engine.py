@@ -384,8 +384,17 @@ class Engine(object):
                     continue
                 src, dst = self.acts[node.src.id], self.acts[node.dst.id]
                 h, w, cc = node.src.h, node.src.w, node.src.c
-                gsrc = src.grad_buf()
                 assert dst.grad_written
+                # the pool behind the stem: its backward pass would write the gradient of conv1's output (335 MB at cfg2) for conv1's weight
+                # gradient alone (the image needs no data gradient) -- that kernel rebuilds the tiles it needs from dst.grad and the
+                # arg-max bytes instead (urso_stem_wgrad_pooled): no launch here, no tensor
+                prod = [cc_ for cc_ in self.convs.values() if cc_.dst is src]
+                if (len(prod) == 1 and prod[0].node.stem and not prod[0].batch_bn and dt != hip.F32 and hip.get_option("stem") and cc == 64 and
+                        h % 2 == 0 and w % 2 == 0 and (self.layer_trainable[prod[0].node.name] or bool(prod[0].node.bn and self.layer_trainable[prod[0].node.bn]))):
+                    prod[0].pooled_grad = (dst, node._am)
+                    src.grad_written = True
+                    continue
+                gsrc = src.grad_buf()
                 self.bwd_ops.append((None, lambda d=dst, gs=gsrc, am=node._am, h=h, w=w, cc=cc:
                                      hip.maxpool_bwd(B, h, w, cc, dt, d.data, d.grad, am, 1, gs)))
                 self.labels["bwd"].append("maxpool_bwd")
@@ -410,8 +419,13 @@ class Engine(object):
             if (tr or bn_tr) and node.stem:
                 c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
                 c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev)
-                self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad(c.gf, dt, c.src.data, G, self.ws, c.dw_raw, c.colsum)))
-                self.labels["bwd"].append("wgrad:" + node.name)
+                if getattr(c, "pooled_grad", None) is not None:
+                    self.bwd_ops.append((node.name, lambda c=c, pg=c.pooled_grad: hip.stem_wgrad_pooled(c.gf, dt, c.src.data, pg[0].grad, pg[1], self.ws,
+                                                                                                        c.dw_raw, c.colsum)))
+                    self.labels["bwd"].append("wgrad:%s+maxpool_bwd" % node.name)
+                else:
+                    self.bwd_ops.append((node.name, lambda c=c, G=G: hip.conv_wgrad(c.gf, dt, c.src.data, G, self.ws, c.dw_raw, c.colsum)))
+                    self.labels["bwd"].append("wgrad:" + node.name)
                 c.dw_unp = torch.empty(147 * c.N, dtype=torch.float32, device=dev)
                 self.bwd_ops.append((node.name, lambda c=c: hip.stem_wgrad_unpack(c.N, c.dw_raw, c.dw_unp)))
                 self.labels["bwd"].append("unpack:" + node.name)

@@ -117,6 +117,7 @@ _SIGS = {
     "urso_conv_pair_shortcut": (_i, [C.c_longlong, _i, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _vp, _vp]),
     "urso_conv_dgrad_wgrad_pw": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _fp, _fp, _sz, _vp]),
     "urso_conv_pair_wgrad_entry": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _fp, _fp, _fp, _fp, _sz, _vp]),
+    "urso_stem_wgrad_pooled": (_i, [_gp, _i, _vp, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
@@ -440,6 +441,12 @@ def conv_pair_wgrad_entry(M, dt, src, w1, add, bits, w2, u, dst, ws, xin, mask_b
     _chk(_lib.urso_conv_pair_wgrad_entry(int(M), dt, ptr(src), ptr(w1), ptr(add), ptr(bits), ptr(w2), ptr(u), ptr(dst), ptr(ws), ptr(xin), int(bool(mask_by_xin)), ptr(dxin),
                                          ptr(part), ptr(colpart), ptr(part_s), ptr(colpart_s), int(part_stride), stream_ptr(stream)),
          "urso_conv_pair_wgrad_entry")
+
+
+def stem_wgrad_pooled(g, dt, x, dpool, argmax, ws, dw_raw, colsum, stream=None):
+    """urso_stem_wgrad_pooled: the stem's weight gradient from the max-pool output's gradient + arg-max bytes (no conv1-output gradient)."""
+    _chk(_lib.urso_stem_wgrad_pooled(C.byref(g), dt, ptr(x), ptr(dpool), ptr(argmax), ptr(ws), ws.numel() * ws.element_size(), ptr(dw_raw),
+                                     ptr(colsum), stream_ptr(stream)), "urso_stem_wgrad_pooled")
 
 
 def conv_pair_wgrad_splits(M, dt):
