@@ -227,6 +227,7 @@ class Engine(object):
                 self.acts[node.dst.id] = a
             c.dst = self.acts[node.dst.id]
             c.res = act(node.residual) if node.residual is not None else None
+            c.xin = c.src.data                         # the tensor the forward pass and the weight gradient read (c.gf describes it)
             if node.stem:
                 c.gf = hip.geom(B, self.H, self.W // 2, 8, node.dst.h, node.dst.w, c.npad, 7, 4, 2, 1, 3, 2)
                 c.K_raw = 7 * 4 * 8
@@ -248,6 +249,21 @@ class Engine(object):
                     c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.src.h, node.src.w, node.cin, node.kh, node.kw,
                                     1, 1, node.kh - 1 - pt, node.kw - 1 - pl, s, s)
                 c.K_raw = node.kh * node.kw * node.cin
+                if (node.kh == 1 and node.kw == 1 and s == 2 and dt != hip.F32 and node.src.h % 2 == 0 and node.src.w % 2 == 0 and
+                        (node.cin * 2) % 16 == 0 and os.environ.get("URSO_COMPACT_INPUT", "1") != "0"):
+                    # a stage's stride-2 entry layers (branch2a and the projection shortcut, net.py:121-126) read every second pixel of every
+                    # second row of the previous stage's output: the strided source mapping costs the DMA kernel 20-35 us per layer against
+                    # the same GEMM on a dense tensor (and keeps the layer off the register-filter kernels), forward and in the weight
+                    # gradient.  The sampled pixels are gathered ONCE per step (urso_rows_subsample2) and both layers -- forward and weight
+                    # gradient -- run as plain pointwise layers on that compact tensor
+                    X = c.src
+                    if getattr(X, "data_compact", None) is None:
+                        X.data_compact = torch.empty(X.numel // 4, dtype=self.tdt, device=dev)
+                        self.fwd_ops.append(lambda X=X, hh=node.src.h, ww=node.src.w, rb=node.cin * 2:
+                                            hip.rows_subsample2(B, hh, ww, rb, X.data, X.data_compact))
+                        self.labels["fwd"].append("subsample:T%d" % node.src.id)
+                    c.gf = hip.geom(B, node.dst.h, node.dst.w, node.cin, node.dst.h, node.dst.w, c.npad, 1, 1)
+                    c.xin = X.data_compact
             if node.cin % VE and not node.stem:
                 raise ValueError("layer %s: %d input channels is not a multiple of %d" % (node.name, node.cin, VE))
             kelems = c.npad * c.K_raw
@@ -306,7 +322,7 @@ class Engine(object):
             if (c.halo_f or c.halo_d) and getattr(self, "halo_ws", None) is None:
                 self.halo_ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, dtype=torch.float32, device=dev)
             if c.batch_bn:
-                self.fwd_ops.append(lambda c=c: hip.conv_igemm_ex(c.gf, dt, 0, c.src.data, c.wf, c.biasf, None, None, c.z, None,
+                self.fwd_ops.append(lambda c=c: hip.conv_igemm_ex(c.gf, dt, 0, c.xin, c.wf, c.biasf, None, None, c.z, None,
                                                                   self.igemm_ws if c.ws_f else None))
                 self.labels["fwd"].append("fwd:" + node.name)
                 self.fwd_ops.append(lambda c=c: hip.bn_batch_stats(c.Mpix, c.N, dt, c.z, self.bn_ws, c.bmean, c.bvar, c.bn_mmean, c.bn_mvar,
@@ -318,7 +334,7 @@ class Engine(object):
             else:
                 c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
-                    c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.src.data, c.wf, c.biasf,
+                    c.gf, dt, f | (hip.EPI_EMIT_BITS if c.dst.bits is not None else 0), c.xin, c.wf, c.biasf,
                     c.res.data if c.res is not None else None, None, c.dst.data, c.dst.bits,
                     self.halo_ws if c.halo_f else (self.igemm_ws if c.ws_f else None)))
                 self.labels["fwd"].append("fwd:" + node.name)
@@ -467,7 +483,7 @@ class Engine(object):
                 d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 if not by_pair:
-                    self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.src.data, G, c.wg_ws)))
+                    self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.xin if gf_w is c.gf else c.src.data, G, c.wg_ws)))
                     self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
                     k = last_of_group[node.name]
