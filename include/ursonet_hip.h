@@ -191,6 +191,16 @@ int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_
  * consumer that cannot take the compact operand (stages whose residual hand-over is not a urso_conv_pair launch). */
 int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
 
+/* urso_conv_igemm_ex for a c -> 4c pointwise layer that closes a stage ('res{2c,3d,4f}_branch2c' + BatchNorm + Add + ReLU, net.py:148-157)
+ * with a SECOND output: the pixels at even rows / columns of dst_d, gathered into dst_sampled_d [B][OH/2][OW/2][N] -- what the next
+ * stage's stride-2 entry layers read (Conv2D 1x1 strides 2, net.py:121-126), which then run as dense pointwise layers on it.  Written
+ * from the LDS tile that holds the output rows anyway (conv_pair.hip, single-layer form) instead of by a separate urso_rows_subsample2
+ * pass.  urso_conv_pointwise_sampled_ok() tells whether (g, dt, flags, has_add) qualifies (64 / 128 / 256 input channels, N = 4c resp.
+ * a multiple of 512, even OH / OW); flags / bits_out_d as in urso_conv_igemm_ex (no mask). */
+int urso_conv_pointwise_sampled_ok(const urso_conv_geom* g, int dt, int flags, int has_add);
+int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
+                                const void* add_d, void* dst_d, void* bits_out_d, void* dst_sampled_d, void* stream);
+
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel).  Given a workspace of
  * urso_conv_igemm_halo_ws_bytes() through ws_d, that kernel balances the chip where whole tiles do not (e.g. 340 tiles on 256 CUs):

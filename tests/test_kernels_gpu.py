@@ -889,6 +889,19 @@ def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
         outs[(pair, cap)] = y.float()
     assert torch.equal(outs[(1, 0)], outs[(1, 8)])
     assert float((outs[(1, 0)] - outs[(0, 0)]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[(0, 0)].abs().max())
+    # the same layer with the sampled second output (urso_conv_pointwise_sampled): dst and bit mask unchanged bit for bit, the second
+    # tensor = the even rows / columns of dst; stages 2-4 (the 512-channel shape and the masked form do not offer it)
+    if not mb and c < 512:
+        for cap in (0, 8):
+            y2 = torch.full((B, H, W, 4 * c), 5.0, device="cuda").to(tdt); ys = torch.full((B, H // 2, W // 2, 4 * c), 5.0, device="cuda").to(tdt)
+            bits2 = torch.full_like(bits, 0x55) if bits is not None else None
+            with hip.options(grid_cap=cap):
+                assert hip.conv_pointwise_sampled_ok(g, dt, flags, add is not None)
+                hip.conv_pointwise_sampled(g, dt, flags, x, wf, biasf, add, y2, bits2, ys)
+            torch.cuda.synchronize()
+            assert torch.equal(y2.float(), outs[(1, 0)]) and torch.equal(ys, y2[:, ::2, ::2]) and (bits is None or torch.equal(bits2, bits))
+    else:
+        assert not hip.conv_pointwise_sampled_ok(g, dt, flags, add is not None)
 
 
 C3W_CASES = [

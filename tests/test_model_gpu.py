@@ -570,10 +570,13 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
             eng = Engine(cfg, "training", seed=5, randomize_bn=True)
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
-                    sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l), list(eng.shortcut_folded)))
+                    sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l), list(eng.shortcut_folded),
+                    sum(1 for l in eng.labels["fwd"] if l and l.endswith("+sampled"))))
     assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
     # five fused launches forward (plus the stage-2 projection shortcut, computed inside the first of them), five backward
-    assert res[1][0] - res[0][0] == 6 and res[0][6] == 5 and res[1][6] == 0 and res[0][7] == ["res2a_branch1"] and res[1][7] == []
+    # ... and the stage-closing layers write the sampled copy for the next stage's entry layers themselves instead of a gather pass each
+    assert res[0][8] == 3 and res[1][8] == 0
+    assert res[1][0] - res[0][0] == 6 + res[0][8] and res[0][6] == 5 and res[1][6] == 0 and res[0][7] == ["res2a_branch1"] and res[1][7] == []
     tol_out = 2e-2 if dtype == "bfloat16" else 4e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])

@@ -34,6 +34,9 @@ struct PairArgs {
     // SPARSE add (backward pair behind a stride-2 stage entry): `add` is the COMPACT gradient [B][sp_h/2][sp_w/2][CW] of a dense
     // [B][sp_h][sp_w] pixel grid whose odd rows and columns are zero (only every second pixel of every second row fed the next stage)
     int sp_h, sp_w; uint32_t add_bytes; float rcp_hw, rcp_w;
+    // single layers (VAR != 0, forward) with SPARSE: the layer ALSO writes the pixels at even rows / columns of its [B][sp_h][sp_w] output
+    // to cmp = [B][sp_h/2][sp_w/2][N] -- the copy the next stage's stride-2 entry layers read (they then run as dense pointwise layers)
+    void* cmp; uint32_t cmp_bytes;
     // wide tensors whose rows are longer than the tile (stage-4 single layers: 512 of the 1024 channels per block group = blockIdx.y):
     // bytes per pixel row of add / mid and of the bit mask in memory, and what one group index adds to each pointer
     uint32_t wide_pitch, bits_pitch, g_w1, g_bias, g_wide, g_bits;
@@ -91,7 +94,8 @@ using PairS5 = PairShape<512, 8, 32, 3, 256>;
 // the stride-1 shortcut conv): urso_conv_igemm_ex sends them here.
 template <typename T, int MODE, bool EMIT, typename S, int VAR, bool SPARSE = false>
 __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
-    static_assert(!SPARSE || (MODE == 1 && VAR == 0), "sparse add: backward pair only");
+    static_assert(!SPARSE || (MODE == 1 && VAR == 0) || (MODE == 0 && VAR != 0), "SPARSE: compact add operand of the backward pair, or sampled second output of a single forward layer");
+    constexpr bool SPADD = SPARSE && MODE == 1, CMPW = SPARSE && MODE == 0;
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr bool G2 = VAR == 0, HAS_ADD = VAR != 2;
     static_assert(!G2 || (S::CM / S::NW == 16 && S::CW == 4 * S::CM), "pair: every wave owns 16 of the CM output channels of GEMM 2");
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 
     const uint32_t grp = blockIdx.y, gwide = grp * a.g_wide, gbits = grp * a.g_bits;
     const uint32_t pitch = a.wide_pitch, bpitch = a.bits_pitch;
-    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc((const char*)a.add + gwide, (SPARSE ? a.add_bytes : a.wide_bytes) - gwide);
+    const i32x4_t rs = pr_rsrc(a.src, a.nar_bytes), ra = pr_rsrc((const char*)a.add + gwide, (SPADD ? a.add_bytes : a.wide_bytes) - gwide);
     const __amdgpu_buffer_rsrc_t rmid = make_rsrc((char*)a.mid + gwide, a.wide_bytes - gwide), rdst = make_rsrc(a.dst, a.nar_bytes);
     const __amdgpu_buffer_rsrc_t rbit = make_rsrc(a.bits ? (char*)a.bits + gbits : (char*)a.mid, a.bits ? a.bits_bytes - gbits : 0u);
     const __amdgpu_buffer_rsrc_t rmk2 = make_rsrc(MODE == 1 ? a.mask2 : a.dst, MODE == 1 ? a.nar_bytes : 0u);
@@ -138,11 +142,11 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         const uint32_t nb = (uint32_t)t * (uint32_t)(BM * AROW), wb = (uint32_t)t * (uint32_t)BM * pitch;
 #pragma unroll
         for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
-        if constexpr (HAS_ADD && !SPARSE) {
+        if constexpr (HAS_ADD && !SPADD) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + rgo[i]);
         }
-        if constexpr (SPARSE) {
+        if constexpr (SPADD) {
             // row -> pixel (b, y, x) of the dense grid; odd y or x: the gradient is zero there (out-of-range offset = zero fill),
             // else the row comes from compact pixel (b, y/2, x/2)
             const int hw = a.sp_h * a.sp_w, w2 = a.sp_w >> 1, hw4 = (a.sp_h >> 1) * w2;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     const uint32_t bitoff = (uint32_t)l31 * bpitch + 4u * C2T * wave;     // the wave's 32 C2T channels = 4 C2T mask bytes per pixel
 
     // vector-memory operations a tile issues after its requests for later tiles: the stores
-    constexpr int NST = NR + (G2 ? NA : 0) + ((MODE == 0 && EMIT) ? PT1 : 0);   // mid stores + dst stores + bit-mask stores
+    constexpr int NST = NR + (G2 ? NA : 0) + ((MODE == 0 && EMIT) ? PT1 : 0) + (CMPW ? NR : 0);   // mid stores + dst stores + bit-mask stores + sampled copy
 
     i32x2_t pbits[PT1];                                        // backward: bit masks of the NEXT tile (requested one tile ahead)
     i32x4_t pm2[NA];                                           //           mask2 vectors of its dst rows
@@ -337,6 +341,22 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
             for (int i = 0; i < NR; ++i) v[i] = *(const i32x4_t*)(sR + (wave + NW * i) * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + rgo[i], v[i]);
+            if constexpr (CMPW) {
+                // the same vectors once more for the pixels at even (y, x): row -> pixel (b, y, x) -> [b][y/2][x/2] of the sampled copy
+                const __amdgpu_buffer_rsrc_t rcmp = make_rsrc((char*)a.cmp + gwide, a.cmp_bytes - gwide);
+                const int hw = a.sp_h * a.sp_w, w2 = a.sp_w >> 1, hw4 = (a.sp_h >> 1) * w2;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int row = (1024 / RROW) * (wave + NW * i) + lane / (RROW / 16);
+                    const int p = tile * BM + row;
+                    int b = (int)((float)p * a.rcp_hw), rem = p - b * hw;
+                    { const bool lo = rem < 0, hi = rem >= hw; b += hi ? 1 : (lo ? -1 : 0); rem += hi ? -hw : (lo ? hw : 0); }
+                    int y = (int)((float)rem * a.rcp_w), x = rem - y * a.sp_w;
+                    { const bool lo = x < 0, hi = x >= a.sp_w; y += hi ? 1 : (lo ? -1 : 0); x += hi ? -a.sp_w : (lo ? a.sp_w : 0); }
+                    const uint32_t off = (uint32_t)(b * hw4 + (y >> 1) * w2 + (x >> 1)) * pitch + (roff[i] & (uint32_t)(RROW - 1));
+                    buf_store16(rcmp, ((y | x) & 1) ? URSO_OOB_SHIFT : off, v[i]);
+                }
+            }
         }
         if constexpr (!G2) {
             if (!has_next) break;
@@ -438,6 +458,9 @@ static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks
                 if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 1>), grid, blk, 0, st, a);
                 else hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 1>), grid, blk, 0, st, a);
             }
+        } else if (sparse) {                                   // + the sampled copy of the output (always with the bit mask: block outputs)
+            if (dt == URSO_BF16) { if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
+            else { if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
         } else if (dt == URSO_BF16) {
             if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR>), grid, blk, 0, st, a);
             else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR>), grid, blk, 0, st, a);
@@ -465,8 +488,8 @@ bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const voi
     if (mbits) return false;                                  // stages 2-3 run that layer inside the fused backward pair
     return g->N == 4 * g->C && urso_conv_pair_ok(M, dt, g->C, g->N) != 0;
 }
-int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
-                            const void* mask_bits, void* dst, void* bits_out, hipStream_t st) {
+static int pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
+                              const void* mask_bits, void* dst, void* bits_out, void* dst_sampled, hipStream_t st) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const int cm = g->C, cw = g->N;
     const int mode = (flags & URSO_EPI_MASK_BITS) ? 1 : 0;
@@ -477,24 +500,51 @@ int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const vo
     a.nar_bytes = (uint32_t)(M * cm * 2); a.wide_bytes = (uint32_t)(M * cw * 2); a.bits_bytes = (uint32_t)(M * (cw / 8));
     a.wide_pitch = (uint32_t)cw * 2u; a.bits_pitch = (uint32_t)cw / 8u; a.g_w1 = a.g_bias = a.g_wide = a.g_bits = 0;
     const bool emit = !mode && bits_out != nullptr;
+    const bool smp = dst_sampled != nullptr;
+    a.cmp = dst_sampled; a.cmp_bytes = (uint32_t)(M / 4 * cw * 2);
+    if (smp) { a.sp_h = g->OH; a.sp_w = g->OW; a.rcp_hw = 1.0f / (float)(g->OH * g->OW); a.rcp_w = 1.0f / (float)g->OW; }
     if (cm == PairS4::CM) {
         const int groups = cw / PairS4::CW;
         a.g_w1 = (uint32_t)PairS4::CW * cm * 2u; a.g_bias = PairS4::CW; a.g_wide = PairS4::CW * 2u; a.g_bits = PairS4::CW / 8u;
         a.ntiles = (int)(M / PairS4::BM);
-        if (add) pr_launch<PairS4, 1>(a, dt, mode, emit, 1, st, false, groups); else pr_launch<PairS4, 2>(a, dt, 0, emit, 1, st, false, groups);
+        if (add) pr_launch<PairS4, 1>(a, dt, mode, emit, 1, st, smp, groups); else pr_launch<PairS4, 2>(a, dt, 0, emit, 1, st, smp, groups);
     } else if (cm == PairS5::CM) {
         const int groups = cw / PairS5::CW;
         a.g_w1 = (uint32_t)PairS5::CW * cm * 2u; a.g_bias = PairS5::CW; a.g_wide = PairS5::CW * 2u; a.g_bits = PairS5::CW / 8u;
         a.ntiles = (int)(M / PairS5::BM);
-        if (add) pr_launch<PairS5, 1>(a, dt, mode, emit, 1, st, false, groups); else pr_launch<PairS5, 2>(a, dt, 0, emit, 1, st, false, groups);
+        if (add) pr_launch<PairS5, 1>(a, dt, mode, emit, 1, st, smp, groups); else pr_launch<PairS5, 2>(a, dt, 0, emit, 1, st, smp, groups);
     } else if (cm == PairS2::CM) {
         a.ntiles = (int)(M / PairS2::BM);
-        if (add) pr_launch<PairS2, 1>(a, dt, 0, emit, 2, st); else pr_launch<PairS2, 2>(a, dt, 0, emit, 2, st);
+        if (add) pr_launch<PairS2, 1>(a, dt, 0, emit, 2, st, smp); else pr_launch<PairS2, 2>(a, dt, 0, emit, 2, st, smp);
     } else {
         a.ntiles = (int)(M / PairS3::BM);
-        if (add) pr_launch<PairS3, 1>(a, dt, 0, emit, 1, st); else pr_launch<PairS3, 2>(a, dt, 0, emit, 1, st);
+        if (add) pr_launch<PairS3, 1>(a, dt, 0, emit, 1, st, smp); else pr_launch<PairS3, 2>(a, dt, 0, emit, 1, st, smp);
     }
     return urso_check_launch("urso_conv_igemm(wide pointwise)");
+}
+int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
+                            const void* mask_bits, void* dst, void* bits_out, hipStream_t st) {
+    return pair_single_launch(g, dt, flags, src, wgt, bias, add, mask_bits, dst, bits_out, nullptr, st);
+}
+
+// urso_conv_igemm_ex for a c -> 4c pointwise layer that closes a stage (res{2c,3d,4f}_branch2c, net.py:148-157), with a SECOND output: the
+// pixels at even rows / columns of dst, gathered into dst_sampled_d [B][H/2][W/2][N] -- the tensor the next stage's stride-2 entry
+// layers read (net.py:121-126), written from the LDS tile that holds the output rows anyway instead of by a separate gather pass.
+extern "C" int urso_conv_pointwise_sampled_ok(const urso_conv_geom* g, int dt, int flags, int has_add) {
+    if (!g || (flags & URSO_EPI_MASK_BITS) || (g->OH & 1) || (g->OW & 1) || g->C >= PairS5::CM) return 0;      // stages 2-4 close in front of a stride-2 stage entry; the 512-channel shape has no registers left for it
+    return urso_pair_single_fits(g, dt, flags, has_add ? (const void*)g : nullptr, nullptr) ? 1 : 0;
+}
+extern "C" int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
+                                           const void* add_d, void* dst_d, void* bits_out_d, void* dst_sampled_d, void* stream) {
+    if (!g || !src_d || !wgt_d || !dst_d || !dst_sampled_d || ((flags & URSO_EPI_EMIT_BITS) && !bits_out_d)) { urso_set_error("urso_conv_pointwise_sampled: null argument"); return URSO_EINVAL; }
+    if (!urso_conv_pointwise_sampled_ok(g, dt, flags, add_d != nullptr)) { urso_set_error("urso_conv_pointwise_sampled: the layer does not take the register-filter kernel (urso_conv_pointwise_sampled_ok)"); return URSO_EINVAL; }
+    if ((((uintptr_t)src_d) | ((uintptr_t)wgt_d) | ((uintptr_t)add_d) | ((uintptr_t)dst_d) | ((uintptr_t)bits_out_d) | ((uintptr_t)dst_sampled_d)) & 15) {
+        urso_set_error("urso_conv_pointwise_sampled: pointers must be 16-byte aligned"); return URSO_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const double M = (double)g->B * g->OH * g->OW;
+    ProfScope ps(st, URSO_K_IGEMM, 2.0 * M * g->C * g->N, M * 2.0 * (g->C + g->N * (add_d ? 2.25 : 1.25)) + ((flags & URSO_EPI_EMIT_BITS) ? M * g->N / 8 : 0.0));
+    return pair_single_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, nullptr, dst_d, (flags & URSO_EPI_EMIT_BITS) ? bits_out_d : nullptr, dst_sampled_d, st);
 }
 
 extern "C" int urso_conv_pair(long long M, int c_narrow, int dt, int mode, const void* src_d, const void* w1_d, const float* bias1_d,

@@ -259,9 +259,20 @@ class Engine(object):
                     X = c.src
                     if getattr(X, "data_compact", None) is None:
                         X.data_compact = torch.empty(X.numel // 4, dtype=self.tdt, device=dev)
-                        self.fwd_ops.append(lambda X=X, hh=node.src.h, ww=node.src.w, rb=node.cin * 2:
-                                            hip.rows_subsample2(B, hh, ww, rb, X.data, X.data_compact))
-                        self.labels["fwd"].append("subsample:T%d" % node.src.id)
+                        # ... by the layer that produces X where that is a stage-closing c -> 4c layer on the register-filter kernel
+                        # (urso_conv_pointwise_sampled: a second store from the LDS tile that holds the output rows), else by a gather pass
+                        P = [cc_ for cc_ in self.convs.values() if cc_.dst is X]
+                        Pc = P[0] if len(P) == 1 else None
+                        if (Pc is not None and not Pc.batch_bn and hasattr(Pc, "fwd_index") and hip.get_option("pair") and
+                                hip.conv_pointwise_sampled_ok(Pc.gf, dt, Pc.fwd_flags | hip.EPI_EMIT_BITS, Pc.res is not None)):
+                            self.fwd_ops[Pc.fwd_index] = (lambda Pc=Pc, X=X: hip.conv_pointwise_sampled(
+                                Pc.gf, dt, Pc.fwd_flags | (hip.EPI_EMIT_BITS if Pc.dst.bits is not None else 0), Pc.xin, Pc.wf, Pc.biasf,
+                                Pc.res.data if Pc.res is not None else None, Pc.dst.data, Pc.dst.bits, X.data_compact))
+                            self.labels["fwd"][Pc.fwd_index] = "fwd:%s+sampled" % Pc.name
+                        else:
+                            self.fwd_ops.append(lambda X=X, hh=node.src.h, ww=node.src.w, rb=node.cin * 2:
+                                                hip.rows_subsample2(B, hh, ww, rb, X.data, X.data_compact))
+                            self.labels["fwd"].append("subsample:T%d" % node.src.id)
                     c.gf = hip.geom(B, node.dst.h, node.dst.w, node.cin, node.dst.h, node.dst.w, c.npad, 1, 1)
                     c.xin = X.data_compact
             if node.cin % VE and not node.stem:

@@ -120,6 +120,8 @@ _SIGS = {
     "urso_stem_wgrad_pooled": (_i, [_gp, _i, _vp, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
+    "urso_conv_pointwise_sampled_ok": (_i, [_gp, _i, _i, _i]),
+    "urso_conv_pointwise_sampled": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rows_expand2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
@@ -459,6 +461,16 @@ def conv_pair_wgrad(M, dt, src, w1, add, bits, mid, w2, u, dst, part, colpart, p
     ah, aw = add_hw if add_hw else (0, 0)
     _chk(_lib.urso_conv_pair_wgrad(int(M), dt, ptr(src), ptr(w1), ptr(add), ptr(bits), ptr(mid), ptr(w2), ptr(u), ptr(dst), int(ah), int(aw),
                                    ptr(part), ptr(colpart), int(part_stride), stream_ptr(stream)), "urso_conv_pair_wgrad")
+
+
+def conv_pointwise_sampled_ok(g, dt, flags, has_add=False):
+    return bool(_lib.urso_conv_pointwise_sampled_ok(C.byref(g), dt, flags, int(bool(has_add))))
+
+
+def conv_pointwise_sampled(g, dt, flags, src, wgt, bias, add, dst, bits_out, dst_sampled, stream=None):
+    """urso_conv_pointwise_sampled: a stage-closing c -> 4c pointwise layer that also writes the even-row / even-column pixels of its output."""
+    _chk(_lib.urso_conv_pointwise_sampled(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(dst), ptr(bits_out), ptr(dst_sampled),
+                                          stream_ptr(stream)), "urso_conv_pointwise_sampled")
 
 
 def rows_expand2(B, H, W, row_bytes, src, dst, stream=None):
