@@ -42,7 +42,7 @@ enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
 #define URSO_EPI_EMIT_BITS 8   /* urso_conv_igemm_ex: also write the bit mask of (dst > 0) to bits_out_d  */
 
 const char* urso_last_error(void);
-int         urso_abi_version(void);           /* bumped on any signature change */
+int         urso_abi_version(void);           /* bumped on any signature or data-format change (6: arg-max bytes of the max-pool carry the ReLU decision in bit 4) */
 
 /*
  * Kernel-policy options (process-wide, explicit; defaults in parentheses).  They select between kernels / tile shapes
