@@ -676,6 +676,11 @@ void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int
 
 struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split, narrow; size_t part_elems, col_elems; };
 
+// conv_c3g.hip: the 64-channel 3x3 layers keep the whole gradient in registers (one partial per block)
+bool urso_c3g_fits(const urso_conv_geom* g, int dt);
+int urso_c3g_splits(const urso_conv_geom* g);
+int urso_c3g_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
+
 static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int es = (int)dt_size(dt);
     p.VE = 16 / es; p.RM = 128 / es;
@@ -702,6 +707,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     if (splits > max_splits) splits = max_splits;
     int steps_per = ceil_div(steps, splits);
     splits = ceil_div(steps, steps_per);
+    if (urso_c3g_fits(g, dt)) splits = urso_c3g_splits(g);      // that kernel: one partial per block
     p.splits = splits; p.m_per_split = steps_per * p.RM;
     p.part_elems = (size_t)splits * ((size_t)p.K * g->N + URSO_WGRAD_PART_PAD);
     p.col_elems = (size_t)splits * g->N;
@@ -794,7 +800,11 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
 #define URSO_WGP(TT, MD) do { if (MD == 0) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 0, true>), grid, dim3(256), 0, st, a); \
                          else if (MD == 1) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 1, true>), grid, dim3(256), 0, st, a); \
                          else hipLaunchKernelGGL((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)
-    if (dt == URSO_F32) URSO_WG(wgrad_kernel, float, mode);
+    if (!zscat && urso_c3g_fits(g, dt)) {
+        int rc3 = urso_c3g_launch(g, dt, x_d, dz_d, a.part, a.colpart, (size_t)p.K * g->N + URSO_WGRAD_PART_PAD, st);
+        if (rc3 != URSO_OK) return rc3;
+    }
+    else if (dt == URSO_F32) URSO_WG(wgrad_kernel, float, mode);
     else if (p.narrow) { if (dt == URSO_BF16) URSO_WG(wgrad_tr64_kernel, __bf16, tmode); else URSO_WG(wgrad_tr64_kernel, _Float16, tmode); }
     else if (dt == URSO_BF16) { if (pipe) URSO_WGP(__bf16, tmode); else URSO_WG(wgrad_tr_kernel, __bf16, tmode); }
     else { if (pipe) URSO_WGP(_Float16, tmode); else URSO_WG(wgrad_tr_kernel, _Float16, tmode); }
