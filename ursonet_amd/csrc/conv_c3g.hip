@@ -26,7 +26,7 @@ constexpr int CG_ABUF = 224 * 128, CG_ZOFF = CG_ABUF, CG_STAGE = CG_ABUF + CG_TH
 // slot swizzle of the 128-byte rows of both tiles.  They are read ONLY by transposing reads (4 consecutive rows x 32 bytes per 16-lane
 // group): XOR-ing the 32-byte block index with (row >> 1) & 3 puts the four rows of a group on four different bank quarters
 #ifndef CG_SWZ
-#define CG_SWZ(r) ((((r) >> 1) & 3) << 1)
+#define CG_SWZ(r) ((((r) >> 1) & 1) << 2)
 #endif
 template <typename T> struct CgMma;
 template <> struct CgMma<__bf16> {
