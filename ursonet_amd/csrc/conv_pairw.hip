@@ -83,6 +83,13 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
     //      slot lane & 31, logical slot = slot ^ (row & 15).
     const int nrow = 8 * wave + (lane >> 3);
     const uint32_t noff = (uint32_t)(nrow * 128 + (((lane & 7) ^ ((nrow >> 1) & 7)) << 4));
+    // the u (and P) tiles are read by transposing reads (4 consecutive rows x 2 x 32 bytes per half wave) and once linearly for the masks:
+    // their 32-byte blocks are swizzled with ((row >> 1) & 1) << 1, which separates the two row pairs of such a read (conv_c3g.hip:
+    // LDS bank conflicts 42 percent -> 0); toff = the DMA source offset for that layout, moff = where this lane's mask vector (the element
+    // of its dst vector, which sits in the OTHER swizzle) lies in it
+#define PW_SWZT(r) ((((r) >> 1) & 1) << 2)
+    const uint32_t toff = (uint32_t)(nrow * 128 + (((lane & 7) ^ PW_SWZT(nrow)) << 4));
+    const uint32_t moff = (uint32_t)(nrow * 128 + (((lane & 7) ^ ((nrow >> 1) & 7) ^ PW_SWZT(nrow)) << 4));
     uint32_t roff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
     auto dma_tile = [&](int t, int buf) {
         const uint32_t nb = (uint32_t)t * (BM * 128u), wb = (uint32_t)t * (BM * 512u), sb = lds0 + buf * PW_STAGE;
         if constexpr (!SOLO) pw_dma16(rs, sb + PW_A + wave * 1024, nb + noff);
-        pw_dma16(ru, sb + PW_U + wave * 1024, nb + noff);
+        pw_dma16(ru, sb + PW_U + wave * 1024, nb + toff);
         if constexpr (!SPARSE) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pw_dma16(ra, sb + PW_R + (wave + NW * i) * 1024, wb + roff[i]);
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int slot = 2 * (2 * ct + (g & 1)) + (tp >> 1);
-            tu[ct][q] = (uint32_t)(PW_U + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + (tp & 1) * 8);
+            tu[ct][q] = (uint32_t)(PW_U + row * 128 + ((slot ^ PW_SWZT(row)) << 4) + (tp & 1) * 8);
         }
         const int slot = 2 * (2 * wave + (g & 1)) + (tp >> 1);
         tm[q] = (uint32_t)(PW_R + row * 512 + ((slot ^ (row & 15)) << 4) + (tp & 1) * 8);
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
             pw_barrier();                                      // (3)
             {
                 i32x4_t v = *(const i32x4_t*)(st + PW_A + wave * 1024 + lane * 16);
-                const i32x4_t m4 = *(const i32x4_t*)(st + PW_U + wave * 1024 + lane * 16);
+                const i32x4_t m4 = *(const i32x4_t*)(st + PW_U + moff);
                 T x[8], m[8];
                 __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &m4, 16);
 #pragma unroll

@@ -99,6 +99,13 @@ __global__ __launch_bounds__(512, 2) void pairx_kernel(const PairxArgs a) {
     //      the wide tile four (rows 2 (wave + 8 i) + (lane >> 5), slot (lane & 31) ^ (row & 15))
     const int nrow = 8 * wave + (lane >> 3);
     const uint32_t noff = (uint32_t)(nrow * 128 + (((lane & 7) ^ ((nrow >> 1) & 7)) << 4));
+    // the u (and P) tiles are read by transposing reads (4 consecutive rows x 2 x 32 bytes per half wave) and once linearly for the masks:
+    // their 32-byte blocks are swizzled with ((row >> 1) & 1) << 1, which separates the two row pairs of such a read (conv_c3g.hip:
+    // LDS bank conflicts 42 percent -> 0); toff = the DMA source offset for that layout, moff = where this lane's mask vector (the element
+    // of its dst vector, which sits in the OTHER swizzle) lies in it
+#define PX_SWZT(r) ((((r) >> 1) & 1) << 2)
+    const uint32_t toff = (uint32_t)(nrow * 128 + (((lane & 7) ^ PX_SWZT(nrow)) << 4));
+    const uint32_t moff = (uint32_t)(nrow * 128 + (((lane & 7) ^ ((nrow >> 1) & 7) ^ PX_SWZT(nrow)) << 4));
     uint32_t roff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(512, 2) void pairx_kernel(const PairxArgs a) {
     };
     auto dma_side = [&](int t, int s2) {                       // 2 instructions
         const uint32_t nb = (uint32_t)t * (BM * 128u), sb = lds0 + PX_S2BASE + s2 * PX_S2;
-        px_dma16(ru, sb + PX_U + wave * 1024, nb + noff);
-        px_dma16(rp, sb + PX_P + wave * 1024, nb + noff);
+        px_dma16(ru, sb + PX_U + wave * 1024, nb + toff);
+        px_dma16(rp, sb + PX_P + wave * 1024, nb + toff);
     };
     constexpr int NMAIN = 5, NSIDE = 2, NPRE = 2, NST = 2;
 
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void pairx_kernel(const PairxArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int slot = 2 * (2 * ct + (g & 1)) + (tp >> 1);
-            tn[ct][q] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + (tp & 1) * 8);
+            tn[ct][q] = (uint32_t)(row * 128 + ((slot ^ PX_SWZT(row)) << 4) + (tp & 1) * 8);
         }
         const int slot = 2 * (2 * wave + (g & 1)) + (tp >> 1);
         tm[q] = (uint32_t)(PX_R + row * 512 + ((slot ^ (row & 15)) << 4) + (tp & 1) * 8);
@@ -279,9 +286,9 @@ __global__ __launch_bounds__(512, 2) void pairx_kernel(const PairxArgs a) {
             px_barrier();                                      // (3)
             {
                 i32x4_t v = *(const i32x4_t*)(st + PX_A + wave * 1024 + lane * 16);
-                const i32x4_t m4 = *(const i32x4_t*)(sd + PX_U + wave * 1024 + lane * 16);
+                const i32x4_t m4 = *(const i32x4_t*)(sd + PX_U + moff);
                 i32x4_t vp = *(const i32x4_t*)(smem + PX_DP + wave * 1024 + lane * 16);
-                const i32x4_t mp = *(const i32x4_t*)(sd + PX_P + wave * 1024 + lane * 16);
+                const i32x4_t mp = *(const i32x4_t*)(sd + PX_P + moff);
                 T x[8], m[8];
                 __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &m4, 16);
 #pragma unroll

@@ -10,7 +10,7 @@
 //   * A (rows = 32 k of one window row ky, reduction = 16 output pixels of one tile row): the 32 k of output pixel cx are the 64
 //     contiguous bytes at patch row 2 ry + ky, byte 16 cx -- a transposing read of 4 "rows" (pixels cx .. cx + 3, 16 B apart: the
 //     windows overlap) x 16 k each gives a lane its k for 4 consecutive pixels;
-//   * B (reduction = the same pixels, columns = 32 filters): dz tile [256 pixels][128 B] (LDS-DMA, slot ^ ((row >> 1) & 7)) read the same way.
+//   * B (reduction = the same pixels, columns = 32 filters): dz tile [256 pixels][128 B] (LDS-DMA, slot ^ SW_SWZT(row)) read the same way.
 // 4 waves: wave (nh = w & 1, ks = w >> 1) owns filters 32 nh .. +31 and window rows ky = ks, ks + 2, .. (4 or 3 of the 7; the waves
 // with 3 also carry the column sums: an all-ones A operand) -- 64 persistent accumulator registers, never reset: a block walks its
 // tiles and writes ONE fp32 partial [224][64] (+ [64]) at the end; the partials are summed in a fixed order by reduce_partials_kernel.
@@ -41,6 +41,8 @@ constexpr int SW_PATCH = 12288, SW_ZOFF = SW_PATCH, SW_LDS = SW_ZOFF + 32768;
 constexpr int SW_PR = SW_TH / 2 + 1, SW_PC = SW_TW / 2 + 1, SW_PP = SW_PR * SW_PC;           // 5 x 17 pooled pixels touch a tile
 constexpr int SW_DPOFF = SW_LDS, SW_AMOFF = SW_DPOFF + 12288, SW_LDS_POOLED = SW_AMOFF + 8192;   // 85 x 128 B, 85 x 64 B; sized for the whole DMA instructions (the lanes past pixel 84 write zeros)
 
+// the dz tile is read only by transposing reads: 32-byte-block swizzle that separates the two row pairs of such a read (conv_c3g.hip)
+#define SW_SWZT(r) ((((r) >> 1) & 1) << 2)
 template <typename T> struct SwMma;
 template <> struct SwMma<__bf16> {
     static constexpr int ONES = 0x3F803F80;
@@ -89,9 +91,9 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
     uint32_t zoff[2];                                           // dz tile: row = pixel, 16-filter block 2 nh + (g & 1)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int row = pix8 + 4 * q;                          // + 16 hs + 32 ry: adds a multiple of 16 rows, the swizzle ((row >> 1) & 7) repeats
+        const int row = pix8 + 4 * q;                          // + 16 hs + 32 ry: adds a multiple of 16 rows, the swizzle SW_SWZT(row) repeats
         const int slot = 2 * (2 * nh + (g & 1)) + ((l15 & 3) >> 1);
-        zoff[q] = (uint32_t)(SW_ZOFF + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + ((l15 & 3) & 1) * 8);
+        zoff[q] = (uint32_t)(SW_ZOFF + row * 128 + ((slot ^ SW_SWZT(row)) << 4) + ((l15 & 3) & 1) * 8);
     }
 
     f32x16_t acc[4];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
             for (int i = 0; i < 8; ++i) {
                 const int row = 8 * (wave + 4 * i) + (lane >> 3);
                 const int oy = oy0 + (row >> 5), ox = ox0 + (row & 31);
-                const uint32_t so = (oy < a.OH && ox < a.OW) ? (uint32_t)(((b * a.OH + oy) * a.OW + ox) * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) : URSO_OOB_SHIFT;
+                const uint32_t so = (oy < a.OH && ox < a.OW) ? (uint32_t)(((b * a.OH + oy) * a.OW + ox) * 128 + (((lane & 7) ^ SW_SWZT(row)) << 4)) : URSO_OOB_SHIFT;
                 sw_dma16(rz, lds0 + SW_ZOFF + (wave + 4 * i) * 1024, so);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
                     for (int q = 0; q < 8; ++q) o[q] = Elem<T>::from_f(gsum[k][q]);
                     i32x4_t ov; __builtin_memcpy(&ov, o, 16);
                     const int row = (2 * by + (k >> 1)) * 32 + 2 * bx + (k & 1);
-                    *(i32x4_t*)(smem + SW_ZOFF + row * 128 + ((cv ^ ((row >> 1) & 7)) << 4)) = ov;
+                    *(i32x4_t*)(smem + SW_ZOFF + row * 128 + ((cv ^ SW_SWZT(row)) << 4)) = ov;
                 }
             }
             __syncthreads();
