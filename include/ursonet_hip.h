@@ -62,6 +62,11 @@ int         urso_abi_version(void);           /* bumped on any signature or data
  *   c3 (1)            register-resident-filter kernels (conv_c3.hip) for 3x3 stride-1 layers: 64 channels / filters always, 128 / 128
  *                     where the 4 x 32 tiles cover the image to >= 88 % (else the halo kernel); 2: only the 64-channel form, 3: both always
  *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
+ *   cus (0)           > 0: the CUs the persistent conv grids, the weight-gradient split and their workspaces are planned for (whole XCD
+ *                     rows of 8; 0 = all of the device's).  A data-parallel host sets it to (CUs - what the collective's resident
+ *                     workgroups hold) BEFORE it plans a step, so that a CU held by RCCL never gives a statically partitioned tile
+ *                     stream a second wave; split counts (urso_*_splits, urso_conv_wgrad_ws_bytes) follow it, so it must not change
+ *                     between planning and launching
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
  *                     itself never fuses behind the caller's back); 1 also lets the stage-2 backward pair accumulate the block-closing
  *                     layer's weight gradient (urso_conv_pair_wgrad) and the first stage-2 forward pair take the projection shortcut in

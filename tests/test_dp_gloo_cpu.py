@@ -145,3 +145,16 @@ def test_bf16_gradient_buckets_with_error_feedback():
     mp.spawn(_worker_bf16, args=(2, _free_port(), out), nprocs=2, join=True)
     assert 5e-4 < out["single"] < 8e-3, dict(out)
     assert out["accumulated"] < 2e-3 and out["accumulated"] < 0.3 * out["single"], dict(out)
+
+
+def test_reserved_comm_cus_bound_rccl_channels(monkeypatch):
+    """reserve_comm_cus: the CUs DataParallelEngine plans around are also the bound handed to RCCL (one resident workgroup per
+    channel); an explicit NCCL_MAX_NCHANNELS in the environment is left alone, 0 switches the reservation off."""
+    from ursonet_amd import dp
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("URSO_DP_COMM_CUS", raising=False)
+    assert dp.reserve_comm_cus() == dp.DEFAULT_COMM_CUS and os.environ["NCCL_MAX_NCHANNELS"] == str(dp.DEFAULT_COMM_CUS)
+    assert dp.reserve_comm_cus(24) == 24 and os.environ["NCCL_MAX_NCHANNELS"] == str(dp.DEFAULT_COMM_CUS)      # explicit setting wins
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("URSO_DP_COMM_CUS", "0")
+    assert dp.reserve_comm_cus() == 0 and "NCCL_MAX_NCHANNELS" not in os.environ

@@ -529,6 +529,7 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
     import torch.distributed as dist
     from ursonet_amd.engine import Engine
     from ursonet_amd.dp import DataParallelEngine
+    from ursonet_amd import hip
     monkeypatch.setenv("URSO_DP_FORCE_COLLECTIVES", "1")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
@@ -551,7 +552,21 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
             torch.cuda.synchronize()
             assert torch.equal(eng.flat_w, plain.flat_w), "DP (1 rank) differs from the plain engine (exact=%s)" % exact
             assert eng.losses() == plain.losses()
+        # CUs reserved for the collective (comm_cus): the DP engine re-plans grids and weight-gradient splits for (CUs - comm_cus), option
+        # `cus`, process-wide; a plain engine planned under the same option value is again matched bit for bit
+        total = torch.cuda.get_device_properties(0).multi_processor_count
+        eng = Engine(cfg, "training", seed=8, randomize_bn=True, grad_bucket_bytes=8 << 20)
+        dp = DataParallelEngine(eng, bucket_bytes=8 << 20, comm_cus=total - 64)
+        assert hip.get_option("cus") == 64
+        plain = Engine(cfg, "training", seed=8, randomize_bn=True)
+        for e, step in ((plain, plain.step), (eng, dp.step)):
+            e.load_batch(img, loc, ori)
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.flat_w, plain.flat_w) and eng.losses() == plain.losses()
     finally:
+        hip.set_option("cus", 0)
         dist.destroy_process_group()
 
 
@@ -621,6 +636,33 @@ def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
         else:
             assert torch.equal(a, b), (ln, wn)
     assert len(seen) == 6, seen
+
+
+def test_step_planned_for_fewer_cus():
+    """Option cus (what DataParallelEngine(comm_cus=N) sets before it plans): grids, weight-gradient splits and workspaces are planned
+    for 64 of the device's CUs, so every persistent kernel walks a multi-tile stream and every split reduction sums another number of
+    partials.  Same step up to summation order (fp32 partial sums of the weight gradients; where a stream-K 3x3 tile is cut).
+    The option is held while the step runs: split counts are queried at plan AND launch time and must agree."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 128, 192, batch=4, regress_ori=False, ori_bins=4, dtype="bfloat16", lr=1e-3)
+    img, loc, ori, _ = synthetic_batch(cfg, 4, seed=23)
+    res = []
+    for cus in (0, 64):
+        with hip.options(cus=cus):
+            eng = Engine(cfg, "training", seed=7, randomize_bn=True)
+            eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+            res.append((eng.flat_g.clone(), eng.losses(), eng.flat_w.clone(), sum(getattr(c, "splits", 0) for c in eng.convs.values())))
+    assert res[1][3] < res[0][3]                   # fewer partials were planned
+    # a stream-K 3x3 tile or a split-K GEMM is cut at other boundaries (fp32 order, then one 16-bit rounding): two valid 16-bit runs, whose
+    # rounding flips make tensor-wise gradient comparisons meaningless (see test_fused_pointwise_pairs_...); what a plan/launch
+    # disagreement about a split count would produce is garbage or NaN, which these bounds exclude
+    for k, v in res[0][1].items():
+        assert abs(v - res[1][1][k]) <= 2e-2 * abs(v) + 1e-4, (k, v, res[1][1][k])
+    g0, g1 = res[0][0].double(), res[1][0].double()
+    assert bool(torch.isfinite(g1).all()) and float(g0.norm()) > 0
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cos >= 0.98 and 0.9 <= float(g1.norm() / g0.norm()) <= 1.1, cos
 
 
 def test_urso_comm_bucket_averaging_one_rank():

@@ -29,9 +29,13 @@ struct UrsoOptions {
     int pair = 1;            // conv_pair.hip: fused pointwise pairs of stages 2-3 (read by the host plan, ursonet_amd/engine.py)
     int c3 = 1;              // conv_c3.hip (register-resident 3x3 filter) for 64-channel / 64-filter 3x3 layers
     int stem = 1;            // conv_stem.hip (im2col on the LDS read side) for the packed 7x7 stem
+    int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);
+                             // ursonet_amd/dp.py leaves the rest to the collective's resident workgroups.  0 = all of the device's
     int hconv_dbg = 0;       // kernel-development switches of conv_halo.hip (0 in production)
 };
 extern UrsoOptions g_urso_opt;
+int urso_device_cus();      // CUs of the current device (runtime.hip)
+int urso_usable_cus();      // the same, or option `cus` when that is smaller: what every grid / split / workspace plan is sized for
 
 #define URSO_REDUCE_COLS 256   // threads per block of the split-reduction kernels (conv_wgrad.hip): (256 / lanes) float4 columns x lanes; prep.hip plans with it
 // split-lanes of the reduction for a layer with `splits` partials (each lane adds <= ~48 splits in a row)

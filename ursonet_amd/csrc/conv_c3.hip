@@ -417,15 +417,7 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
     }
 }
 
-static int c3_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int c3_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // 128-channel form: percentage of the tiles' pixels that lie inside the image, for the 4 x 32 (tw = 32) or 8 x 16 (tw = 16) geometry
 static int c3w_util(int H, int W, int tw) {

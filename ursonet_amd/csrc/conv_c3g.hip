@@ -171,15 +171,7 @@ __global__ __launch_bounds__(512, 2) void c3g_kernel(const C3gArgs a) {
     }
 }
 
-static int cg_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int cg_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // 3x3 / stride 1 / pad 1, 64 channels, 64 filters, dense dz, 16-bit (option "c3")
 bool urso_c3g_fits(const urso_conv_geom* g, int dt) {

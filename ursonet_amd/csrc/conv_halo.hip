@@ -397,15 +397,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     }
 }
 
-static int hc_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int hc_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 128 == 0, N % 128 == 0, halo tile within the LDS
 // budget -- and a tile count that fills the 256 one-block-per-CU slots evenly: every block walks ceil(tiles / blocks) tiles, so e.g. 340
@@ -429,7 +421,7 @@ bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add
 }
 
 // hand-over workspace of the stream-K schedule: 4 KiB of flags (zero on entry, left zero) + one 128 KiB accumulator slab per block
-size_t urso_hconv_ws_bytes() { return 4096 + (size_t)hc_device_cus() * 512 * 64 * sizeof(float); }
+size_t urso_hconv_ws_bytes() { return 4096 + (size_t)urso_device_cus() * 512 * 64 * sizeof(float); }       // sized for the whole device: independent of option `cus`
 
 int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,

@@ -414,15 +414,7 @@ size_t urso_hconv_ws_bytes();
 
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
-static int device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 template <typename T>
 static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -415,15 +415,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     }
 }
 
-static int pr_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int pr_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 extern "C" int urso_conv_pair_ok(long long M, int dt, int c_narrow, int c_wide) {
     if (M <= 0 || !(dt == URSO_BF16 || dt == URSO_F16) || c_wide != 4 * c_narrow) return 0;

@@ -228,15 +228,7 @@ __global__ __launch_bounds__(256, 2) void pairs_kernel(const PairsArgs a) {
     }
 }
 
-static int ps_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int ps_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 extern "C" int urso_conv_pair_shortcut(long long M, int dt, const void* src_d, const void* w1_d, const float* bias1_d,
                                        const void* xin_d, const void* ws_d, const float* bias_s_d, void* bits_d, void* mid_d,

@@ -306,15 +306,7 @@ __global__ __launch_bounds__(512, 2) void pairw_kernel(const PairwArgs a) {
     if (a.colpart && h == 0) a.colpart[(size_t)blockIdx.x * 256 + 32 * wave + l31] = accc[0];
 }
 
-static int pw_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int pw_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 static int pw_grid(long long M) {
     int bpx = ceil_div((int)(M / PW_BM), 8);

@@ -353,15 +353,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
     }
 }
 
-static int pw_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int pw_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,

@@ -176,15 +176,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     }
 }
 
-static int st_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int st_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // conv_igemm.hip asks before choosing a kernel for the packed stem geometry (option "stem": 0 keeps it on conv_pw.hip).
 bool urso_stem_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask) {

@@ -232,15 +232,7 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
     }
 }
 
-static int sw_device_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    return ncu;
-}
+static int sw_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // the packed stem geometry (conv_stem.hip urso_stem_fits), 16-bit, option "stem"
 bool urso_stemw_fits(const urso_conv_geom* g, int dt) {

@@ -697,7 +697,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int steps = ceil_div(p.M, p.RM);
     // aim for ~2 resident blocks per CU (64 KiB LDS each) but keep >= 8 reduction steps per block;
     // every extra split costs a K*N fp32 partial written and re-read, so do not over-split
-    const int target = g_urso_opt.wgrad_blocks;
+    const int target = (int)((long long)g_urso_opt.wgrad_blocks * urso_usable_cus() / urso_device_cus());     // option `cus` scales the resident-block target with the CUs it may fill
 #ifndef URSO_WGRAD_NARROW_PCT
 #define URSO_WGRAD_NARROW_PCT 150                     // narrow tiles use 48 KiB of LDS: 3 blocks fit a CU, so they get 1.5x the block target (+1 % on the step)
 #endif

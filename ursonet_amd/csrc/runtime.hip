@@ -28,9 +28,23 @@ static int* opt_slot(const char* name) {
     if (!name) return nullptr;
 #define URSO_OPT(n) if (!strcmp(name, #n)) return &g_urso_opt.n;
     URSO_OPT(pw_kernel) URSO_OPT(pw_small) URSO_OPT(igemm_shortk) URSO_OPT(wgrad_narrow) URSO_OPT(wgrad_blocks) URSO_OPT(wgrad_pipe)
-    URSO_OPT(grid_cap) URSO_OPT(hconv) URSO_OPT(hconv_dbg) URSO_OPT(pair) URSO_OPT(c3) URSO_OPT(stem)
+    URSO_OPT(grid_cap) URSO_OPT(hconv) URSO_OPT(hconv_dbg) URSO_OPT(pair) URSO_OPT(c3) URSO_OPT(stem) URSO_OPT(cus)
 #undef URSO_OPT
     return nullptr;
+}
+int urso_device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+int urso_usable_cus() {
+    const int hw = urso_device_cus(), want = g_urso_opt.cus;
+    if (want <= 0 || want >= hw) return hw;
+    return want < 8 ? 8 : want / 8 * 8;
 }
 extern "C" int urso_set_option(const char* name, int value) {
     int* s = opt_slot(name);

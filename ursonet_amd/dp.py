@@ -12,8 +12,12 @@ towards its start, because that is the order in which the backward pass finalise
 xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): buckets are large (default 32 MiB)
 so each collective is bandwidth- not latency-bound, and there are few of them.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import hip
 
 
 def plan_buckets(layer_sizes, bucket_bytes=32 << 20):
@@ -38,6 +42,22 @@ def allreduce_rel_norms(norms, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1 or _force_collectives():
         dist.all_reduce(norms, op=dist.ReduceOp.SUM, group=group)
     return norms
+
+
+DEFAULT_COMM_CUS = 16
+
+
+def reserve_comm_cus(n=None):
+    """Call BEFORE dist.init_process_group: bounds RCCL's resident workgroups (one per channel, NCCL_MAX_NCHANNELS; an explicit
+    setting in the environment wins) to the CUs DataParallelEngine leaves free, and returns that number.  16 channels carry the
+    134 MB gradient of cfg2 several times over inside one backward pass; measured on one GPU with a stand-in kernel
+    (profiles/r02_dp_cu_contention.json): 8 held CUs cost full-size grids +30 % on the step, planning for 16 fewer CUs costs 2.6 %."""
+    if n is None:
+        n = int(os.environ.get("URSO_DP_COMM_CUS", str(DEFAULT_COMM_CUS)))
+    n = max(0, int(n))
+    if n > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    return n
 
 
 def _force_collectives():
@@ -104,10 +124,21 @@ class GradReducer(object):
 class DataParallelEngine(object):
     """Wraps an Engine: broadcasts the initial weights, splits the captured step into
     [prep+forward+loss+backward-part-0], [backward-part-1], ..., [optimizer] hipGraphs and
-    interleaves the bucket all-reduces between their replays."""
+    interleaves the bucket all-reduces between their replays.  Construct it BEFORE the first load_batch: a bucket size or comm_cus
+    that differs from the engine's plan rebuilds the plan, which reallocates the activation (and input) buffers."""
 
-    def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None, comm=None):
+    def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None, comm=None, comm_cus=None):
         self.eng, self.group, self.compress, self.comm = engine, group, compress, comm
+        # CUs left to the collective's resident workgroups.  Every persistent conv grid is a static partition of the tile stream over
+        # "all CUs"; a CU held by an RCCL workgroup makes the blocks that wanted it wait for a whole stream to finish -- a second wave.
+        # With comm_cus > 0 the library plans grids, weight-gradient splits and workspaces for (CUs - comm_cus) instead (option `cus`,
+        # include/ursonet_hip.h), process-wide: one process drives one GPU.  tools/dp_cu_contention.py measures both sides of the
+        # trade on one GPU (profiles/r02_dp_cu_contention.json).  Default: URSO_DP_COMM_CUS, else 16 (reserve_comm_cus above keeps
+        # RCCL inside that many); 0 = full grids.  Only applied when collectives actually run (world > 1).
+        explicit = comm_cus is not None              # a forced-collective run with one rank reserves only when asked to
+        if comm_cus is None:
+            comm_cus = int(os.environ.get("URSO_DP_COMM_CUS", str(DEFAULT_COMM_CUS)))
+        self.comm_cus = max(0, int(comm_cus))
         self.world = dist.get_world_size(group)
         # DP_EXACT_REL_LOSS: the location loss is ONE ratio of norms over the global batch (net.py:750-762); its two squared norms are
         # summed over the ranks between forward and backward and the gradient is pre-scaled by the world size (undone by the averaging)
@@ -118,7 +149,14 @@ class DataParallelEngine(object):
         dist.broadcast(eng.flat_w, src=0, group=group)
         dist.broadcast(eng.flat_stats, src=0, group=group)
         # gradient buckets are planned by the engine (it batches the gradient finalisation per bucket)
-        if bucket_bytes != eng.grad_bucket_bytes:
+        replan = False
+        if self.comm_cus and eng.device.type == "cuda" and (self.world > 1 or (explicit and _force_collectives())):
+            total = torch.cuda.get_device_properties(eng.device).multi_processor_count
+            usable = max(8, total - self.comm_cus)
+            if hip.get_option("cus") != usable:
+                hip.set_option("cus", usable)           # split counts follow it: the plan below must be rebuilt under the new value
+                replan = True
+        if bucket_bytes != eng.grad_bucket_bytes or replan:
             eng.grad_bucket_bytes = int(bucket_bytes)
             eng._graphs = None
             eng._build_plan()

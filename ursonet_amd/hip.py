@@ -146,7 +146,7 @@ def _chk(rc, what):
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "pair", "c3", "stem")
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "pair", "c3", "stem", "cus")
 
 
 def set_option(name, value):
