@@ -39,6 +39,13 @@ for name, comp in (("dp_segments_fp32_ms", None), ("dp_segments_bf16_ms", "bf16"
     out["buckets"] = [(e - s_) * 4 for s_, e, _ in dp.buckets]
     del dp, e2
     torch.cuda.empty_cache()
+from ursonet_amd import hip
+e3 = Engine(cfg, "training", seed=1, randomize_bn=True)
+dp = DataParallelEngine(e3, comm_cus=16)               # re-plans for 240 CUs (option cus): what the reservation costs while nothing is beside the step
+e3.load_batch(img, loc, ori)
+out["dp_segments_fp32_comm_cus16_ms"] = timed(dp.step)
+hip.set_option("cus", 0)
+del dp, e3
 out["note"] = ("world size 1, RCCL calls forced: overhead of the per-bucket graph segmentation + stream events + (bf16) the rounding / "
                "error-feedback passes; no bytes move.  No multi-GPU scaling curve exists for this build yet.")
 print(json.dumps(out))
