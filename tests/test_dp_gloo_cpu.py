@@ -26,6 +26,11 @@ def test_plan_buckets_backward_order():
     assert covered[0][0] == 0 and covered[-1][1] == 9100 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
     one = plan_buckets(layers, bucket_bytes=1 << 30)
     assert one == [(0, 9100, ["e", "d", "c", "b", "a"])]
+    # capped tail: the layers at the start of the buffer that fit form the last bucket on their own
+    t = plan_buckets(layers, bucket_bytes=1 << 30, tail_bytes=3000 * 4)
+    assert t == [(3000, 9100, ["e", "d", "c"]), (0, 3000, ["b", "a"])]
+    assert plan_buckets(layers, bucket_bytes=1 << 30, tail_bytes=100) == one           # nothing fits: unchanged
+    assert plan_buckets(layers, bucket_bytes=1 << 30, tail_bytes=1 << 30)[-1] == (0, 9000, ["d", "c", "b", "a"])   # never the whole buffer
 
 
 def _free_port():

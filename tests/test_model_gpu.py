@@ -556,9 +556,13 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
         # `cus`, process-wide; a plain engine planned under the same option value is again matched bit for bit
         total = torch.cuda.get_device_properties(0).multi_processor_count
         eng = Engine(cfg, "training", seed=8, randomize_bn=True, grad_bucket_bytes=8 << 20)
-        dp = DataParallelEngine(eng, bucket_bytes=8 << 20, comm_cus=total - 64)
+        dp = DataParallelEngine(eng, bucket_bytes=8 << 20, comm_cus=total - 64, tail_bytes=256 << 10)
         assert hip.get_option("cus") == 64
+        # ... and the stem-side bucket capped (what world size > 1 gets by default): one more, small, last bucket
+        assert (dp.buckets[-1][1] - dp.buckets[-1][0]) * 4 <= 256 << 10 and dp.buckets[-1][0] == 0 and "conv1" in dp.buckets[-1][2]
         plain = Engine(cfg, "training", seed=8, randomize_bn=True)
+        plain.grad_bucket_bytes, plain.grad_tail_bytes = 8 << 20, 256 << 10      # same buckets: a layer pair whose weight gradients share a launch
+        plain._build_plan()                                                      # only when they share a bucket sums in another fp32 order otherwise
         for e, step in ((plain, plain.step), (eng, dp.step)):
             e.load_batch(img, loc, ori)
             for _ in range(3):

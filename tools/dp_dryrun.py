@@ -19,14 +19,18 @@ cfg = make_config(backbone="resnet50", h=512, w=640, batch=32, regress_ori=False
 img, loc, ori, _ = synthetic_batch(cfg, 32, seed=1)
 
 
-def timed(step, n=30, warm=8):
+def timed(step, n=20, warm=8, reps=3):
+    """Median of `reps` timings of n steps (the first collective of a process also pays RCCL's lazy set-up: warm-up covers it)."""
     for _ in range(warm):
         step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    ms = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) / n * 1e3)
+    return sorted(ms)[len(ms) // 2]
 
 
 out = {}
@@ -46,6 +50,12 @@ e3.load_batch(img, loc, ori)
 out["dp_segments_fp32_comm_cus16_ms"] = timed(dp.step)
 hip.set_option("cus", 0)
 del dp, e3
+e4 = Engine(cfg, "training", seed=1, randomize_bn=True)
+dp = DataParallelEngine(e4, tail_bytes=1 << 20)        # what a world size > 1 gets by default: the stem-side bucket capped at 1 MiB
+e4.load_batch(img, loc, ori)
+out["dp_segments_fp32_tail_1MiB_ms"] = timed(dp.step)
+out["buckets_tail_1MiB"] = [(e - s_) * 4 for s_, e, _ in dp.buckets]
+del dp, e4
 out["note"] = ("world size 1, RCCL calls forced: overhead of the per-bucket graph segmentation + stream events + (bf16) the rounding / "
                "error-feedback passes; no bytes move.  No multi-GPU scaling curve exists for this build yet.")
 print(json.dumps(out))

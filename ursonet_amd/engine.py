@@ -79,6 +79,7 @@ class Engine(object):
     def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False, grad_bucket_bytes=32 << 20):
         assert mode in ("training", "inference")
         self.grad_bucket_bytes = int(grad_bucket_bytes)
+        self.grad_tail_bytes = 0                       # > 0: the last bucket (stem side) is capped at this size; set by ursonet_amd/dp.py (plan_buckets)
         if not torch.cuda.is_available():
             raise RuntimeError("ursonet_amd.Engine needs an AMD GPU (MI355X / gfx950); there is no CPU fallback")
         self.config, self.mode = config, mode
@@ -380,7 +381,8 @@ class Engine(object):
         for (ln, wn), (o, n, _) in self.slices.items():
             s0, e0 = ext.get(ln, (o, o))
             ext[ln] = (min(s0, o), max(e0, o + _round_up(n, 4)))
-        self.buckets = plan_buckets(sorted(((ln, s0, e0) for ln, (s0, e0) in ext.items()), key=lambda t: t[1]), self.grad_bucket_bytes)
+        self.buckets = plan_buckets(sorted(((ln, s0, e0) for ln, (s0, e0) in ext.items()), key=lambda t: t[1]), self.grad_bucket_bytes,
+                                    tail_bytes=self.grad_tail_bytes)
         bucket_of = {ln: k for k, (_, _, names) in enumerate(self.buckets) for ln in names}
         groups = OrderedDict()                      # bucket index -> [conv names], backward order
         for node in reversed(g.nodes):
