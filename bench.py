@@ -211,6 +211,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dp_info = None
+    if world > 1 or force_dp:                      # outside the timed region: what the backward pass did not hide of the exchange step
+        ex = torch.tensor([runner.exposed_comm_ms(5)], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        dp_info = {"exposed_comm_ms": round(float(ex.item()), 4), "bucket_bytes": [(e - s_) * 4 for s_, e, _ in runner.buckets],
+                   "comm_cus": comm_cus, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"), "compress": runner.compress}
     losses = eng.losses()
     if rank != 0:
         if dist.is_initialized():
@@ -267,7 +274,7 @@ def main():
                                                                                      args.width, "+RCCL all-reduce" if world > 1 else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "comm_cus": comm_cus, "hipgraph": True,
                    "step_tflop": round(step_flops / 1e12, 3), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
-        "roofline": roofline, "kernels": kernels, "pcie_inclusive": pcie,
+        "roofline": roofline, "kernels": kernels, "pcie_inclusive": pcie, "dp": dp_info,
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline({"h": args.height, "w": args.width, "backbone": args.backbone, "ori_bins": args.ori_bins},

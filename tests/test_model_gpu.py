@@ -569,6 +569,8 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
                 step()
         torch.cuda.synchronize()
         assert torch.equal(eng.flat_w, plain.flat_w) and eng.losses() == plain.losses()
+        ex = dp.exposed_comm_ms(2)             # events around the join with the collectives' stream; one rank moves no bytes
+        assert 0.0 <= ex < 5.0, ex
     finally:
         hip.set_option("cus", 0)
         dist.destroy_process_group()

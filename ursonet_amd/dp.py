@@ -143,6 +143,7 @@ class DataParallelEngine(object):
 
     def __init__(self, engine, bucket_bytes=32 << 20, group=None, compress=None, comm=None, comm_cus=None, tail_bytes=None):
         self.eng, self.group, self.compress, self.comm = engine, group, compress, comm
+        self._exposed_events = None
         # CUs left to the collective's resident workgroups.  Every persistent conv grid is a static partition of the tile stream over
         # "all CUs"; a CU held by an RCCL workgroup makes the blocks that wanted it wait for a whole stream to finish -- a second wave.
         # With comm_cus > 0 the library plans grids, weight-gradient splits and workspaces for (CUs - comm_cus) instead (option `cus`,
@@ -267,5 +268,23 @@ class DataParallelEngine(object):
             if self._graphs[k] is not None:
                 self._graphs[k].replay()
             self.reducer.launch(k)           # RCCL runs on its own stream, ordered after the replay
+        ev = self._exposed_events
+        if ev is not None:
+            ev[0].record()                   # the backward pass is enqueued up to here ...
         self.reducer.wait_all()              # compute stream waits for every bucket
+        if ev is not None:
+            ev[1].record()                   # ... and this one completes only once the last collective has
         self._graphs[-1].replay()            # global-norm clip + momentum SGD on the averaged gradient
+
+    def exposed_comm_ms(self, steps=5):
+        """Mean time per step the compute stream spends waiting for collectives after its last backward kernel: the part of the exchange
+        step that the backward pass did not hide (two events around the join, outside the captured graphs)."""
+        dev = self.eng.device
+        total = 0.0
+        for _ in range(steps):
+            self._exposed_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.step()
+            torch.cuda.synchronize(dev)
+            total += self._exposed_events[0].elapsed_time(self._exposed_events[1])
+        self._exposed_events = None
+        return total / max(steps, 1)
