@@ -7,6 +7,7 @@ side stream.  For N in 8, 16, 32 the captured step (cfg2) is timed
     contended       full grids, N workgroups resident beside it (what data parallelism with comm_cus = 0 risks)
     planned         option cus = CUs - N (DataParallelEngine(comm_cus=N)), N workgroups resident beside it
     planned_clean   option cus = CUs - N, nothing beside it (what the reservation costs while no collective runs)
+    *_light         the same with 16 KiB of LDS per stand-in workgroup: it can share a CU with the kernels that leave that much free
 Prints one JSON line (profiles/r02_dp_cu_contention.json)."""
 import ctypes, json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ from ursonet_amd import hip
 from ursonet_amd.engine import Engine
 
 occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "bin", "liboccupy.so"))
-occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 occ.occupy_launch.restype = ctypes.c_int
 dev = torch.device("cuda", 0)
 cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -28,7 +29,7 @@ img, loc, ori, _ = synthetic_batch(cfg, 32, seed=1)
 TICKS_PER_MS = 100000           # wall_clock64: constant 100 MHz
 
 
-def timed(eng, n_occ, reps=12):
+def timed(eng, n_occ, reps=12, lds=65536):
     """Median ms of one graph replay; with n_occ > 0 the stand-in is launched first and outlives the step."""
     for _ in range(5):
         eng.step()
@@ -37,7 +38,7 @@ def timed(eng, n_occ, reps=12):
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if n_occ:
-            rc = occ.occupy_launch(n_occ, 14 * TICKS_PER_MS, sink.data_ptr(), side.cuda_stream)
+            rc = occ.occupy_launch(n_occ, 14 * TICKS_PER_MS, lds, sink.data_ptr(), side.cuda_stream)
             assert rc == 0, rc
             torch.cuda._sleep(200000)          # let the stand-in's workgroups become resident before the step starts (~0.1 ms)
         e0.record(); eng.step(); e1.record()
@@ -53,13 +54,14 @@ def engine(usable):
     return e
 
 
-out = {"cus": cus, "occupier": "256 threads + 64 KiB LDS per workgroup, resident for the whole step", "rows": []}
+out = {"cus": cus, "occupier": "256 threads + 64 KiB LDS per workgroup (light: 16 KiB), resident for the whole step", "rows": []}
 full = engine(0)
 out["clean_ms"] = timed(full, 0)
 for n in (8, 16, 32):
-    row = {"held_cus": n, "contended_ms": timed(full, n)}
+    row = {"held_cus": n, "contended_ms": timed(full, n), "contended_light_ms": timed(full, n, lds=16384)}
     e = engine(cus - n)
     row["planned_ms"] = timed(e, n)
+    row["planned_light_ms"] = timed(e, n, lds=16384)
     row["planned_clean_ms"] = timed(e, 0)
     out["rows"].append(row)
     del e

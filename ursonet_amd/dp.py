@@ -65,7 +65,7 @@ def reserve_comm_cus(n=None):
     """Call BEFORE dist.init_process_group: bounds RCCL's resident workgroups (one per channel, NCCL_MAX_NCHANNELS; an explicit
     setting in the environment wins) to the CUs DataParallelEngine leaves free, and returns that number.  16 channels carry the
     134 MB gradient of cfg2 several times over inside one backward pass; measured on one GPU with a stand-in kernel
-    (profiles/r02_dp_cu_contention.json): 8 held CUs cost full-size grids +30 % on the step, planning for 16 fewer CUs costs 2.6 %."""
+    (profiles/r02_dp_cu_contention.json): 8 held CUs cost full-size grids +25-30 % on the step, planning for 16 fewer CUs costs 3-4 %."""
     if n is None:
         n = int(os.environ.get("URSO_DP_COMM_CUS", str(DEFAULT_COMM_CUS)))
     n = max(0, int(n))
