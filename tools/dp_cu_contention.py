@@ -17,7 +17,12 @@ from util import make_config, synthetic_batch
 from ursonet_amd import hip
 from ursonet_amd.engine import Engine
 
-occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "bin", "liboccupy.so"))
+LIB = os.path.join(ROOT, "tools", "probes", "bin", "liboccupy.so")
+if not os.path.exists(LIB):                    # tools/probes/bin/ is not tracked: build the stand-in where hipcc is at hand
+    import subprocess
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", LIB, os.path.join(ROOT, "tools", "probes", "occupy.hip")])
+occ = ctypes.CDLL(LIB)
 occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 occ.occupy_launch.restype = ctypes.c_int
 dev = torch.device("cuda", 0)
