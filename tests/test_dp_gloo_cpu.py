@@ -69,7 +69,8 @@ def _worker(rank, world, port, regress_loc, out, exact=False):
     for ln in grads:
         n = sum(grads[ln][wn].numel() for wn in grads[ln])
         sizes.append((ln, off, off + n)); off += n
-    buckets = plan_buckets(sizes, bucket_bytes=64 << 10)
+    buckets = plan_buckets(sizes, bucket_bytes=64 << 10, tail_bytes=48 << 10)     # with the capped stem-side bucket a world size > 1 gets
+    assert (buckets[-1][1] - buckets[-1][0]) * 4 <= 48 << 10 and buckets[-1][0] == 0 and len(buckets) >= 2
     red = GradReducer(flat, buckets)
     for k in range(len(buckets)):
         red.launch(k)
