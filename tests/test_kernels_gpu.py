@@ -450,12 +450,13 @@ def test_param_grad_finalize_matches_autograd_through_frozen_bn():
     assert relerr(gbe, Q["beta"].grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 16, 16), (3, 10, 20, 64), (1, 34, 70, 8)])      # the forward kernel walks 4 x 8 output tiles: whole and ragged
 @pytest.mark.parametrize("dt", [0, 1])
-def test_maxpool_same_fwd_bwd(dt):
+def test_maxpool_same_fwd_bwd(dt, shape):
     from oracle import graph_ref as G
     hip = _hip()
     torch.manual_seed(2)
-    B, H, W, Cc = 2, 12, 16, 16
+    B, H, W, Cc = shape
     x = F.relu(rnd(torch.randn(B, H, W, Cc), dt))          # post-ReLU input with many zero ties
     xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
     yr = G.maxpool_3x3_s2_same(xr)

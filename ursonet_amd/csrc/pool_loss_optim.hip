@@ -8,10 +8,17 @@ template <typename T>
 __global__ void maxpool_fwd_kernel(int B, int H, int W, int C, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ am) {
     constexpr int VE = Elem<T>::VE;
     const int OH = H / 2, OW = W / 2, Cv = C / VE;
-    const uint32_t total = (uint32_t)B * OH * OW * Cv;
+    // consecutive threads walk 4 x 8 output-pixel tiles (channel vector fastest): the windows of a tile share 9 x 17 input pixels, so
+    // the overlap between neighbouring windows -- rows too, not only columns -- is served by the CU's own cache.  Walking whole output rows,
+    // the row a window shares with the one below it was fetched by a block on another XCD, i.e. a second time from HBM.
+    const int TY = (OH + 3) >> 2, TX = (OW + 7) >> 3;
+    const uint32_t total = (uint32_t)B * TY * TX * 32u * (uint32_t)Cv;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int cv = (int)(i % (uint32_t)Cv); uint32_t p = i / (uint32_t)Cv;
-        const int ox = (int)(p % (uint32_t)OW); p /= (uint32_t)OW; const int oy = (int)(p % (uint32_t)OH); const int b = (int)(p / (uint32_t)OH);
+        const int in = (int)(p & 31u); p >>= 5;
+        const int tx = (int)(p % (uint32_t)TX); p /= (uint32_t)TX; const int ty = (int)(p % (uint32_t)TY); const int b = (int)(p / (uint32_t)TY);
+        const int ox = tx * 8 + (in & 7), oy = ty * 4 + (in >> 3);
+        if (ox >= OW || oy >= OH) continue;
         float best[VE]; int arg[VE];
 #pragma unroll
         for (int q = 0; q < VE; ++q) { best[q] = -INFINITY; arg[q] = 0; }
