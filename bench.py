@@ -175,7 +175,7 @@ def main():
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         from ursonet_amd.dp import reserve_comm_cus
-        comm_cus = reserve_comm_cus()               # RCCL channels <= the CUs the step's grids leave free (URSO_DP_COMM_CUS, default 16)
+        comm_cus = reserve_comm_cus()               # RCCL channels <= the CUs the step's grids leave free (URSO_DP_COMM_CUS; default 0 = none)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ursonet_amd.engine import Engine

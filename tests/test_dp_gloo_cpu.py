@@ -159,8 +159,9 @@ def test_reserved_comm_cus_bound_rccl_channels(monkeypatch):
     from ursonet_amd import dp
     monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
     monkeypatch.delenv("URSO_DP_COMM_CUS", raising=False)
-    assert dp.reserve_comm_cus() == dp.DEFAULT_COMM_CUS and os.environ["NCCL_MAX_NCHANNELS"] == str(dp.DEFAULT_COMM_CUS)
-    assert dp.reserve_comm_cus(24) == 24 and os.environ["NCCL_MAX_NCHANNELS"] == str(dp.DEFAULT_COMM_CUS)      # explicit setting wins
+    assert dp.reserve_comm_cus() == dp.DEFAULT_COMM_CUS == 0 and "NCCL_MAX_NCHANNELS" not in os.environ        # default: no reservation
+    assert dp.reserve_comm_cus(16) == 16 and os.environ["NCCL_MAX_NCHANNELS"] == "16"
+    assert dp.reserve_comm_cus(24) == 24 and os.environ["NCCL_MAX_NCHANNELS"] == "16"      # a setting already in the environment wins
     monkeypatch.delenv("NCCL_MAX_NCHANNELS")
-    monkeypatch.setenv("URSO_DP_COMM_CUS", "0")
-    assert dp.reserve_comm_cus() == 0 and "NCCL_MAX_NCHANNELS" not in os.environ
+    monkeypatch.setenv("URSO_DP_COMM_CUS", "8")
+    assert dp.reserve_comm_cus() == 8 and os.environ["NCCL_MAX_NCHANNELS"] == "8"

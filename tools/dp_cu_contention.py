@@ -34,7 +34,7 @@ img, loc, ori, _ = synthetic_batch(cfg, 32, seed=1)
 TICKS_PER_MS = 100000           # wall_clock64: constant 100 MHz
 
 
-def timed(eng, n_occ, reps=12, lds=65536):
+def timed(eng, n_occ, reps=12, lds=65536, hold_ms=14):
     """Median ms of one graph replay; with n_occ > 0 the stand-in is launched first and outlives the step."""
     for _ in range(5):
         eng.step()
@@ -43,7 +43,7 @@ def timed(eng, n_occ, reps=12, lds=65536):
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if n_occ:
-            rc = occ.occupy_launch(n_occ, 14 * TICKS_PER_MS, lds, sink.data_ptr(), side.cuda_stream)
+            rc = occ.occupy_launch(n_occ, int(hold_ms * TICKS_PER_MS), lds, sink.data_ptr(), side.cuda_stream)
             assert rc == 0, rc
             torch.cuda._sleep(200000)          # let the stand-in's workgroups become resident before the step starts (~0.1 ms)
         e0.record(); eng.step(); e1.record()
@@ -72,5 +72,7 @@ for n in (8, 16, 32):
     del e
     torch.cuda.empty_cache()
 hip.set_option("cus", 0)
+# stand-in resident for part of the step only (from its start): is the loss proportional to the time the CUs are held?
+out["partial_hold_full_grids"] = [{"held_cus": 16, "hold_ms": h, "step_ms": timed(full, 16, hold_ms=h)} for h in (1, 2, 4)]
 out["clean_again_ms"] = timed(full, 0)
 print(json.dumps(out))

@@ -57,15 +57,16 @@ def allreduce_rel_norms(norms, group=None):
     return norms
 
 
-DEFAULT_COMM_CUS = 16
+DEFAULT_COMM_CUS = 0           # off until an N > 1 A/B settles it: by the one-GPU model (DESIGN.md section 7 vi) reserving 16 CUs breaks even at
+                               # about 2 ms of resident collectives per step; URSO_DP_COMM_CUS / comm_cus= switch it on
 DEFAULT_TAIL_BYTES = 1 << 20
 
 
 def reserve_comm_cus(n=None):
     """Call BEFORE dist.init_process_group: bounds RCCL's resident workgroups (one per channel, NCCL_MAX_NCHANNELS; an explicit
-    setting in the environment wins) to the CUs DataParallelEngine leaves free, and returns that number.  16 channels carry the
-    134 MB gradient of cfg2 several times over inside one backward pass; measured on one GPU with a stand-in kernel
-    (profiles/r02_dp_cu_contention.json): 8 held CUs cost full-size grids +25-30 % on the step, planning for 16 fewer CUs costs 3-4 %."""
+    setting in the environment wins) to the CUs DataParallelEngine leaves free, and returns that number (0 = no reservation, RCCL's own
+    channel count).  Measured on one GPU with a stand-in kernel (profiles/r02_dp_cu_contention.json): CUs held beside full-size grids cost
+    the step +0.24 ms per ms they are held; planning for 16 fewer CUs costs 3 % of every step and still 6 % of the time they are held."""
     if n is None:
         n = int(os.environ.get("URSO_DP_COMM_CUS", str(DEFAULT_COMM_CUS)))
     n = max(0, int(n))
@@ -148,8 +149,8 @@ class DataParallelEngine(object):
         # "all CUs"; a CU held by an RCCL workgroup makes the blocks that wanted it wait for a whole stream to finish -- a second wave.
         # With comm_cus > 0 the library plans grids, weight-gradient splits and workspaces for (CUs - comm_cus) instead (option `cus`,
         # include/ursonet_hip.h), process-wide: one process drives one GPU.  tools/dp_cu_contention.py measures both sides of the
-        # trade on one GPU (profiles/r02_dp_cu_contention.json).  Default: URSO_DP_COMM_CUS, else 16 (reserve_comm_cus above keeps
-        # RCCL inside that many); 0 = full grids.  Only applied when collectives actually run (world > 1).
+        # trade on one GPU (profiles/r02_dp_cu_contention.json).  Default: URSO_DP_COMM_CUS, else DEFAULT_COMM_CUS = 0 = full grids
+        # (reserve_comm_cus above keeps RCCL inside a non-zero reservation).  Only applied when collectives actually run (world > 1).
         explicit = comm_cus is not None              # a forced-collective run with one rank reserves only when asked to
         if comm_cus is None:
             comm_cus = int(os.environ.get("URSO_DP_COMM_CUS", str(DEFAULT_COMM_CUS)))
