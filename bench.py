@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--pcie-steps", type=int, default=20, help="steps of the host-buffer-inclusive leg (0 = skip)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-policy option for A/B runs (urso_set_option; repeatable); recorded in config.options")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,6 +183,9 @@ def main():
     from ursonet_amd.engine import Engine
     from ursonet_amd import hip
     from util import synthetic_batch
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        hip.set_option(k, int(v))
 
     cfg = bench_config(args.dtype, args.batch, args.height, args.width, args.backbone, args.ori_bins)
     cfg.DP_EXACT_REL_LOSS = os.environ.get("URSO_DP_EXACT_REL_LOSS", "0") == "1"      # default: per-rank loss
@@ -273,7 +278,7 @@ def main():
                                "full training step (prep+fwd+loss+bwd+clip+SGD%s)" % (args.backbone, args.ori_bins, args.batch, args.height,
                                                                                      args.width, "+RCCL all-reduce" if world > 1 else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "comm_cus": comm_cus, "hipgraph": True,
-                   "step_tflop": round(step_flops / 1e12, 3), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
+                   "step_tflop": round(step_flops / 1e12, 3), "options": dict(kv.split("=", 1) for kv in args.opt), "loc_loss": losses["loc_loss"], "ori_loss": losses["ori_loss"]},
         "roofline": roofline, "kernels": kernels, "pcie_inclusive": pcie, "dp": dp_info,
     }
     if not args.no_cpu_baseline and world == 1:

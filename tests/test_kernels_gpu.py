@@ -1169,3 +1169,72 @@ def test_weight_gradient_with_dz_on_a_coarser_grid(dt, shape):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert relerr(b[0], c[0]) < 2e-5 and relerr(b[1], c[1]) < 2e-5
     assert float(b[0].abs().max()) > 0
+
+
+PWX_FORMS = ["relu", "add_relu_bits", "mask_tensor", "add_maskbits", "maskbits", "add_relu"]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("form", PWX_FORMS)
+@pytest.mark.parametrize("shape", [(2, 16, 20, 1024, 256, 0), (3, 17, 21, 512, 320, 0), (4, 32, 40, 256, 512, 8), (2, 9, 13, 128, 72, 0),
+                                   (32, 16, 20, 2048, 512, 0), (32, 32, 40, 1024, 256, 0), (32, 16, 20, 512, 2048, 0)],
+                         ids=["one_round", "ragged_MN", "capped_multi_tile", "tiny_tails", "stage5_2a", "stage4_2a", "stage5_2c"])
+def test_big_tile_pointwise_kernel_forced(dt, form, shape):
+    """conv_pwx.hip (option pwx = 2: every supported pointwise layer; pwx_bn forces its 256- and 128-filter tiles) through urso_conv_igemm_ex
+    for each instantiated epilogue form: against the CPU fp32 reference, and BIT FOR BIT against the DMA kernel of conv_pw.hip (same MFMA,
+    same k order, same fp32 epilogue) -- output, emitted ReLU bit mask, masked data-gradient forms.  Shapes: whole tiles, ragged M and N
+    tails (zero-filled rows, dropped stores), a grid capped to 8 blocks (the copy stream continues across tile seams and epilogues; counted
+    vmcnt of the first mid-step after an epilogue), K = 128 (two K-steps per tile: the stream runs more than a tile ahead), and the three
+    cfg2 geometries of VERDICT r02 item 1 at full size."""
+    hip = _hip()
+    B, H, W, K, N, cap = shape
+    if B * H * W * max(K, N) > 20e6 and (dt == 2 or form not in ("relu", "add_relu_bits", "mask_tensor", "add_maskbits")):
+        pytest.skip("full-size geometries: bf16 and the four forms the cfg2 plan uses")
+    M = B * H * W
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(K + N + dt)
+    x = dev(torch.randn(B, H, W, K), dt)
+    w = torch.randn(1, 1, K, N) / K ** 0.5
+    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(N) * 0.2)
+    has_add = form.startswith("add")
+    relu = "relu" in form
+    emit = form.endswith("_bits")
+    mbits = "maskbits" in form
+    mtens = form == "mask_tensor"
+    if mbits or mtens:
+        biasf = None                                          # data-gradient forms carry no bias
+    add = dev(torch.randn(B, H, W, N), dt) if has_add else None
+    if N % 32 and (emit or mbits):
+        pytest.skip("bit masks need N % 32 == 0")
+    mask = None
+    if mbits:
+        mask = torch.randint(0, 256, (M * N // 8,), dtype=torch.uint8, device="cuda")
+    if mtens:
+        mask = dev(torch.randn(B, H, W, N), dt)
+    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_EMIT_BITS if emit else 0) | (hip.EPI_MASK_BITS if mbits else 0)
+    g = hip.geom(B, H, W, K, H, W, N, 1, 1)
+    ref = x.float().cpu().reshape(M, K) @ wf.float().cpu().reshape(N, K).T
+    if biasf is not None:
+        ref = ref + biasf.cpu()
+    if add is not None:
+        ref = ref + add.float().cpu().reshape(M, N)
+    if relu:
+        ref = torch.relu(ref)
+    if mbits:
+        keep = ((mask.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, N).float()
+        ref = ref * keep
+    if mtens:
+        ref = ref * (mask.float().cpu().reshape(M, N) > 0).float()
+    outs, obits = {}, {}
+    for pwx, bn in ((2, 256), (2, 128), (0, 0)):
+        y = torch.full((B, H, W, N), 5.0, device="cuda").to(tdt)
+        bits = torch.full((M * N // 8,), 0x55, dtype=torch.uint8, device="cuda") if emit else None
+        with hip.options(pwx=pwx, pwx_bn=bn, pair=0, grid_cap=cap):
+            hip.conv_igemm_ex(g, dt, flags, x, wf, biasf, add, mask, y, bits)
+        torch.cuda.synchronize()
+        assert relerr(y.reshape(M, N), ref) < (1.2e-2 if dt == 1 else 1.5e-3), (pwx, bn)
+        outs[(pwx, bn)], obits[(pwx, bn)] = y, bits
+    for key in ((2, 256), (2, 128)):
+        assert torch.equal(outs[key], outs[(0, 0)]), key
+        if emit:
+            assert torch.equal(obits[key], obits[(0, 0)]), key

@@ -354,11 +354,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
 }
 
 static int pw_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
+int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                 const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
+                 hipStream_t st);                              // conv_pwx.hip
 
 // Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
                    uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st) {
+    if (conv == 0) {                     // the reduction-heavy pointwise layers: 8-wave big-tile kernel (conv_pwx.hip)
+        const int rc = urso_pwx_try(g, dt, relu, src, wgt, bias, add, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, bits_out, st);
+        if (rc != 0) return rc > 0 ? URSO_OK : rc;
+    }
     PwArgs a;
     a.bits_out = bits_out;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;

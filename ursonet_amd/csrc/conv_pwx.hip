@@ -1,0 +1,346 @@
+// Big-tile pointwise GEMM for the MFMA-bound 1x1 layers of ResNet stages 4-5 (net.py:101,111,138,148,152: res{4,5}x_branch2a forward,
+// the data gradient of res{4,5}x_branch2c, the stride-2 entry layers on their sampled input), 16-bit dtypes, gfx950.
+//
+// Why a third pointwise kernel.  conv_pw.hip runs these layers on 128 x {128,64} tiles with 2-3 blocks per CU and ONE K-tile of copies
+// in flight per block: (i) their tile counts do not divide the chip (stage 4: 640 tiles on 512 slots, stage 5: 320), (ii) a 64x64 wave
+// tile loads the LDS read port as much as the matrix pipe, (iii) every K-tile ends in vmcnt(0) + barrier.  Measured 33-47 us per layer
+// against 9-19 us of roofline (profiles/r02_layer_profile.txt).  Here:
+//   * tile = 160 pixels x {256,128} filters: M = 40,960 / 10,240 (cfg2 stages 4 / 5) are 256 / 64 tiles of 160 rows, so every layer is a
+//     whole number of rounds over 256 CUs; 8 waves (2 x 4), wave tile 80 x 64 (5 x 4 MFMA 16x16x32 sub-tiles): 9 fragment reads per
+//     20 MFMAs instead of 8 per 16;
+//   * ONE block per CU with the whole LDS: a ring of NST stages of (BM + BN) x 128 B, copies (buffer_load ... lds, issued from inline
+//     asm, hand-counted vmcnt as in conv_pw.hip) run NST - 1 K-steps ahead of the MFMAs and CONTINUE across tile seams and epilogues:
+//     100-110 KiB in flight per CU;
+//   * one barrier per K-step, placed mid-step: the step's second-half fragments are read while the first half multiplies, the next
+//     step's first-half fragments while the second half multiplies (two named fragment sets); at the barrier this wave's copies of step
+//     s + 1 are checked (counted vmcnt, never 0 in steady state), the copies of step s + NST are issued into the buffer just released;
+//   * bias comes through the same DMA queue into a 4-slot LDS table (no compiler-visible load lives across the K loop, so hipcc places
+//     no vmcnt of its own inside it); residual / mask vectors of the next tile are requested while the epilogue retires the registers
+//     of this one ("rolling prefetch", conv_pw.hip).
+// Same math, weight layout (filter rows permuted on the DMA source side so that a lane owns whole 16-byte output vectors) and epilogue
+// semantics (bias, residual, ReLU, mask tensor / ReLU bit mask, emitted bit mask, scatter destination) as conv_pw.hip; results are
+// bit-identical to it (same MFMA, same k order inside a 64-wide K-tile, same fp32 epilogue).
+#include "common.h"
+
+struct PxArgs {
+    const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst; void* bits_out;
+    uint32_t src_bytes, wgt_bytes, dst_bytes;
+    int M, C, N, Kc, nkt, tilesN, ntiles;
+    int OH, OW, FH, FW, OSH, OSW;      // destination scatter (FH == 0: dense)
+    float rcp_ohw, rcp_ow;
+    int relu;
+    int dbg;                           // urso_set_option("pwx_dbg"): 1 no copies after the prologue, 2 no MFMAs, 4 no epilogue (timing experiments)
+};
+
+__device__ __forceinline__ void px_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    // m0 = wave-uniform LDS destination; lane l lands at m0 + 16 l (conv_pw.hip pw_dma16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t px_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void px_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// MASKK: 0 none, 1 mask tensor like dst (keep where > 0), 2 ReLU BIT mask (1 byte per 16-byte vector of dst); EMIT: write such a bit mask
+template <typename T, int TMW, int BN, int NST, bool HAS_ADD, int MASKK, bool EMIT>
+__global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr bool HAS_MASK = MASKK == 1;
+    constexpr int VE = 8;
+    constexpr int WM = 16 * TMW, BM = 2 * WM, WN = BN / 4, TM = TMW, TN = WN / 16;
+    constexpr int GA = BM / 8, RA = (GA + 7) / 8, RB = BN / 64, NDMA = RA + RB;      // 8-row groups of the pixel tile; DMA instructions per wave and K-step
+    static_assert(GA % 8 == 0 || GA % 8 == 4, "pixel-tile row groups: whole or half rounds of the 8 waves");
+    constexpr int STAGE = (BM + BN) * 128, BIAS_OFF = NST * STAGE, LDS = BIAS_OFF + 4 * 1024;
+    static_assert(LDS <= 163840, "LDS budget");
+    constexpr int CH = TN * 4, JPV = VE / 4, NV = CH / VE;                           // channels / sub-tiles per vector / vectors per lane and pixel row
+    constexpr int NEPI = TM * NV * (1 + (HAS_ADD ? 1 : 0) + (MASKK ? 1 : 0) + (EMIT ? 1 : 0));      // vm operations of one epilogue
+    static_assert((NST - 2) * NDMA + NEPI <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    const int tile0 = xcd * cpx + lb;
+    if (tile0 >= t_end) return;
+
+    const i32x4_t rs = px_rsrc(a.src, a.src_bytes), rw = px_rsrc(a.wgt, a.wgt_bytes);
+    const i32x4_t rbi = px_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? (MASKK == 2 ? a.dst_bytes / 16u : a.dst_bytes) : 0u);
+    const __amdgpu_buffer_rsrc_t rmo = make_rsrc(EMIT ? a.bits_out : a.dst, EMIT ? a.dst_bytes / 16u : 0u);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
+
+    // ---- DMA roles: instruction q of a wave covers the 8-row group wave + 8 q (lane: row lane >> 3, physical 16-byte slot lane & 7);
+    //      a half round (BM = 160: groups 16-19) is issued twice, by waves w and w + 4, with identical sources and destinations
+    const int c8 = lane & 7, r8 = lane >> 3;
+    uint32_t asrc[RA], bsrc[RB];
+    int ga[RA];
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+        int g = wave + 8 * q;
+        if (g >= GA) g -= 4;
+        ga[q] = g;
+        const int R = 8 * g + r8;
+        asrc[q] = (uint32_t)R * (uint32_t)a.C * 2u + (uint32_t)((c8 ^ lds_swz(R)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int R = 8 * (wave + 8 * q) + r8;          // LDS row of the filter tile -> which filter it holds (conv_pw.hip nrow)
+        const int w = R / WN, rr = R % WN, j = rr >> 4, qq = (rr & 15) >> 2, t = rr & 3;
+        const int nrow = w * WN + (j / JPV) * 4 * VE + qq * VE + (j % JPV) * 4 + t;
+        bsrc[q] = (uint32_t)nrow * (uint32_t)a.Kc * 16u + (uint32_t)((c8 ^ lds_swz(R)) << 4);
+    }
+    // DMA pointer: the next K-step to copy (tile dtile, K-tile dkt, dcnt = tiles completed by the pointer)
+    int dtile = tile0, dkt = 0, dcnt = 0;
+    uint32_t d_a = 0, d_b = 0;
+    auto dma_tile_base = [&]() {
+        const bool ok = dtile < t_end;
+        const int m0 = (dtile / a.tilesN) * BM, n0 = (dtile % a.tilesN) * BN;
+        d_a = ok ? (uint32_t)m0 * (uint32_t)a.C * 2u : URSO_OOB_SHIFT;           // OOB_SHIFT + anything below 2 GiB stays out of range: zeros, no traffic
+        d_b = ok ? (uint32_t)n0 * (uint32_t)a.Kc * 16u : URSO_OOB_SHIFT;
+    };
+    dma_tile_base();
+    auto dma_issue = [&](int stg) {
+        const uint32_t la = lds0 + (uint32_t)stg * STAGE;
+        if (dkt == 0 && wave == 0) {                      // the tile's bias (BN floats) -> table slot dcnt & 3
+            const int n0 = (dtile % a.tilesN) * BN;
+            px_dma16(rbi, lds0 + BIAS_OFF + (uint32_t)(dcnt & 3) * 1024u, (dtile < t_end && lane * 4 < BN) ? (uint32_t)(n0 + lane * 4) * 4u : URSO_OOB_SHIFT);
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) px_dma16(rw, la + BM * 128 + (uint32_t)(wave + 8 * q) * 1024u, d_b + bsrc[q]);
+#pragma unroll
+        for (int q = 0; q < RA; ++q) px_dma16(rs, la + (uint32_t)ga[q] * 1024u, d_a + asrc[q]);
+        d_a += 128u; d_b += 128u;                         // an OOB base stays out of range: nkt * 128 < 2 GiB
+        if (++dkt == a.nkt) { dkt = 0; dtile += bpx; ++dcnt; dma_tile_base(); }
+    };
+
+    // ---- fragment read offsets inside a stage (k half 0; half 1 = ^ 64)
+    uint32_t offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = (uint32_t)lds_off(wm * WM + i * 16 + fr, fg);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = (uint32_t)(BM * 128 + lds_off(wn * WN + j * 16 + fr, fg));
+
+    // ---- epilogue geometry of a tile (conv_pw.hip): byte offset of the lane's first vector of pixel sub-tile i, OOB when outside
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    auto tile_offs = [&](int ts, bool exists, uint32_t (&eo)[TM]) {
+        const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
+        const int nb = n0 + wn * WN + fg * VE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + fr;
+            int dp = m;
+            if (a.FH != 0 && m < a.M) { int b, rem, oy, ox; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
+                                        dp = (b * a.FH + oy * a.OSH) * a.FW + ox * a.OSW; }
+            eo[i] = (exists && m < a.M && nb < a.N) ? (uint32_t)(((size_t)dp * a.N + nb) * 2) : URSO_OOB_SHIFT;
+        }
+    };
+    auto voff = [&](uint32_t base, int ts, int v) -> uint32_t {       // vector v of the lane: 4 VE channels further
+        const int nb = (ts % a.tilesN) * BN + wn * WN + fg * VE + v * 4 * VE;
+        return (nb < a.N) ? base + (uint32_t)(v * 4 * VE * 2) : URSO_OOB_SHIFT;
+    };
+
+    i32x4_t radd[HAS_ADD ? TM * NV : 1], rmsk[HAS_MASK ? TM * NV : 1];
+    uint32_t rbit[MASKK == 2 ? TM * NV : 1];
+    uint32_t eo_cur[TM], eo_nxt[TM];
+    int tile = tile0;
+    tile_offs(tile, true, eo_cur);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const uint32_t o = voff(eo_cur[i], tile, v);
+            if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+            if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+            if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
+        }
+    // ---- block prologue: the first NST K-steps of the stream
+#pragma unroll
+    for (int p = 0; p < NST; ++p) dma_issue(p);
+    px_wait_vm<(NST - 1) * NDMA>();
+    __builtin_amdgcn_s_barrier();
+
+    i32x4_t fa0[TN], fb0[TM], fa1[TN], fb1[TM];         // fragment sets of the two 32-deep halves of a K-step (a = filters, b = pixels)
+    auto rd = [&](i32x4_t (&fa)[TN], i32x4_t (&fb)[TM], const char* sb, uint32_t kx) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fa[j] = *(const i32x4_t*)(sb + (offB[j] ^ kx));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fb[i] = *(const i32x4_t*)(sb + (offA[i] ^ kx));
+    };
+    int stage = 0, tcnt = 0;
+    rd(fa0, fb0, smem, 0u);
+
+    while (true) {
+        const int next = tile + bpx;
+        const bool has_next = next < t_end;
+        f32x4_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            const char* sb = smem + stage * STAGE;
+            // the read offsets are functions of the lane only: keep the compiler from hoisting NST x 2 copies of them out of the loop
+            asm volatile("" : "+v"(offA[0]), "+v"(offB[0]));
+            // ---- first half: multiply set 0, read set 1 (this step, k half 1)
+            rd(fa1, fb1, sb, 64u);
+            if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa0[j], fb0[i], acc[i][j]);
+            }
+#pragma unroll
+            for (int q = 0; q < TM + TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- mid-step: this wave's copies of step s + 1 have landed (the younger ones stay in flight) -> barrier -> every wave's
+            //      have, and every wave has finished reading this step's buffer: the copies of step s + NST go there
+            if (kt == 0 && tcnt > 0) px_wait_vm<(NST - 2) * NDMA + NEPI>(); else px_wait_vm<(NST - 2) * NDMA>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(a.dbg & 1)) dma_issue(stage);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- second half: multiply set 1, read set 0 of the next step (the next tile's first step across a seam; stale bytes at the
+            //      very end of the stream, never used)
+            stage = (stage + 1 == NST) ? 0 : stage + 1;
+            rd(fa0, fb0, smem + stage * STAGE, 0u);
+            if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa1[j], fb1[i], acc[i][j]);
+            }
+#pragma unroll
+            for (int q = 0; q < TM + TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: + bias (LDS table) + residual -> ReLU -> mask -> 16-bit, 16-byte vectors straight from the accumulators
+        if (a.dbg & 4) { if (!has_next) break; tile = next; ++tcnt; continue; }
+        tile_offs(next, has_next, eo_nxt);
+        float bv[CH];
+        {
+            const char* bt = smem + BIAS_OFF + (tcnt & 3) * 1024 + (wn * WN + fg * VE) * 4;
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) {
+                const f32x4_t b = *(const f32x4_t*)(bt + ((q / JPV) * 4 * VE + (q % JPV) * 4) * 4);
+                bv[q * 4] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                T ea[VE], em[VE], eo[VE];
+                if constexpr (HAS_ADD) __builtin_memcpy(ea, &radd[i * NV + v], 16);
+                if constexpr (HAS_MASK) __builtin_memcpy(em, &rmsk[i * NV + v], 16);
+                uint32_t mbits = 0;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int c = v * VE + e;
+                    float y = acc[i][c >> 2][c & 3] + bv[c];
+                    if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
+                    y = a.relu ? fmaxf(y, 0.f) : y;
+                    if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
+                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> e) & 1u) ? y : 0.f;
+                    eo[e] = Elem<T>::from_f(y);
+                    if constexpr (EMIT) mbits |= (Elem<T>::to_f(eo[e]) > 0.f) ? (1u << e) : 0u;       // of the STORED value
+                }
+                i32x4_t ov; __builtin_memcpy(&ov, eo, 16);
+                const uint32_t so = voff(eo_cur[i], tile, v);
+                buf_store16(rds, so, ov);
+                if constexpr (EMIT) {
+                    // the four lanes of a pixel (fg = 0..3) hold four consecutive mask bytes: one dword store by lane fg = 0 (conv_pw.hip)
+                    const uint32_t x = (uint32_t)__shfl_xor((int)mbits, 16, 64);
+                    const uint32_t pr = (fg & 1) ? (x | (mbits << 8)) : (mbits | (x << 8));
+                    const uint32_t y2 = (uint32_t)__shfl_xor((int)pr, 32, 64);
+                    const uint32_t dw = (fg & 2) ? (y2 | (pr << 16)) : (pr | (y2 << 16));
+                    __builtin_amdgcn_raw_buffer_store_b32(dw, rmo, (fg == 0) ? (so >> 4) : URSO_OOB_SHIFT, 0, 0);
+                }
+                {   // this slot's registers are free: request the next tile's vector (out of range = zeros, no traffic, when there is none:
+                    // the operation count of an epilogue stays fixed for the counted wait of the next mid-step)
+                    const uint32_t o = voff(eo_nxt[i], next, v);
+                    if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+                    if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
+                    if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = next; ++tcnt;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) eo_cur[i] = eo_nxt[i];
+    }
+    px_wait_vm<0>();                                     // the (out-of-range) copies past the end of the stream must not outlive the block's LDS
+}
+
+// ---------------------------------------------------------------- host side
+// Returns 1 after launching, 0 when the layer does not take this kernel (conv_pw.hip then serves it), < 0 on a launch error.
+// Policy (option `pwx`: 0 off, 1 default, 2 every supported layer): pointwise 16-bit layers with whole 64-channel K-tiles whose
+// epilogue form is instantiated below, K >= 256 and enough work per CU that the matrix pipe, not the stream, is the bound.
+int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                 const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
+                 hipStream_t st) {
+    const int mode = g_urso_opt.pwx;
+    if (!mode) return 0;
+    const int maskk = mask ? (mask_bits ? 2 : 1) : 0;
+    const bool emit = bits_out != nullptr;
+    // instantiated epilogue forms: (add, maskk, emit)
+    const int form = (!add && !maskk && !emit) ? 0 : (add && !maskk && emit) ? 1 : (!add && maskk == 1 && !emit) ? 2 :
+                     (add && maskk == 2 && !emit) ? 3 : (!add && maskk == 2 && !emit) ? 4 : (add && !maskk && !emit) ? 5 : -1;
+    if (form < 0 || (g->C % 64) || (g->N % 8)) return 0;
+    const long long M = (long long)g->B * g->OH * g->OW;
+    const int K = g->C, N = g->N;
+    if (mode == 1) {
+        // the HBM-bound c -> 4c layers stay where they are (register-filter kernel / conv_pw.hip); this kernel takes the reduction-heavy
+        // ones: K >= 512 with at least 128 filters, on pixel counts where a 160-row tile grid fills the chip
+        if (K < 512 || N < 128 || M < 160 * 64) return 0;
+    }
+    PxArgs a;
+    a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst; a.bits_out = bits_out;
+    a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
+    a.M = (int)M; a.C = g->C; a.N = N; a.Kc = g->C / 8; a.nkt = a.Kc / 8;
+    a.OH = g->OH; a.OW = g->OW; a.FH = g->FH > 0 ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
+    a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu; a.dbg = g_urso_opt.pwx_dbg;
+    const int cus = urso_usable_cus();
+    // tile width: the one with the fewer rounds over the chip (cost = rounds x tile area), wide on a tie
+    const int tm = ceil_div((int)M, 160);
+    auto cost = [&](int bn) { const long long nt = (long long)tm * ceil_div(N, bn); return ((nt + cus - 1) / cus) * (long long)bn; };
+    int bn = (N > 128 && cost(256) <= cost(128)) ? 256 : 128;
+    if (g_urso_opt.pwx_bn == 128 || g_urso_opt.pwx_bn == 256) bn = g_urso_opt.pwx_bn;
+    a.tilesN = ceil_div(N, bn); a.ntiles = tm * a.tilesN;
+    int bpx = ceil_div(a.ntiles, 8);
+    if (bpx > cus / 8) bpx = cus / 8;
+    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
+    const dim3 grid(8 * bpx), blk(512);
+#define URSO_PX(TT, BN_, NST_, AD_, MK_, EM_) hipLaunchKernelGGL((pwx_kernel<TT, 5, BN_, NST_, AD_, MK_, EM_>), grid, blk, 0, st, a)
+#define URSO_PXF(TT, BN_, NST_) switch (form) { case 0: URSO_PX(TT, BN_, NST_, false, 0, false); break; case 1: URSO_PX(TT, BN_, NST_, true, 0, true); break; \
+                                                case 2: URSO_PX(TT, BN_, NST_, false, 1, false); break; case 3: URSO_PX(TT, BN_, NST_, true, 2, false); break; \
+                                                case 4: URSO_PX(TT, BN_, NST_, false, 2, false); break; default: URSO_PX(TT, BN_, NST_, true, 0, false); }
+    if (dt == URSO_BF16) { if (bn == 256) { URSO_PXF(__bf16, 256, 3) } else { URSO_PXF(__bf16, 128, 4) } }
+    else { if (bn == 256) { URSO_PXF(_Float16, 256, 3) } else { URSO_PXF(_Float16, 128, 4) } }
+#undef URSO_PXF
+#undef URSO_PX
+    const int rc = urso_check_launch("urso_conv_igemm(pwx)");
+    return rc == URSO_OK ? 1 : rc;
+}
