@@ -210,14 +210,14 @@ class DataParallelEngine(object):
     def _segments(self):
         eng = self.eng
         segs, prev = [], 0
-        main = lambda ops: [(op, False) for op in ops]
         for k, c in enumerate(self.cuts):
-            ops = eng.bwd_entries(prev, c)             # [(op, on the engine's side stream)]: joined at the end of every segment
+            ops = [op for _, op in eng.bwd_ops[prev:c]]
             if k == 0:
-                ops = main(([] if self.rel_exact else eng.prep_ops + eng.fwd_ops + eng.loss_pre_ops) + eng.loss_ops) + ops
+                ops = ([] if self.rel_exact else eng.prep_ops + eng.fwd_ops + eng.loss_pre_ops) + eng.loss_ops + ops
             segs.append(ops)
             prev = c
-        return segs, eng.bwd_entries(prev, None) + main(eng.opt_ops)
+        tail = [op for _, op in eng.bwd_ops[prev:]]
+        return segs, tail + eng.opt_ops
 
     def capture(self):
         eng = self.eng
@@ -251,7 +251,8 @@ class DataParallelEngine(object):
                 continue
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, pool=pool):
-                eng.run_entries(ops)
+                for op in ops:
+                    op()
             pool = gr.pool()
             graphs.append(gr)
         self._graphs = graphs

@@ -93,12 +93,6 @@ class Engine(object):
         self.layer_trainable = {n: True for n in self.graph.params}
         self.world_size = 1
         self._graphs = None
-        # Weight gradients (and their reduction / finalisation) depend on the data-gradient chain but nothing in the backward pass depends
-        # on them: they run on a SECOND stream, forked behind the launch that completed their operands and joined before the optimizer,
-        # so that the tail of one kernel (its last tiles, its store burst) overlaps the head of an independent one.  Captured into the same
-        # hipGraph as parallel branches.  URSO_BWD_SIDE_STREAM=0 restores the single chain (profile_step always runs the single chain).
-        self.side_stream_on = int(os.environ.get("URSO_BWD_SIDE_STREAM", "1"))      # 1 everything in SIDE_LABELS, 2 only the reduction / finalisation tail
-        self._side = None
         self._alloc_params(seed, randomize_bn)
         self._build_plan()
 
@@ -883,53 +877,19 @@ class Engine(object):
         for op in self.fwd_ops:
             op()
 
-    SIDE_LABELS = ("wgrad:", "unpack:", "finalize:", "reduce:", "finalize_mat:", "finalize_vec:")
-
-    def bwd_entries(self, lo=0, hi=None):
-        """[(op, runs_on_side_stream)] of the backward launches lo..hi: pure weight-gradient work (partials, split reduction, gradient
-        finalisation) may leave the data-gradient chain; everything else (incl. the fused data + weight gradient launches) stays on it."""
-        ops, labs = self.bwd_ops[lo:hi], self.labels["bwd"][lo:hi]
-        pre = self.SIDE_LABELS if self.side_stream_on != 2 else self.SIDE_LABELS[1:]
-        return [(op, bool(lab) and lab.startswith(pre)) for (_, op), lab in zip(ops, labs)]
-
-    def run_entries(self, entries, side=None):
-        """Launch [(op, on_side)] in order; a side op waits for everything launched before it on the main stream (its operands: the
-        gradient tensors written by earlier data-gradient launches), later main ops do not wait for it; joined at the end."""
-        side = self.side_stream_on if side is None else side
-        if not side or not any(f for _, f in entries):
-            for op, _ in entries:
-                op()
-            return
-        main = torch.cuda.current_stream(self.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        sd, fresh, forked = self._side, True, False       # fresh: the main stream has launched something the side stream has not waited for
-        for op, on_side in entries:
-            if on_side:
-                if fresh:
-                    sd.wait_stream(main)
-                    fresh = False
-                with torch.cuda.stream(sd):
-                    op()
-                forked = True
-            else:
-                op()
-                fresh = True
-        if forked:
-            main.wait_stream(sd)
-
-    def run_backward(self, side=None):
+    def run_backward(self):
         for op in self.loss_pre_ops + self.loss_ops:
             op()
-        self.run_entries(self.bwd_entries(), side)
+        for _, op in self.bwd_ops:
+            op()
 
     def run_optimizer(self):
         for op in self.opt_ops:
             op()
 
-    def step_eager(self, side=None):
+    def step_eager(self):
         """One training step, launched kernel by kernel (used for capture, profiling and debugging)."""
-        self.run_prep(); self.run_forward(); self.run_backward(side); self.run_optimizer()
+        self.run_prep(); self.run_forward(); self.run_backward(); self.run_optimizer()
 
     def profile_step(self):
         """One eager training step with the library's HIP-event launch profiler on.
@@ -940,7 +900,7 @@ class Engine(object):
         hip.prof_collect()
         hip.prof_enable(True)
         try:
-            self.step_eager(side=False)                # one chain: a launch's events bracket that launch alone
+            self.step_eager()
             torch.cuda.synchronize(self.device)
             recs = hip.prof_collect()
         finally:
