@@ -389,9 +389,28 @@ def forward(P, images_nhwc, config, relu_hook=None, q=None):
 # --------------------------------------------------------------------------
 # losses (net.py:705-762) and compile() (net.py:973-1028)
 # --------------------------------------------------------------------------
+class _SoftmaxXentTF(torch.autograd.Function):
+    """tf.nn.softmax_cross_entropy_with_logits as TF's kernel defines it (net.py:710 reaches it through tf.losses.softmax_cross_entropy):
+    per-row loss = sum_k p_k (logsumexp(z) - z_k), and the gradient w.r.t. the logits is the kernel's `backprop` output
+    softmax(z) - p -- NOT the derivative of the loss expression (softmax(z) * sum_k p_k - p) unless the labels sum to one.  encode_ori's
+    soft labels are normalised (utils.py:333-380), so both forms agree on the reference's own data; the restatement follows the kernel
+    so that un-normalised labels (sum != 1) are covered too."""
+
+    @staticmethod
+    def forward(ctx, z, p):
+        lse = torch.logsumexp(z, dim=-1, keepdim=True)
+        ctx.save_for_backward(torch.softmax(z, dim=-1) - p)
+        return (p * (lse - z)).sum(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (bp,) = ctx.saved_tensors
+        return g.unsqueeze(-1) * bp, None
+
+
 def softmax_loss(y_gt, y_pred):
-    """net.py:710 + [A6]: sum_b(-sum_k p log_softmax(z)) / B."""
-    return -(y_gt * F.log_softmax(y_pred, dim=-1)).sum(-1).mean()
+    """net.py:710 + [A6]: sum_b(-sum_k p log_softmax(z)) / B, gradient softmax - p per row (TF kernel semantics, see above)."""
+    return _SoftmaxXentTF.apply(y_pred, y_gt).mean()
 
 
 def one_minus_dot_prod(y_true, y_pred):

@@ -475,14 +475,17 @@ def test_maxpool_same_fwd_bwd(dt, shape):
     assert relerr(dx, ref) < (1e-6 if dt == 0 else 1e-2)
 
 
+@pytest.mark.parametrize("label_sum", [1.0, 0.6, 1.7], ids=["normalised", "sum_below_1", "sum_above_1"])
 @pytest.mark.parametrize("K", [4096, 13824, 64])
-def test_softmax_xent_soft_labels(K):
+def test_softmax_xent_soft_labels(K, label_sum):
+    """Loss and gradient against the oracle; label rows that do NOT sum to one pin the TF-kernel semantics on both sides: the
+    gradient is softmax - p (not softmax * sum(p) - p), the loss logsumexp * sum(p) - sum(p z)."""
     from oracle import graph_ref as G
     hip = _hip()
     torch.manual_seed(K)
     B = 6
     z = F.relu(torch.randn(B, K) * 2).requires_grad_(True)          # logits are post-ReLU (net.py:350)
-    p = torch.softmax(torch.randn(B, K) * 3, -1)
+    p = torch.softmax(torch.randn(B, K) * 3, -1) * label_sum
     loss = G.softmax_loss(p, z) * 0.7
     loss.backward()
     lo = torch.empty(1, device="cuda"); dz = torch.empty(B, K, device="cuda"); rw = torch.empty(B, device="cuda")

@@ -88,6 +88,11 @@ CASES = [
     ("r34_euler", dict(backbone="resnet34", h=64, w=128, batch=3, regress_ori=True, ori_param="euler_angles")),
     ("r50_classify_loc", dict(backbone="resnet50", h=64, w=128, batch=2, regress_ori=False, regress_loc=False, ori_bins=4, loc_bins=4)),
     ("r101_softclass", dict(backbone="resnet101", h=64, w=128, batch=2, regress_ori=False, ori_bins=8)),      # cfg4's trunk, one TRAINING step
+    ("r50_no_dense_layer", dict(backbone="resnet50", h=64, w=128, batch=2, regress_ori=False, ori_bins=4, nr_dense=0)),     # NR_DENSE_LAYERS = 0 (net.py:295): the heads' final Dense reads the flattened bottleneck
+    ("r18_two_dense_layers", dict(backbone="resnet18", h=128, w=128, batch=2, regress_ori=True, nr_dense=2)),              # NR_DENSE_LAYERS = 2: two Dense + ReLU per branch
+    # one step at the real cfg2 WIDTH (512 x 640, ori_resolution 16): the row / tile geometry of every cfg2 layer (160-row tiles of the
+    # big-tile pointwise kernel, 641-wide virtual rows of the halo kernel, ...) sits inside an oracle comparison, not only a property check
+    ("cfg2_width_r50_n16", dict(backbone="resnet50", h=512, w=640, batch=2, regress_ori=False, ori_bins=16)),
 ]
 
 
@@ -193,6 +198,25 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
     _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3)
+
+
+@pytest.mark.parametrize("pwx", [1, 2], ids=["policy", "pwx_everywhere"])
+def test_training_step_parity_bf16_at_cfg2_width(pwx):
+    """The benchmarked dtype at the real cfg2 image size (2 x 512 x 640, ori_resolution 16) against the rounding-aware oracle: the
+    per-layer geometry of the benchmark (every kernel the cfg2 plan selects, its tile walk over 640-pixel rows) inside an oracle-compared
+    step; batch 2 instead of 32 only shortens the tile streams.  pwx = 2 additionally sends every pointwise layer the big-tile kernel
+    (conv_pwx.hip) supports through it (fused pairs off so that the stage-2/3 layers reach it too)."""
+    import ursonet_amd.hip as hip
+    from oracle import graph_ref as G
+    cfg = make_config(dtype="bfloat16", backbone="resnet50", h=512, w=640, batch=2, regress_ori=False, ori_bins=16)
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=1)
+    with hip.options(pwx=pwx, pair=(1 if pwx == 1 else 0)):
+        eng, w0 = _run_engine(cfg, img, loc, ori)
+    q = G.StorageRounding(torch.bfloat16)
+    dec = ReluDecisions(eng, tol=8e-2)
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+    assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
+    _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3)
 
 
 @pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 4e-3, 7e-3)])
