@@ -165,3 +165,101 @@ def test_reserved_comm_cus_bound_rccl_channels(monkeypatch):
     monkeypatch.delenv("NCCL_MAX_NCHANNELS")
     monkeypatch.setenv("URSO_DP_COMM_CUS", "8")
     assert dp.reserve_comm_cus() == 8 and os.environ["NCCL_MAX_NCHANNELS"] == "8"
+
+
+class _FakeConv(object):
+    def __init__(self, bn):
+        self.bn = bn
+
+
+def _schedule_worker(rank, world, port, out):
+    """DataParallelEngine over a FAKE engine (an op list + buckets, CPU tensors): the schedule logic of _derive_cuts / _segments /
+    step_eager without a GPU."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ursonet_amd.dp import DataParallelEngine, plan_buckets
+    # six layers in forward order a..f, each with a BN sibling; gradients are produced in backward order (f first); layer c's
+    # gradient is completed late (its "finalize" op comes after b's weight gradient): cuts must follow the LAST producing op
+    sizes = [("a", 0, 100), ("bn_a", 100, 110), ("b", 110, 400), ("bn_b", 400, 420), ("c", 420, 900), ("bn_c", 900, 910),
+             ("d", 910, 1500), ("bn_d", 1500, 1520), ("e", 1520, 1800), ("bn_e", 1800, 1830), ("f", 1830, 2000), ("bn_f", 2000, 2010)]
+    n = 2010
+    log = []
+
+    class Eng(object):
+        pass
+    eng = Eng()
+    eng.device = torch.device("cpu")
+    eng.flat_w, eng.flat_stats, eng.flat_g = torch.full((n,), float(rank)), torch.full((8,), float(rank)), torch.zeros(n)
+    eng.rel_exact, eng.loss_pre_ops, eng.plan_version = False, [], 1
+    eng.grad_bucket_bytes, eng.grad_tail_bytes = 600 * 4, 0
+    eng.buckets = plan_buckets(sizes, bucket_bytes=600 * 4)
+    eng.convs = {k: _FakeConv("bn_" + k) for k in "abcdef"}
+    span = {nm: (s, e) for nm, s, e in sizes}
+
+    def producer(names, tag):
+        def op():
+            log.append(("op", tag))
+            for nm in names:
+                for x in (nm, "bn_" + nm):
+                    s, e = span[x]
+                    eng.flat_g[s:e] = (rank + 1) * (1.0 + s)          # rank-dependent: the average is 1.5 * (1 + s)
+        return op
+
+    def noop(tag):
+        return lambda: log.append(("op", tag))
+    eng.prep_ops, eng.fwd_ops, eng.loss_ops = [noop("prep")], [noop("fwd")], [noop("loss")]
+    eng.bwd_ops = [("f", noop("wgrad:f")), (None, noop("dgrad:f")), (("f", "e"), producer("fe", "finalize:f,e")), ("d", producer("d", "wgrad:d")),
+                   (None, noop("dgrad:d")), ("b", noop("wgrad:b")), (("c", "b"), producer("cb", "finalize:c,b")), (None, noop("dgrad:b")),
+                   ("a", producer("a", "wgrad:a")), (None, noop("tail"))]
+    seen = {}
+
+    def opt():
+        log.append(("op", "optimizer"))
+        seen["g"] = eng.flat_g.clone()
+    eng.opt_ops = [opt]
+    eng._graphs = None
+    eng._build_plan = lambda: None
+    dp = DataParallelEngine(eng, bucket_bytes=600 * 4, tail_bytes=0)
+    launch0 = dp.reducer.launch
+
+    def launch(k):
+        log.append(("allreduce", k))
+        launch0(k)
+    dp.reducer.launch = launch
+    dp.step_eager()
+    out.put((rank, list(dp.buckets), list(dp.cuts), log, seen["g"].numpy(), eng.flat_w.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_dp_schedule_launches_every_bucket_after_its_last_producer_and_before_the_optimizer():
+    """2 ranks (gloo): the backward op list is cut where each gradient bucket becomes complete -- after the LAST op that produces any
+    layer (or BN sibling) of the bucket -- the bucket's all-reduce is launched right there, all of them are joined before the optimizer,
+    which sees the rank-averaged gradient; initial weights are rank 0's."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_schedule_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([out.get(timeout=120) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+    for rank, buckets, cuts, log, g, w in res:
+        assert np.all(w == 0.0)                                        # broadcast from rank 0
+        names = [b[2] for b in buckets]
+        assert sorted(sum(names, [])) == sorted(["a", "b", "c", "d", "e", "f"] + ["bn_" + k for k in "abcdef"])
+        pos = {entry: i for i, entry in enumerate(log)}
+        last_producer = {"a": "wgrad:a", "b": "finalize:c,b", "c": "finalize:c,b", "d": "wgrad:d", "e": "finalize:f,e", "f": "finalize:f,e"}
+        for k, nm in enumerate(names):
+            after = max(pos[("op", last_producer[x.replace("bn_", "")])] for x in nm)
+            assert pos[("allreduce", k)] > after, (k, nm, log)
+            # ... and immediately behind the segment that ends there: no later producer of ANOTHER bucket was launched first unless that
+            # bucket's own cut lies later
+            assert pos[("allreduce", k)] < pos[("op", "optimizer")]
+        assert [e for e in log if e[0] == "allreduce"] == [("allreduce", k) for k in range(len(buckets))]
+        assert log[-1] == ("op", "optimizer") and log[-2] == ("op", "tail")
+        assert cuts == sorted(cuts)
+        s_of = {nm: s for nm, s, e in [("a", 0, 100), ("bn_a", 100, 110), ("b", 110, 400), ("bn_b", 400, 420), ("c", 420, 900), ("bn_c", 900, 910),
+                                      ("d", 910, 1500), ("bn_d", 1500, 1520), ("e", 1520, 1800), ("bn_e", 1800, 1830), ("f", 1830, 2000), ("bn_f", 2000, 2010)]}
+        for nm, s in s_of.items():
+            assert abs(g[s] - 1.5 * (1.0 + s)) < 1e-4 * (1.0 + s), (nm, g[s])

@@ -176,6 +176,65 @@ def test_weights_file_roundtrip_npz(tmp_path):
     assert R["conv0"]["kernel"].shape == (7, 7, 3, 64) and "bias" not in R["conv0"]
 
 
+def test_h5_to_npz_converter_against_a_stand_in_h5py(tmp_path, monkeypatch):
+    """tools/h5_to_npz.py (the offline route for the released Keras .h5 files: h5py is absent from this image, so its h5py calls run
+    against a minimal stand-in): flat and nested ('model_weights') files, bytes attributes, 'layer/weight:0' dataset names -> the .npz
+    twin that read_weights_file / UrsoNet.load_weights take, values bit-equal, layer order kept."""
+    import importlib.util
+    import sys
+    import types
+    from ursonet_amd import net
+    from ursonet_amd.engine import initial_weights
+    from ursonet_amd.graph import build_graph
+
+    class Node(dict):
+        def __init__(self):
+            super(Node, self).__init__()
+            self.attrs = {}
+    store = {}
+
+    class File(object):
+        def __init__(self, path, mode="r"):
+            self.root = store[path]
+
+        def __enter__(self):
+            return self.root
+
+        def __exit__(self, *exc):
+            return False
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    W = initial_weights(build_graph(make_config("resnet18", 64, 64, regress_ori=True)), 2, True)
+    root = Node()
+    root.attrs["layer_names"] = [ln.encode("utf8") for ln in W]
+    for ln, ws in W.items():
+        g = Node(); g.attrs["weight_names"] = [("%s/%s:0" % (ln, wn)).encode("utf8") for wn in ws]
+        for wn, a in ws.items():
+            g["%s/%s:0" % (ln, wn)] = a
+        root[ln] = g
+    nested = Node(); nested["model_weights"] = root
+    store["flat.h5"], store["full_model.h5"] = root, nested
+    spec = importlib.util.spec_from_file_location("h5_to_npz", os.path.join(ROOT, "tools", "h5_to_npz.py"))
+    conv = importlib.util.module_from_spec(spec); spec.loader.exec_module(conv)
+    for src in ("flat.h5", "full_model.h5"):
+        dst = str(tmp_path / (src[:-3] + ".npz"))
+        assert conv.main([src, dst]) == 0
+        R = net.read_weights_file(dst)
+        assert list(R) == list(W) and all(np.array_equal(R[l][w], W[l][w]) and R[l][w].dtype == W[l][w].dtype for l in W for w in W[l])
+
+
+def test_build_rebuilds_on_source_hash_not_mtime(tmp_path, monkeypatch):
+    """ursonet_amd/build.py: the library is current iff the SHA-256 of its sources, header, flags and compiler version recorded next
+    to it (lib/liburso_hip.so.srchash) matches -- file times (a fresh checkout, a pushed snapshot) play no part."""
+    from ursonet_amd import build
+    assert os.path.exists(build.LIB) and not build.needs_build()
+    h = build.source_hash()
+    assert open(build.LIB + ".srchash").read().strip() == h and len(h) == 64
+    os.utime(os.path.join(build.CSRC, "common.h"), None)          # a newer mtime alone changes nothing
+    assert not build.needs_build()
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DURSO_TEST_FLAG=1"])
+    assert build.source_hash() != h and build.needs_build()        # different flags (or sources): stale
+
+
 def test_data_generator_and_mold_image():
     from ursonet_amd import net
     from ursonet_amd.dataset import SyntheticPoses

@@ -765,3 +765,37 @@ def test_compact_stage_boundary_gradients_equal_the_dense_path(dtype, monkeypatc
     # a 16-bit rounding here and there; the plans agree to a small fraction of a storage rounding step
     tol = 1e-2 if dtype == "bfloat16" else 2e-3          # measured 1e-3 ... 5e-3 / 1e-3 at this tiny size (3e-7 at cfg2 size: only the summation order of six weight gradients differs)
     assert wa[0] < tol and ww[0] < tol, (wa, ww)
+
+
+def test_bench_under_torchrun_with_forced_collectives_one_rank():
+    """What the driver's N > 1 run does, with the one GPU a test box has: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1` with URSO_DP_FORCE_COLLECTIVES=1 runs the REAL data-parallel path (rendezvous on 127.0.0.1, RCCL communicator, weight
+    broadcast, segmented hipGraphs, one RCCL all-reduce per gradient bucket, join before the optimizer).  The JSON line must carry the
+    dp record (exposed_comm_ms, bucket_bytes summing to 4 bytes x parameters) and a throughput within 5 % of the plain single-process
+    run (a one-rank all-reduce is a copy: the segmentation itself must cost next to nothing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--pcie-steps", "0", "--profile-steps", "1"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("URSO_DP_FORCE_COLLECTIVES", None)
+    plain = subprocess.run([sys.executable] + common, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert plain.returncode == 0, plain.stderr.decode()[-2000:]
+    p = json.loads(plain.stdout.decode().strip().splitlines()[-1])
+    env["URSO_DP_FORCE_COLLECTIVES"] = "1"
+    dp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541"] + common, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert dp.returncode == 0, dp.stderr.decode()[-2000:]
+    d = json.loads([l for l in dp.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
+    assert p["dp"] is None and d["dp"] is not None
+    assert d["n_gpus"] == 1 and d["metric"] == p["metric"]
+    assert d["dp"]["exposed_comm_ms"] >= 0.0 and len(d["dp"]["bucket_bytes"]) >= 2
+    cfg = make_config("resnet50", 512, 640, batch=32, regress_ori=False, ori_bins=16, dtype="bfloat16")
+    from ursonet_amd.graph import build_graph
+    # trainable parameters as the flat gradient buffer lays them out (each tensor padded to 4 floats; moving statistics are not gradients)
+    n_params = sum((int(np.prod(shp)) + 3) // 4 * 4 for ws in build_graph(cfg).params.values() for wn, shp in ws.items()
+                   if wn not in ("moving_mean", "moving_variance"))
+    assert sum(d["dp"]["bucket_bytes"]) == 4 * n_params
+    assert abs(d["value"] / p["value"] - 1.0) < 0.05, (d["value"], p["value"])

@@ -21,12 +21,35 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash():
+    """SHA-256 over everything the library is a function of: every file of csrc/ (name + bytes), the public header, the compile flags
+    (incl. URSO_VARIANT_FLAGS) and the compiler's version string."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "ursonet_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + os.environ.get("URSO_VARIANT_FLAGS", "").split() + SOURCES).encode())
+    try:
+        h.update(subprocess.run([_hipcc(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout)
+    except Exception:
+        pass
+    return h.hexdigest()
+
+
 def needs_build():
+    """Stale unless the hash recorded next to the .so equals the hash of the sources as they are now (mtimes are meaningless after a
+    checkout or a snapshot push; a .so shipped without its hash file is rebuilt where a compiler exists and trusted where none does)."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "ursonet_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(LIB + ".srchash") as fh:
+            return fh.read().strip() != source_hash()
+    except IOError:
+        return True
 
 
 def build(force=False, verbose=True):
@@ -53,6 +76,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(LIB + ".srchash", "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

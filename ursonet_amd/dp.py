@@ -277,6 +277,25 @@ class DataParallelEngine(object):
             ev[1].record()                   # ... and this one completes only once the last collective has
         self._graphs[-1].replay()            # global-norm clip + momentum SGD on the averaged gradient
 
+    def step_eager(self):
+        """The same schedule as step() launched op by op instead of by graph replay (debugging; the gloo CPU test of the schedule):
+        backward segment k, then the all-reduce of bucket k, ..., every collective joined, then the tail of the backward pass and
+        the optimizer."""
+        if self.plan_version != self.eng.plan_version:
+            self._derive_cuts()
+        segs, last = self._segments()
+        if self.rel_exact:
+            for op in self.eng.prep_ops + self.eng.fwd_ops + self.eng.loss_pre_ops:
+                op()
+            allreduce_rel_norms(self.eng.rel_norms, self.group)
+        for k, ops in enumerate(segs):
+            for op in ops:
+                op()
+            self.reducer.launch(k)
+        self.reducer.wait_all()
+        for op in last:
+            op()
+
     def exposed_comm_ms(self, steps=5):
         """Mean time per step the compute stream spends waiting for collectives after its last backward kernel: the part of the exchange
         step that the backward pass did not hide (two events around the join, outside the captured graphs)."""
