@@ -478,6 +478,17 @@ enum { URSO_K_IGEMM = 1, URSO_K_WGRAD = 2, URSO_K_PREP = 3, URSO_K_FINALIZE = 4,
        URSO_K_LOSS = 6, URSO_K_OPTIM = 7, URSO_K_DECODE = 8, URSO_K_MOLD = 9 };
 int urso_prof_enable(int on);
 int urso_prof_collect(urso_prof_record* out, int max_records);   /* returns #records, clears */
+/* The same records with the device symbol of the (first) kernel each urso_* call launched, as the HIP runtime knows it
+ * (hipKernelNameRefByPtr: the mangled name rocprofv3's kernel trace prints), and the number of kernels the call launched. */
+typedef struct urso_prof_record_ex {
+    int32_t kernel_id;
+    float   ms;
+    double  flops;
+    double  bytes;
+    int32_t n_launches;
+    char    symbol[236];
+} urso_prof_record_ex;
+int urso_prof_collect_ex(urso_prof_record_ex* out, int max_records);
 
 /*
  * Data-parallel exchange (replaces keras.utils.multi_gpu_model's gradient gather, pose_estimator.py:28): bucketed

@@ -26,10 +26,19 @@ eng.step_eager(); eng.step_eager()
 recs = eng.profile_step()
 tot = sum(r[2] for r in recs)
 print("# %s B=%d %dx%d %s : %.3f ms per eager step (sum of launches)" % (a.backbone, a.batch, a.height, a.width, a.dtype, tot))
-print("%-34s %9s %9s %9s" % ("launch", "us", "TFLOP/s", "GB/s(alg)"))
+def short(sym):
+    """_Z15wgrad_tr_kernelIDF16bLi0ELb1EEv9WgradArgs -> wgrad_tr_kernel<...>: the name up to its template arguments."""
+    import re
+    m = re.match(r"_Z(\d+)", sym)
+    if m:
+        n = int(m.group(1)); st = m.end()
+        return sym[st:st + n] + ("<" + sym[st + n + 1:st + n + 25] + ">" if len(sym) > st + n and sym[st + n] == "I" else "")
+    return sym.split("(")[0][:40]
+print("%-34s %9s %9s %9s  %s" % ("launch", "us", "TFLOP/s", "GB/s(alg)", "kernel (device symbol, first of the call)"))
 groups = {}
-for label, kid, ms, fl, by in recs:
-    print("%-34s %9.1f %9.1f %9.1f" % (label, ms * 1e3, fl / (ms * 1e9) if ms > 0 else 0, by / (ms * 1e6) if ms > 0 else 0))
+for label, kid, ms, fl, by, nl, sym in recs:
+    print("%-34s %9.1f %9.1f %9.1f  %s%s" % (label, ms * 1e3, fl / (ms * 1e9) if ms > 0 else 0, by / (ms * 1e6) if ms > 0 else 0, short(sym),
+                                          (" +%d" % (nl - 1)) if nl > 1 else ""))
     g = label.split(":")[0]
     groups.setdefault(g, [0.0, 0.0, 0]); groups[g][0] += ms; groups[g][1] += fl; groups[g][2] += 1
 print("\n# totals")

@@ -54,8 +54,8 @@ extern "C" int urso_warp_perspective(int B, int H, int W, int C, int interp, con
     const size_t npix = (size_t)B * H * W;
     int blocks = (int)((npix + 255) / 256); if (blocks > 8192) blocks = 8192;
     ProfScope ps(st, URSO_K_MOLD, 0, (double)npix * C * 2);
-    if (interp) hipLaunchKernelGGL(warp_kernel<1>, dim3(blocks), dim3(256), 0, st, B, H, W, C, src_d, m_d, dst_d);
-    else hipLaunchKernelGGL(warp_kernel<0>, dim3(blocks), dim3(256), 0, st, B, H, W, C, src_d, m_d, dst_d);
+    if (interp) URSO_KLAUNCH(warp_kernel<1>, dim3(blocks), dim3(256), 0, st, B, H, W, C, src_d, m_d, dst_d);
+    else URSO_KLAUNCH(warp_kernel<0>, dim3(blocks), dim3(256), 0, st, B, H, W, C, src_d, m_d, dst_d);
     return urso_check_launch("urso_warp_perspective");
 }
 
@@ -96,7 +96,7 @@ extern "C" int urso_encode_ori(int B, int K, const double* q_d, const float* hqu
     if (((uintptr_t)hquat_d) & 15) { urso_set_error("urso_encode_ori: hquat must be 16-byte aligned"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 17);
-    hipLaunchKernelGGL(encode_ori_kernel, dim3(B), dim3(256), 0, st, K, q_d, hquat_d, redundant_d, var, out_d);
+    URSO_KLAUNCH(encode_ori_kernel, dim3(B), dim3(256), 0, st, K, q_d, hquat_d, redundant_d, var, out_d);
     return urso_check_launch("urso_encode_ori");
 }
 
@@ -130,7 +130,7 @@ extern "C" int urso_encode_loc(int B, int K, const double* loc_d, const double* 
     if (!loc_d || !hmap_d || !out_d || B <= 0 || K <= 0 || !(sig2 > 0)) { urso_set_error("urso_encode_loc: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 24);
-    hipLaunchKernelGGL(encode_loc_kernel, dim3(B), dim3(256), 0, st, K, loc_d, hmap_d, sig2, out_d);
+    URSO_KLAUNCH(encode_loc_kernel, dim3(B), dim3(256), 0, st, K, loc_d, hmap_d, sig2, out_d);
     return urso_check_launch("urso_encode_loc");
 }
 
@@ -206,7 +206,7 @@ extern "C" int urso_rgb_to_grey3(int B, int H, int W, const uint8_t* src_d, uint
     if (!src_d || !dst_d || B <= 0 || H <= 0 || W <= 0) { urso_set_error("urso_rgb_to_grey3: bad argument"); return URSO_EINVAL; }
     const size_t npix = (size_t)B * H * W;
     int blocks = (int)((npix + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(grey3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, npix, src_d, dst_d);
+    URSO_KLAUNCH(grey3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, npix, src_d, dst_d);
     return urso_check_launch("urso_rgb_to_grey3");
 }
 
@@ -216,7 +216,7 @@ extern "C" int urso_sim2real_op(int B, int H, int W, const uint8_t* src_d, uint8
         urso_set_error("urso_sim2real_op: bad argument (src and dst must differ)"); return URSO_EINVAL;
     }
     int bx = (H * W + 255) / 256; if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(sim2real_op_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, src_d, dst_d, op_d, par_d, seed_d, drop_d, drop_stride);
+    URSO_KLAUNCH(sim2real_op_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, src_d, dst_d, op_d, par_d, seed_d, drop_d, drop_stride);
     return urso_check_launch("urso_sim2real_op");
 }
 
@@ -236,6 +236,6 @@ extern "C" int urso_pad_images_u8(int B, int H, int W, int C, int OH, int OW, in
     }
     const size_t n = (size_t)OH * OW * C;
     int bx = (int)((n + 255) / 256); if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(place_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, C, OH, OW, top, left, src_d, dst_d);
+    URSO_KLAUNCH(place_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, H, W, C, OH, OW, top, left, src_d, dst_d);
     return urso_check_launch("urso_pad_images_u8");
 }

@@ -159,10 +159,10 @@ extern "C" int urso_bn_batch_stats(int M, int N, int dt, const void* z_d, void* 
     const int nb = bn_red_blocks(M);
     const size_t lds = bn_red_lds(N, dt);
     ProfScope ps(st, URSO_K_POOL, 0, (double)M * N * dt_size(dt));
-    if (dt == URSO_F32) hipLaunchKernelGGL((bn_colreduce_kernel<float, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const float*)z_d, (const float*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((bn_colreduce_kernel<__bf16, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const __bf16*)z_d, (const __bf16*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
-    else hipLaunchKernelGGL((bn_colreduce_kernel<_Float16, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const _Float16*)z_d, (const _Float16*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, M, N, nb, (const double*)ws_d, mean_d, var_d, moving_mean_d, moving_var_d, momentum, eps);
+    if (dt == URSO_F32) URSO_KLAUNCH((bn_colreduce_kernel<float, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const float*)z_d, (const float*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((bn_colreduce_kernel<__bf16, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const __bf16*)z_d, (const __bf16*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
+    else URSO_KLAUNCH((bn_colreduce_kernel<_Float16, 0>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const _Float16*)z_d, (const _Float16*)nullptr, nullptr, nullptr, eps, (double*)ws_d);
+    URSO_KLAUNCH(bn_stats_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, M, N, nb, (const double*)ws_d, mean_d, var_d, moving_mean_d, moving_var_d, momentum, eps);
     return urso_check_launch("urso_bn_batch_stats");
 }
 
@@ -174,9 +174,9 @@ extern "C" int urso_bn_apply(int M, int N, int dt, const void* z_d, const float*
     const size_t nvec = (size_t)M * N * dt_size(dt) / 16;
     int blocks = (int)((nvec + 255) / 256); if (blocks > 8192) blocks = 8192;
     ProfScope ps(st, URSO_K_POOL, 0, (double)M * N * dt_size(dt) * (res_d ? 3 : 2));
-    if (dt == URSO_F32) hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, nvec, N, (const float*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const float*)res_d, relu, (float*)y_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((bn_apply_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, nvec, N, (const __bf16*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const __bf16*)res_d, relu, (__bf16*)y_d);
-    else hipLaunchKernelGGL((bn_apply_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, nvec, N, (const _Float16*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const _Float16*)res_d, relu, (_Float16*)y_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((bn_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, nvec, N, (const float*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const float*)res_d, relu, (float*)y_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((bn_apply_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, nvec, N, (const __bf16*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const __bf16*)res_d, relu, (__bf16*)y_d);
+    else URSO_KLAUNCH((bn_apply_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, nvec, N, (const _Float16*)z_d, mean_d, var_d, gamma_d, beta_d, eps, (const _Float16*)res_d, relu, (_Float16*)y_d);
     return urso_check_launch("urso_bn_apply");
 }
 
@@ -193,9 +193,9 @@ extern "C" int urso_bn_backward(int M, int N, int dt, const void* g_d, const voi
     int blocks = (int)((nvec + 255) / 256); if (blocks > 8192) blocks = 8192;
     ProfScope ps(st, URSO_K_POOL, 0, (double)M * N * dt_size(dt) * 5);
 #define URSO_BNB(TT) do { \
-        hipLaunchKernelGGL((bn_colreduce_kernel<TT, 1>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const TT*)g_d, (const TT*)z_d, mean_d, var_d, eps, (double*)ws_d); \
-        hipLaunchKernelGGL(bn_sum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, nb, (const double*)ws_d, dbeta_d, dgamma_d, bn_trainable, gbeta_d, ggamma_d); \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<TT>), dim3(blocks), dim3(256), 0, st, nvec, N, 1.0f / (float)M, (const TT*)g_d, (const TT*)z_d, mean_d, var_d, gamma_d, eps, \
+        URSO_KLAUNCH((bn_colreduce_kernel<TT, 1>), dim3(nb, bn_col_groups(N, dt)), dim3(256), lds, st, M, N, (const TT*)g_d, (const TT*)z_d, mean_d, var_d, eps, (double*)ws_d); \
+        URSO_KLAUNCH(bn_sum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, nb, (const double*)ws_d, dbeta_d, dgamma_d, bn_trainable, gbeta_d, ggamma_d); \
+        URSO_KLAUNCH((bn_bwd_apply_kernel<TT>), dim3(blocks), dim3(256), 0, st, nvec, N, 1.0f / (float)M, (const TT*)g_d, (const TT*)z_d, mean_d, var_d, gamma_d, eps, \
                            (const float*)dbeta_d, (const float*)dgamma_d, (TT*)dz_d); } while (0)
     if (dt == URSO_F32) URSO_BNB(float); else if (dt == URSO_BF16) URSO_BNB(__bf16); else URSO_BNB(_Float16);
 #undef URSO_BNB

@@ -48,6 +48,10 @@ static __host__ __device__ inline int urso_reduce_lanes(int splits) { return spl
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);
 void urso_prof_after(hipStream_t s);
 
+void urso_prof_symbol(const void* host_fn);        // runtime.hip: remembers which kernel the open profiler record launched
+// every kernel launch of the library goes through this macro so that the launch profiler can name the kernel by its device symbol
+#define URSO_KLAUNCH(kern, grid, blk, shm, st, ...) do { urso_prof_symbol((const void*)(kern)); hipLaunchKernelGGL(kern, grid, blk, shm, st, ##__VA_ARGS__); } while (0)
+
 struct ProfScope {
     hipStream_t s;
     ProfScope(hipStream_t st, int id, double flops, double bytes) : s(st) { urso_prof_before(s, id, flops, bytes); }

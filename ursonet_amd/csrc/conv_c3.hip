@@ -456,19 +456,19 @@ int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, c
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(wide ? 512 : 256);
     if (wide) {
-#define URSO_C3W(TT, TWV) do { if (mask) hipLaunchKernelGGL((c3w_kernel<TT, true, TWV>), grid, blk, 0, st, a); \
-                               else hipLaunchKernelGGL((c3w_kernel<TT, false, TWV>), grid, blk, 0, st, a); } while (0)
+#define URSO_C3W(TT, TWV) do { if (mask) URSO_KLAUNCH((c3w_kernel<TT, true, TWV>), grid, blk, 0, st, a); \
+                               else URSO_KLAUNCH((c3w_kernel<TT, false, TWV>), grid, blk, 0, st, a); } while (0)
         if (dt == URSO_BF16) { if (tw == 32) URSO_C3W(__bf16, 32); else URSO_C3W(__bf16, 16); }
         else { if (tw == 32) URSO_C3W(_Float16, 32); else URSO_C3W(_Float16, 16); }
 #undef URSO_C3W
         return urso_check_launch("urso_conv_igemm(3x3, 128 channels)");
     }
     if (dt == URSO_BF16) {
-        if (mask) hipLaunchKernelGGL((c3_kernel<__bf16, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((c3_kernel<__bf16, false>), grid, blk, 0, st, a);
+        if (mask) URSO_KLAUNCH((c3_kernel<__bf16, true>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((c3_kernel<__bf16, false>), grid, blk, 0, st, a);
     } else {
-        if (mask) hipLaunchKernelGGL((c3_kernel<_Float16, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((c3_kernel<_Float16, false>), grid, blk, 0, st, a);
+        if (mask) URSO_KLAUNCH((c3_kernel<_Float16, true>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((c3_kernel<_Float16, false>), grid, blk, 0, st, a);
     }
     return urso_check_launch("urso_conv_igemm(3x3, 64 channels)");
 }

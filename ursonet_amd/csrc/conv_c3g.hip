@@ -195,7 +195,7 @@ int urso_c3g_launch(const urso_conv_geom* g, int dt, const void* x, const void* 
     a.bytes = (uint32_t)((size_t)g->B * g->H * g->W * 128);
     a.tiles_x = ceil_div(a.W, CG_TW); a.tiles_y = ceil_div(a.H, CG_TH); a.ntiles = a.B * a.tiles_y * a.tiles_x;
     const dim3 grid(urso_c3g_splits(g)), blk(512);
-    if (dt == URSO_BF16) hipLaunchKernelGGL((c3g_kernel<__bf16>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((c3g_kernel<_Float16>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((c3g_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((c3g_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_wgrad(c3)");
 }

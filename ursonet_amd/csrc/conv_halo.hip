@@ -452,7 +452,7 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     a.flags = streamk ? (unsigned int*)ws : nullptr;
     a.part = streamk ? (float*)((char*)ws + 4096) : nullptr;
     a.units = streamk ? a.ntiles * a.nchunks : a.ntiles;
-    if (dt == URSO_BF16) hipLaunchKernelGGL((hconv_kernel<__bf16>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((hconv_kernel<_Float16>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((hconv_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((hconv_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(halo)");
 }

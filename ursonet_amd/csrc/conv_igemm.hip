@@ -447,24 +447,24 @@ static int launch_igemm(const urso_conv_geom* g, int flags, IgemmArgs& a, void* 
     if (emit && (a.mask || !a.bits_out)) { urso_set_error("urso_conv_igemm: EMIT_BITS needs bits_out and no mask"); return URSO_EINVAL; }
     // the scalar path reads add/mask through a.*
     const int sel = fastepi ? ((a.add ? 1 : 0) | (a.mask ? (mbits ? 4 : 2) : 0) | (emit ? 8 : 0)) : 0;
-#define URSO_LAUNCH(BN_, AD_, MK_, SP_, EM_) hipLaunchKernelGGL((igemm_kernel<T, 128, BN_, AD_, MK_, SP_, EM_>), grid, blk, 0, st, a)
+#define URSO_IG(BN_, AD_, MK_, SP_, EM_) URSO_KLAUNCH((igemm_kernel<T, 128, BN_, AD_, MK_, SP_, EM_>), grid, blk, 0, st, a)
 #define URSO_SEL(BN_) switch (sel) { \
-        case 0: URSO_LAUNCH(BN_, false, 0, false, false); break; case 1: URSO_LAUNCH(BN_, true, 0, false, false); break; \
-        case 2: URSO_LAUNCH(BN_, false, 1, false, false); break; case 3: URSO_LAUNCH(BN_, true, 1, false, false); break; \
-        case 4: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, false, 2, false, false); break; \
-        case 5: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, true, 2, false, false); break; \
-        case 8: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, false, 0, false, true); break; \
-        case 9: if constexpr (sizeof(T) == 2) URSO_LAUNCH(BN_, true, 0, false, true); break; \
+        case 0: URSO_IG(BN_, false, 0, false, false); break; case 1: URSO_IG(BN_, true, 0, false, false); break; \
+        case 2: URSO_IG(BN_, false, 1, false, false); break; case 3: URSO_IG(BN_, true, 1, false, false); break; \
+        case 4: if constexpr (sizeof(T) == 2) URSO_IG(BN_, false, 2, false, false); break; \
+        case 5: if constexpr (sizeof(T) == 2) URSO_IG(BN_, true, 2, false, false); break; \
+        case 8: if constexpr (sizeof(T) == 2) URSO_IG(BN_, false, 0, false, true); break; \
+        case 9: if constexpr (sizeof(T) == 2) URSO_IG(BN_, true, 0, false, true); break; \
         default: urso_set_error("urso_conv_igemm: unsupported epilogue combination"); return URSO_EINVAL; }
-    if (a.ksplit > 1) { if (small) URSO_LAUNCH(64, false, 0, true, false); else URSO_LAUNCH(128, false, 0, true, false); }
+    if (a.ksplit > 1) { if (small) URSO_IG(64, false, 0, true, false); else URSO_IG(128, false, 0, true, false); }
     else if (small) { URSO_SEL(64) }
     else { URSO_SEL(128) }
 #undef URSO_SEL
-#undef URSO_LAUNCH
+#undef URSO_IG
     if (a.ksplit > 1) {
         const size_t elems = (size_t)a.M * g->N, n4 = elems / 4;
         int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3(blocks), dim3(256), 0, st, n4, g->N, a.ksplit, elems, (const float*)a.part, a.bias,
+        URSO_KLAUNCH((splitk_finish_kernel<T>), dim3(blocks), dim3(256), 0, st, n4, g->N, a.ksplit, elems, (const float*)a.part, a.bias,
                            (const T*)a.add, (const T*)a.mask, a.dst, flags);
     }
     return urso_check_launch("urso_conv_igemm");

@@ -433,32 +433,32 @@ static void pr_launch(const PairArgs& a, int dt, int mode, bool emit, int blocks
     const dim3 grid(8 * bpx, groups), blk(S::NW * 64);
     if constexpr (VAR == 0) {
         if (sparse && mode == 1) {
-            if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0, true>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 0, true>), grid, blk, 0, st, a);
+            if (dt == URSO_BF16) URSO_KLAUNCH((pair_kernel<__bf16, 1, false, S, 0, true>), grid, blk, 0, st, a);
+            else URSO_KLAUNCH((pair_kernel<_Float16, 1, false, S, 0, true>), grid, blk, 0, st, a);
         } else if (dt == URSO_BF16) {
-            if (mode == 1) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 0>), grid, blk, 0, st, a);
-            else if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, 0>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, 0>), grid, blk, 0, st, a);
+            if (mode == 1) URSO_KLAUNCH((pair_kernel<__bf16, 1, false, S, 0>), grid, blk, 0, st, a);
+            else if (emit) URSO_KLAUNCH((pair_kernel<__bf16, 0, true, S, 0>), grid, blk, 0, st, a);
+            else URSO_KLAUNCH((pair_kernel<__bf16, 0, false, S, 0>), grid, blk, 0, st, a);
         } else {
-            if (mode == 1) hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 0>), grid, blk, 0, st, a);
-            else if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, 0>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, 0>), grid, blk, 0, st, a);
+            if (mode == 1) URSO_KLAUNCH((pair_kernel<_Float16, 1, false, S, 0>), grid, blk, 0, st, a);
+            else if (emit) URSO_KLAUNCH((pair_kernel<_Float16, 0, true, S, 0>), grid, blk, 0, st, a);
+            else URSO_KLAUNCH((pair_kernel<_Float16, 0, false, S, 0>), grid, blk, 0, st, a);
         }
     } else {
         if (mode == 1) {                                     // add + bit-mask form of a single layer (VAR 1 only)
             if constexpr (VAR == 1) {
-                if (dt == URSO_BF16) hipLaunchKernelGGL((pair_kernel<__bf16, 1, false, S, 1>), grid, blk, 0, st, a);
-                else hipLaunchKernelGGL((pair_kernel<_Float16, 1, false, S, 1>), grid, blk, 0, st, a);
+                if (dt == URSO_BF16) URSO_KLAUNCH((pair_kernel<__bf16, 1, false, S, 1>), grid, blk, 0, st, a);
+                else URSO_KLAUNCH((pair_kernel<_Float16, 1, false, S, 1>), grid, blk, 0, st, a);
             }
         } else if (sparse) {                                   // + the sampled copy of the output (always with the bit mask: block outputs)
-            if (dt == URSO_BF16) { if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
-            else { if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
+            if (dt == URSO_BF16) { if (emit) URSO_KLAUNCH((pair_kernel<__bf16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pair_kernel<__bf16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
+            else { if (emit) URSO_KLAUNCH((pair_kernel<_Float16, 0, true, S, VAR, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pair_kernel<_Float16, 0, false, S, VAR, true>), grid, blk, 0, st, a); }
         } else if (dt == URSO_BF16) {
-            if (emit) hipLaunchKernelGGL((pair_kernel<__bf16, 0, true, S, VAR>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((pair_kernel<__bf16, 0, false, S, VAR>), grid, blk, 0, st, a);
+            if (emit) URSO_KLAUNCH((pair_kernel<__bf16, 0, true, S, VAR>), grid, blk, 0, st, a);
+            else URSO_KLAUNCH((pair_kernel<__bf16, 0, false, S, VAR>), grid, blk, 0, st, a);
         } else {
-            if (emit) hipLaunchKernelGGL((pair_kernel<_Float16, 0, true, S, VAR>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((pair_kernel<_Float16, 0, false, S, VAR>), grid, blk, 0, st, a);
+            if (emit) URSO_KLAUNCH((pair_kernel<_Float16, 0, true, S, VAR>), grid, blk, 0, st, a);
+            else URSO_KLAUNCH((pair_kernel<_Float16, 0, false, S, VAR>), grid, blk, 0, st, a);
         }
     }
 }

@@ -253,7 +253,7 @@ extern "C" int urso_conv_pair_shortcut(long long M, int dt, const void* src_d, c
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
-    if (dt == URSO_BF16) { if (bits_d) hipLaunchKernelGGL((pairs_kernel<__bf16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairs_kernel<__bf16, false>), grid, blk, 0, st, a); }
-    else { if (bits_d) hipLaunchKernelGGL((pairs_kernel<_Float16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairs_kernel<_Float16, false>), grid, blk, 0, st, a); }
+    if (dt == URSO_BF16) { if (bits_d) URSO_KLAUNCH((pairs_kernel<__bf16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pairs_kernel<__bf16, false>), grid, blk, 0, st, a); }
+    else { if (bits_d) URSO_KLAUNCH((pairs_kernel<_Float16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pairs_kernel<_Float16, false>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_conv_pair_shortcut");
 }

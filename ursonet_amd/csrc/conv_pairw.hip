@@ -345,8 +345,8 @@ extern "C" int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, cons
     const double bytes = (double)M * (3.0 * 128 + (sparse ? 1.25 : 2.0) * 512 + 32);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     const dim3 grid(splits), blk(512);
-    if (dt == URSO_BF16) { if (sparse) hipLaunchKernelGGL((pairw_kernel<__bf16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairw_kernel<__bf16, false>), grid, blk, 0, st, a); }
-    else { if (sparse) hipLaunchKernelGGL((pairw_kernel<_Float16, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((pairw_kernel<_Float16, false>), grid, blk, 0, st, a); }
+    if (dt == URSO_BF16) { if (sparse) URSO_KLAUNCH((pairw_kernel<__bf16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pairw_kernel<__bf16, false>), grid, blk, 0, st, a); }
+    else { if (sparse) URSO_KLAUNCH((pairw_kernel<_Float16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((pairw_kernel<_Float16, false>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_conv_pair_wgrad");
 }
 
@@ -369,7 +369,7 @@ extern "C" int urso_conv_dgrad_wgrad_pw(long long M, int dt, const void* dz_d, c
     a.sp_h = a.sp_w = 0; a.rcp_hw = a.rcp_w = 0.f; a.masked = mask_by_x ? 1 : 0;
     ProfScope ps(st, URSO_K_IGEMM, 2.0 * (double)M * 64 * 256 * 2.0, (double)M * (2.0 * 128 + 512));
     const dim3 grid(splits), blk(512);
-    if (dt == URSO_BF16) hipLaunchKernelGGL((pairw_kernel<__bf16, false, true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((pairw_kernel<_Float16, false, true>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((pairw_kernel<__bf16, false, true>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((pairw_kernel<_Float16, false, true>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_dgrad_wgrad_pw");
 }

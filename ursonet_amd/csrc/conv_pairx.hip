@@ -346,7 +346,7 @@ extern "C" int urso_conv_pair_wgrad_entry(long long M, int dt, const void* src_d
     a.ntiles = (int)(M / PX_BM); a.mask_p = mask_by_xin ? 1 : 0;
     ProfScope ps(st, URSO_K_IGEMM, 2.0 * (double)M * 64 * 256 * 5.0, (double)M * (5.0 * 128 + 512 + 32));
     const dim3 grid(splits), blk(512);
-    if (dt == URSO_BF16) hipLaunchKernelGGL((pairx_kernel<__bf16>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((pairx_kernel<_Float16>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((pairx_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((pairx_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_pair_wgrad_entry");
 }

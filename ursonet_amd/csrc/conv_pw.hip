@@ -391,25 +391,25 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
     const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
-#define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 0, CV_>), grid, blk, 0, st, a); break; \
-                                        case 1: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 0, CV_>), grid, blk, 0, st, a); break; \
-                                        case 2: hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 1, CV_>), grid, blk, 0, st, a); break; \
-                                        default: hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 1, CV_>), grid, blk, 0, st, a); }
+#define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: URSO_KLAUNCH((pw_kernel<TT, BN_, false, 0, CV_>), grid, blk, 0, st, a); break; \
+                                        case 1: URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, CV_>), grid, blk, 0, st, a); break; \
+                                        case 2: URSO_KLAUNCH((pw_kernel<TT, BN_, false, 1, CV_>), grid, blk, 0, st, a); break; \
+                                        default: URSO_KLAUNCH((pw_kernel<TT, BN_, true, 1, CV_>), grid, blk, 0, st, a); }
 #define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, 1) } else { URSO_PW2(TT, BN_, 0) } } while (0)
     if (mask_bits || bits_out) {         // ReLU bit masks: pointwise layers only (conv_igemm.hip checked): emit = forward with residual, consume = data gradient
 #define URSO_PWB(TT, BN_) do { \
-        if (bits_out) { if (add) hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 0, 0, true>), grid, blk, 0, st, a); \
-                        else hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 0, 0, true>), grid, blk, 0, st, a); } \
-        else { if (add) hipLaunchKernelGGL((pw_kernel<TT, BN_, true, 2, 0, false>), grid, blk, 0, st, a); \
-               else hipLaunchKernelGGL((pw_kernel<TT, BN_, false, 2, 0, false>), grid, blk, 0, st, a); } } while (0)
+        if (bits_out) { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, 0, true>), grid, blk, 0, st, a); \
+                        else URSO_KLAUNCH((pw_kernel<TT, BN_, false, 0, 0, true>), grid, blk, 0, st, a); } \
+        else { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 2, 0, false>), grid, blk, 0, st, a); \
+               else URSO_KLAUNCH((pw_kernel<TT, BN_, false, 2, 0, false>), grid, blk, 0, st, a); } } while (0)
         if (dt == URSO_BF16) { if (small) URSO_PWB(__bf16, 64); else URSO_PWB(__bf16, 128); }
         else { if (small) URSO_PWB(_Float16, 64); else URSO_PWB(_Float16, 128); }
 #undef URSO_PWB
         return urso_check_launch("urso_conv_igemm(dma, bits)");
     }
     if (conv == 2) {                     // the stem: N <= 64, no residual / mask (conv_igemm.hip checked)
-        if (dt == URSO_BF16) hipLaunchKernelGGL((pw_kernel<__bf16, 64, false, 0, 2>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((pw_kernel<_Float16, 64, false, 0, 2>), grid, blk, 0, st, a);
+        if (dt == URSO_BF16) URSO_KLAUNCH((pw_kernel<__bf16, 64, false, 0, 2>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((pw_kernel<_Float16, 64, false, 0, 2>), grid, blk, 0, st, a);
     }
     else if (dt == URSO_BF16) { if (small) URSO_PW(__bf16, 64); else URSO_PW(__bf16, 128); }
     else { if (small) URSO_PW(_Float16, 64); else URSO_PW(_Float16, 128); }

@@ -333,7 +333,7 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
     if (bpx > cus / 8) bpx = cus / 8;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);
-#define URSO_PX(TT, BN_, NST_, AD_, MK_, EM_) hipLaunchKernelGGL((pwx_kernel<TT, 5, BN_, NST_, AD_, MK_, EM_>), grid, blk, 0, st, a)
+#define URSO_PX(TT, BN_, NST_, AD_, MK_, EM_) URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, AD_, MK_, EM_>), grid, blk, 0, st, a)
 #define URSO_PXF(TT, BN_, NST_) switch (form) { case 0: URSO_PX(TT, BN_, NST_, false, 0, false); break; case 1: URSO_PX(TT, BN_, NST_, true, 0, true); break; \
                                                 case 2: URSO_PX(TT, BN_, NST_, false, 1, false); break; case 3: URSO_PX(TT, BN_, NST_, true, 2, false); break; \
                                                 case 4: URSO_PX(TT, BN_, NST_, false, 2, false); break; default: URSO_PX(TT, BN_, NST_, true, 0, false); }

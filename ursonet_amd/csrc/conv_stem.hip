@@ -197,7 +197,7 @@ int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src,
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
-    if (dt == URSO_BF16) hipLaunchKernelGGL((stem_kernel<__bf16>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((stem_kernel<_Float16>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((stem_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((stem_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(stem)");
 }

@@ -260,9 +260,9 @@ int urso_stemw_launch(const urso_conv_geom* g, int dt, const void* x, const void
     a.tiles_x = ceil_div(a.OW, SW_TW); a.tiles_y = ceil_div(a.OH, SW_TH); a.ntiles = a.B * a.tiles_y * a.tiles_x;
     const dim3 grid(urso_stemw_splits(g, dpool != nullptr)), blk(256);
     if (dpool) {
-        if (dt == URSO_BF16) hipLaunchKernelGGL((stemw_kernel<__bf16, true>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((stemw_kernel<_Float16, true>), grid, blk, 0, st, a);
-    } else if (dt == URSO_BF16) hipLaunchKernelGGL((stemw_kernel<__bf16, false>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((stemw_kernel<_Float16, false>), grid, blk, 0, st, a);
+        if (dt == URSO_BF16) URSO_KLAUNCH((stemw_kernel<__bf16, true>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((stemw_kernel<_Float16, true>), grid, blk, 0, st, a);
+    } else if (dt == URSO_BF16) URSO_KLAUNCH((stemw_kernel<__bf16, false>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((stemw_kernel<_Float16, false>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_wgrad(stem)");
 }

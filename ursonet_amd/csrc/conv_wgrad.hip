@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const urso_p
 }
 
 void urso_reduce_partials_batch_launch(const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+    URSO_KLAUNCH(reduce_partials_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
 }
 
 struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split, narrow; size_t part_elems, col_elems; };
@@ -765,8 +765,8 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
         int rc = urso_stemw_launch(g, dt, x_d, dz_d, nullptr, nullptr, part, colsum_d ? colpart : nullptr, pstride, st);
         if (rc != URSO_OK) return rc;
         const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(splits);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
+        URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
+        if (colsum_d) URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
         return urso_check_launch("urso_conv_wgrad(stem reduce)");
     }
     WgradArgs a;
@@ -793,13 +793,13 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
     const int rm = 128 / (int)dt_size(dt);
     const int mode = a.pointwise ? 0 : (g->OW >= rm ? 1 : 2);
     const int tmode = a.pointwise ? 0 : ((64 / g->OW + 1 <= g->OH) ? 1 : 2);     // 16-bit kernel: carried coordinates whenever one wrap suffices
-#define URSO_WG(KERN, TT, MD) do { if (MD == 0) hipLaunchKernelGGL((KERN<TT, 0>), grid, dim3(256), 0, st, a); \
-                         else if (MD == 1) hipLaunchKernelGGL((KERN<TT, 1>), grid, dim3(256), 0, st, a); \
-                         else hipLaunchKernelGGL((KERN<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
+#define URSO_WG(KERN, TT, MD) do { if (MD == 0) URSO_KLAUNCH((KERN<TT, 0>), grid, dim3(256), 0, st, a); \
+                         else if (MD == 1) URSO_KLAUNCH((KERN<TT, 1>), grid, dim3(256), 0, st, a); \
+                         else URSO_KLAUNCH((KERN<TT, 2>), grid, dim3(256), 0, st, a); } while (0)
     const int pipe = g_urso_opt.wgrad_pipe;   // measured +0.2 % on the step
-#define URSO_WGP(TT, MD) do { if (MD == 0) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 0, true>), grid, dim3(256), 0, st, a); \
-                         else if (MD == 1) hipLaunchKernelGGL((wgrad_tr_kernel<TT, 1, true>), grid, dim3(256), 0, st, a); \
-                         else hipLaunchKernelGGL((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)
+#define URSO_WGP(TT, MD) do { if (MD == 0) URSO_KLAUNCH((wgrad_tr_kernel<TT, 0, true>), grid, dim3(256), 0, st, a); \
+                         else if (MD == 1) URSO_KLAUNCH((wgrad_tr_kernel<TT, 1, true>), grid, dim3(256), 0, st, a); \
+                         else URSO_KLAUNCH((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)
     if (!zscat && urso_c3g_fits(g, dt)) {
         int rc3 = urso_c3g_launch(g, dt, x_d, dz_d, a.part, a.colpart, (size_t)p.K * g->N + URSO_WGRAD_PART_PAD, st);
         if (rc3 != URSO_OK) return rc3;
@@ -816,8 +816,8 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
         size_t cnt = (size_t)p.K * g->N;                      // multiple of 4: N % VE == 0
         const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(p.splits);
         int blocks = (int)(((cnt + 3) / 4 + rcols - 1) / rcols);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits, cnt + URSO_WGRAD_PART_PAD);
-        if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
+        URSO_KLAUNCH(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, dw_raw_d, cnt, p.splits, cnt + URSO_WGRAD_PART_PAD);
+        if (colsum_d) URSO_KLAUNCH(reduce_partials_kernel, dim3((int)(((size_t)g->N / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)g->N, p.splits, (size_t)g->N);
         rc = urso_check_launch("urso_conv_wgrad(reduce)");
     }
     return rc;
@@ -852,7 +852,7 @@ extern "C" int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const voi
     int rc = urso_stemw_launch(g, dt, x_d, nullptr, dpool_d, argmax_d, part, colsum_d ? colpart : nullptr, pstride, st);
     if (rc != URSO_OK) return rc;
     const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(splits);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
-    if (colsum_d) hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
+    URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
+    if (colsum_d) URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
     return urso_check_launch("urso_stem_wgrad_pooled(reduce)");
 }

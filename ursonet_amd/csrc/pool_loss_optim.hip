@@ -116,9 +116,9 @@ extern "C" int urso_maxpool3x3s2_fwd(int B, int H, int W, int C, int dt, const v
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
     if (total >= 0x7FFFFFFFull) { urso_set_error("urso_maxpool3x3s2_fwd: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.25 + (double)B * H * W * C / 4);
-    if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)x_d, (float*)y_d, argmax_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)x_d, (__bf16*)y_d, argmax_d);
-    else hipLaunchKernelGGL((maxpool_fwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)x_d, (_Float16*)y_d, argmax_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((maxpool_fwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)x_d, (float*)y_d, argmax_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((maxpool_fwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)x_d, (__bf16*)y_d, argmax_d);
+    else URSO_KLAUNCH((maxpool_fwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)x_d, (_Float16*)y_d, argmax_d);
     return urso_check_launch("urso_maxpool3x3s2_fwd");
 }
 
@@ -130,9 +130,9 @@ extern "C" int urso_maxpool3x3s2_bwd(int B, int H, int W, int C, int dt, const v
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / VE);
     if (total >= 0x7FFFFFFFull) { urso_set_error("urso_maxpool3x3s2_bwd: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     ProfScope ps(st, URSO_K_POOL, 0, (double)B * H * W * C * dt_size(dt) * 1.25 + (double)B * H * W * C / 4);       // dx written, dy + arg-max bytes read
-    if (dt == URSO_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)y_d, (const float*)dy_d, argmax_d, relu_mask, (float*)dx_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)y_d, (const __bf16*)dy_d, argmax_d, relu_mask, (__bf16*)dx_d);
-    else hipLaunchKernelGGL((maxpool_bwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)y_d, (const _Float16*)dy_d, argmax_d, relu_mask, (_Float16*)dx_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((maxpool_bwd_kernel<float>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const float*)y_d, (const float*)dy_d, argmax_d, relu_mask, (float*)dx_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((maxpool_bwd_kernel<__bf16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const __bf16*)y_d, (const __bf16*)dy_d, argmax_d, relu_mask, (__bf16*)dx_d);
+    else URSO_KLAUNCH((maxpool_bwd_kernel<_Float16>), dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, C, (const _Float16*)y_d, (const _Float16*)dy_d, argmax_d, relu_mask, (_Float16*)dx_d);
     return urso_check_launch("urso_maxpool3x3s2_bwd");
 }
 
@@ -196,8 +196,8 @@ extern "C" int urso_softmax_xent_fwd_bwd(int B, int K, const float* logits_d, co
     if (!logits_d || !labels_d || !loss_d || !dz_d || !row_ws_d || B <= 0 || K <= 0) { urso_set_error("urso_softmax_xent_fwd_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, (double)B * K * (8 + dt_size(dt)));
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B), dim3(256), 0, st, K, logits_d, labels_d, weight / (float)B, relu_mask, dt, row_ws_d, dz_d);
-    hipLaunchKernelGGL(mean_scale_kernel, dim3(1), dim3(256), 0, st, B, (const float*)row_ws_d, weight / (float)B, loss_d);
+    URSO_KLAUNCH(softmax_xent_kernel, dim3(B), dim3(256), 0, st, K, logits_d, labels_d, weight / (float)B, relu_mask, dt, row_ws_d, dz_d);
+    URSO_KLAUNCH(mean_scale_kernel, dim3(1), dim3(256), 0, st, B, (const float*)row_ws_d, weight / (float)B, loss_d);
     return urso_check_launch("urso_softmax_xent_fwd_bwd");
 }
 
@@ -225,7 +225,7 @@ extern "C" int urso_rel_l2_fwd_bwd(int B, int D, int ld, const float* gt_d, cons
     if (!gt_d || !pred_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_fwd_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, 0);
-    hipLaunchKernelGGL(rel_l2_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d, norms_d);
+    URSO_KLAUNCH(rel_l2_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d, norms_d);
     return urso_check_launch("urso_rel_l2_fwd_bwd");
 }
 
@@ -258,7 +258,7 @@ extern "C" int urso_rel_l2_norms(int B, int D, int ld, const float* gt_d, const 
     if (!gt_d || !pred_d || !norms_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_norms: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, 0);
-    hipLaunchKernelGGL(rel_l2_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, norms_d);
+    URSO_KLAUNCH(rel_l2_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, norms_d);
     return urso_check_launch("urso_rel_l2_norms");
 }
 extern "C" int urso_rel_l2_from_norms(int B, int D, int ld, const float* gt_d, const float* pred_d, float weight, const float* gscale_d,
@@ -266,7 +266,7 @@ extern "C" int urso_rel_l2_from_norms(int B, int D, int ld, const float* gt_d, c
     if (!gt_d || !pred_d || !gscale_d || !norms_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_rel_l2_from_norms: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, 0);
-    hipLaunchKernelGGL(rel_l2_from_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, gscale_d, dt, norms_d, loss_d, dpred_d);
+    URSO_KLAUNCH(rel_l2_from_norms_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, gscale_d, dt, norms_d, loss_d, dpred_d);
     return urso_check_launch("urso_rel_l2_from_norms");
 }
 
@@ -303,7 +303,7 @@ extern "C" int urso_absdot_fwd_bwd(int B, int D, int ld, int normalize, const fl
     if (!x_d || B <= 0 || D <= 0 || ld < D || (gt_d && (!loss_d || !dx_d))) { urso_set_error("urso_absdot_fwd_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, 0);
-    hipLaunchKernelGGL(absdot_kernel, dim3(1), dim3(256), 0, st, B, D, ld, normalize, gt_d, x_d, weight, dt, q_d, loss_d, dx_d);
+    URSO_KLAUNCH(absdot_kernel, dim3(1), dim3(256), 0, st, B, D, ld, normalize, gt_d, x_d, weight, dt, q_d, loss_d, dx_d);
     return urso_check_launch("urso_absdot_fwd_bwd");
 }
 
@@ -327,7 +327,7 @@ extern "C" int urso_mse_fwd_bwd(int B, int D, int ld, const float* gt_d, const f
     if (!gt_d || !pred_d || !loss_d || !dpred_d || B <= 0 || D <= 0 || ld < D) { urso_set_error("urso_mse_fwd_bwd: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_LOSS, 0, 0);
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d);
+    URSO_KLAUNCH(mse_kernel, dim3(1), dim3(256), 0, st, B, D, ld, gt_d, pred_d, weight, dt, loss_d, dpred_d);
     return urso_check_launch("urso_mse_fwd_bwd");
 }
 
@@ -357,8 +357,8 @@ extern "C" int urso_sqnorm(size_t n, const float* g_d, void* ws_d, size_t ws_byt
     if (((uintptr_t)g_d) & 15) { urso_set_error("urso_sqnorm: gradient buffer must be 16-byte aligned"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 4);
-    hipLaunchKernelGGL(sqnorm_part_kernel, dim3(SQN_BLOCKS), dim3(256), 0, st, n, g_d, (float*)ws_d);
-    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, SQN_BLOCKS, (const float*)ws_d, out_d);
+    URSO_KLAUNCH(sqnorm_part_kernel, dim3(SQN_BLOCKS), dim3(256), 0, st, n, g_d, (float*)ws_d);
+    URSO_KLAUNCH(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, SQN_BLOCKS, (const float*)ws_d, out_d);
     return urso_check_launch("urso_sqnorm");
 }
 
@@ -383,7 +383,7 @@ extern "C" int urso_sgd_momentum_clip(size_t n, float* w_d, const float* g_d, fl
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 20);
     size_t blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, v_d, hyper_d, normsq_d);
+    URSO_KLAUNCH(sgd_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, v_d, hyper_d, normsq_d);
     return urso_check_launch("urso_sgd_momentum_clip");
 }
 
@@ -412,9 +412,9 @@ extern "C" int urso_adam_amsgrad_clip(size_t n, float* w_d, const float* g_d, fl
     if (!w_d || !g_d || !m_d || !v_d || !vhat_d || !hyper_d || !normsq_d) { urso_set_error("urso_adam_amsgrad_clip: null argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 36);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, hyper_d);
+    URSO_KLAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, st, hyper_d);
     size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, m_d, v_d, vhat_d, (const float*)hyper_d, normsq_d);
+    URSO_KLAUNCH(adam_kernel, dim3((int)blocks), dim3(256), 0, st, n, w_d, g_d, m_d, v_d, vhat_d, (const float*)hyper_d, normsq_d);
     return urso_check_launch("urso_adam_amsgrad_clip");
 }
 
@@ -426,7 +426,7 @@ extern "C" int urso_scale_f32(size_t n, float* x_d, float s, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 8);
-    hipLaunchKernelGGL(scale_kernel, dim3((int)blocks), dim3(256), 0, st, n, x_d, s);
+    URSO_KLAUNCH(scale_kernel, dim3((int)blocks), dim3(256), 0, st, n, x_d, s);
     return urso_check_launch("urso_scale_f32");
 }
 
@@ -493,7 +493,7 @@ extern "C" int urso_quat_wavg_decode(int B, int K, const float* logits_d, const 
     if (((uintptr_t)hquat_d) & 15) { urso_set_error("urso_quat_wavg_decode: hquat must be 16-byte aligned"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_DECODE, 0, (double)B * K * 4 + (double)K * 16);
-    hipLaunchKernelGGL(quat_wavg_kernel, dim3(B), dim3(256), 0, st, K, logits_d, hquat_d, q_d, a_d);
+    URSO_KLAUNCH(quat_wavg_kernel, dim3(B), dim3(256), 0, st, K, logits_d, hquat_d, q_d, a_d);
     return urso_check_launch("urso_quat_wavg_decode");
 }
 
@@ -518,7 +518,7 @@ extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const vo
     if (total >= 0x7FFFFFFFull) { urso_set_error("urso_rows_subsample2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_POOL, 0, (double)total * 32);
-    hipLaunchKernelGGL(subsample2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
+    URSO_KLAUNCH(subsample2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
     return urso_check_launch("urso_rows_subsample2");
 }
 
@@ -531,6 +531,6 @@ extern "C" int urso_rows_expand2(int B, int H, int W, int row_bytes, const void*
     if (total >= 0x7FFFFFFFull) { urso_set_error("urso_rows_expand2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_POOL, 0, (double)total * 16 * 1.25);
-    hipLaunchKernelGGL(expand2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
+    URSO_KLAUNCH(expand2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
     return urso_check_launch("urso_rows_expand2");
 }

@@ -132,9 +132,9 @@ extern "C" int urso_conv_weight_prep(int KH, int KW, int C, int N, int npad, int
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ceil_div(C, 32), ceil_div(npad, 32), KH * KW);
     ProfScope ps(st, URSO_K_PREP, 0, (double)KH * KW * C * N * (4 + 2 * dt_size(dt)));
-    if (dt == URSO_F32) hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((weight_prep_kernel<__bf16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
-    else if (dt == URSO_F16) hipLaunchKernelGGL((weight_prep_kernel<_Float16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((weight_prep_kernel<float>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((weight_prep_kernel<__bf16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
+    else if (dt == URSO_F16) URSO_KLAUNCH((weight_prep_kernel<_Float16>), grid, dim3(256), 0, st, KH, KW, C, N, npad, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, wd_d, biasf_d, scale_d);
     else { urso_set_error("urso_conv_weight_prep: bad dtype"); return URSO_EINVAL; }
     return urso_check_launch("urso_conv_weight_prep");
 }
@@ -170,9 +170,9 @@ extern "C" int urso_stem_weight_pack(int N, int dt, const float* w_d, const floa
     hipStream_t st = (hipStream_t)stream;
     const int total = N * 224, blocks = ceil_div(total, 256);
     ProfScope ps(st, URSO_K_PREP, 0, 0);
-    if (dt == URSO_F32) hipLaunchKernelGGL((stem_pack_kernel<float>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((stem_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
-    else if (dt == URSO_F16) hipLaunchKernelGGL((stem_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((stem_pack_kernel<float>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((stem_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
+    else if (dt == URSO_F16) URSO_KLAUNCH((stem_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, N, w_d, b_d, gamma_d, beta_d, mean_d, var_d, eps, wf_d, biasf_d, scale_d);
     else { urso_set_error("urso_stem_weight_pack: bad dtype"); return URSO_EINVAL; }
     return urso_check_launch("urso_stem_weight_pack");
 }
@@ -189,7 +189,7 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
     if (!dw_packed_d || !dw_raw_d || N <= 0) { urso_set_error("urso_stem_wgrad_unpack: bad argument"); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
-    hipLaunchKernelGGL(stem_unpack_kernel, dim3(ceil_div(147 * N, 256)), dim3(256), 0, st, N, dw_packed_d, dw_raw_d);
+    URSO_KLAUNCH(stem_unpack_kernel, dim3(ceil_div(147 * N, 256)), dim3(256), 0, st, N, dw_packed_d, dw_raw_d);
     return urso_check_launch("urso_stem_wgrad_unpack");
 }
 
@@ -320,9 +320,9 @@ extern "C" int urso_param_grad_finalize(int K, int N, int ldn, const float* dw_r
     const int ks = finalize_ks(K, N), kb = ceil_div(K, ks);
     const float regc = 2.0f * weight_decay / ((float)K * (float)N), regb = 2.0f * weight_decay / (float)N;
     ProfScope ps(st, URSO_K_FINALIZE, 0, (double)K * N * 12);
-    hipLaunchKernelGGL(finalize_mat_kernel, dim3(ceil_div(N, 64), ks), dim3(256), 0, st, K, N, ldn, kb, dw_raw_d, w_d, gamma_d, var_d, eps, regc, trainable, gw_d, ws_d);
+    URSO_KLAUNCH(finalize_mat_kernel, dim3(ceil_div(N, 64), ks), dim3(256), 0, st, K, N, ldn, kb, dw_raw_d, w_d, gamma_d, var_d, eps, regc, trainable, gw_d, ws_d);
     if (gb_d || ggamma_d)
-        hipLaunchKernelGGL(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d);
+        URSO_KLAUNCH(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d);
     return urso_check_launch("urso_param_grad_finalize");
 }
 
@@ -376,16 +376,16 @@ extern "C" int urso_param_batch_run(int phase, int dt, const urso_param_desc* de
     switch (phase) {
     case URSO_PB_PREP: {
         ProfScope ps(st, URSO_K_PREP, 0, 0);
-        if (dt == URSO_F32) hipLaunchKernelGGL((weight_prep_batch_kernel<float>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
-        else if (dt == URSO_BF16) hipLaunchKernelGGL((weight_prep_batch_kernel<__bf16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
-        else if (dt == URSO_F16) hipLaunchKernelGGL((weight_prep_batch_kernel<_Float16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        if (dt == URSO_F32) URSO_KLAUNCH((weight_prep_batch_kernel<float>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        else if (dt == URSO_BF16) URSO_KLAUNCH((weight_prep_batch_kernel<__bf16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
+        else if (dt == URSO_F16) URSO_KLAUNCH((weight_prep_batch_kernel<_Float16>), dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d);
         else { urso_set_error("urso_param_batch_run: bad dtype"); return URSO_EINVAL; }
         break; }
     case URSO_PB_REDUCE: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0); urso_reduce_partials_batch_launch(descs_d, blockmap_d, nblocks, st); break; }
     case URSO_PB_FINALIZE_MAT: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
-        hipLaunchKernelGGL(finalize_mat_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+        URSO_KLAUNCH(finalize_mat_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
     case URSO_PB_FINALIZE_VEC: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
-        hipLaunchKernelGGL(finalize_vec_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+        URSO_KLAUNCH(finalize_vec_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
     default: urso_set_error("urso_param_batch_run: bad phase"); return URSO_EINVAL;
     }
     return urso_check_launch("urso_param_batch_run");
@@ -413,9 +413,9 @@ extern "C" int urso_mold_images(int B, int H, int W, int src_is_u8, const void* 
     const size_t npix = (size_t)B * H * W;
     int blocks = (int)((npix + 255) / 256); if (blocks > 4096) blocks = 4096;
     ProfScope ps(st, URSO_K_MOLD, 0, (double)npix * ((src_is_u8 ? 3 : 12) + 4 * dt_size(dt)));
-    if (dt == URSO_F32) hipLaunchKernelGGL((mold_kernel<float>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
-    else if (dt == URSO_BF16) hipLaunchKernelGGL((mold_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
-    else if (dt == URSO_F16) hipLaunchKernelGGL((mold_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    if (dt == URSO_F32) URSO_KLAUNCH((mold_kernel<float>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    else if (dt == URSO_BF16) URSO_KLAUNCH((mold_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
+    else if (dt == URSO_F16) URSO_KLAUNCH((mold_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, npix, src_is_u8, src_d, mean3_d, dst_d);
     else { urso_set_error("urso_mold_images: bad dtype"); return URSO_EINVAL; }
     return urso_check_launch("urso_mold_images");
 }

@@ -19,7 +19,7 @@ int urso_check_launch(const char* what) {
 }
 
 extern "C" const char* urso_last_error(void) { return g_err; }
-extern "C" int urso_abi_version(void) { return 6; }
+extern "C" int urso_abi_version(void) { return 7; }
 
 // ---------------------------------------------------------------- explicit policy options
 UrsoOptions g_urso_opt;
@@ -61,7 +61,7 @@ extern "C" int urso_get_option(const char* name, int* value) {
 }
 
 // ---------------------------------------------------------------- profiler
-struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; const void* fn; hipStream_t st; int nl; bool open; };
 static std::mutex g_pmu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
@@ -75,20 +75,48 @@ static hipEvent_t get_event() {
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
-    ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event();
+    ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event(); r.fn = nullptr; r.st = s; r.nl = 0; r.open = true;
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
 void urso_prof_after(hipStream_t s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
-    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
+    if (!g_recs.empty()) { (void)hipEventRecord(g_recs.back().e1, s); g_recs.back().open = false; }
+}
+void urso_prof_symbol(const void* host_fn) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pmu);
+    if (g_recs.empty() || !g_recs.back().open) return;           // a launch outside any profiled entry point
+    ProfRec& r = g_recs.back();
+    if (!r.fn) r.fn = host_fn;                                    // the first kernel of the call names it (a split-K finish or a reduction follows it)
+    ++r.nl;
 }
 
 extern "C" int urso_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_pmu);
     g_prof_on = on != 0;
     return URSO_OK;
+}
+
+extern "C" int urso_prof_collect_ex(urso_prof_record_ex* out, int max_records) {
+    std::lock_guard<std::mutex> lk(g_pmu);
+    int n = 0;
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (out && n < max_records) {
+            urso_prof_record_ex& o = out[n];
+            o.kernel_id = r.id; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.n_launches = r.nl;
+            const char* nm = r.fn ? hipKernelNameRefByPtr(r.fn, r.st) : nullptr;
+            snprintf(o.symbol, sizeof(o.symbol), "%s", nm ? nm : "");
+            ++n;
+        }
+        g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+    return n;
 }
 
 extern "C" int urso_prof_collect(urso_prof_record* out, int max_records) {

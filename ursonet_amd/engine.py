@@ -893,7 +893,7 @@ class Engine(object):
 
     def profile_step(self):
         """One eager training step with the library's HIP-event launch profiler on.
-        Returns [(label, kernel_id, ms, flops, bytes)] in launch order."""
+        Returns [(label, kernel_id, ms, flops, bytes, n_kernels, device_symbol)] in launch order."""
         labels = (self.labels["prep"] + self.labels["fwd"] + ["loss"] * (len(self.loss_pre_ops) + len(self.loss_ops)) +
                   [l for l in self.labels["bwd"] if l is not None] + self.labels["opt"])
         torch.cuda.synchronize(self.device)
@@ -902,7 +902,7 @@ class Engine(object):
         try:
             self.step_eager()
             torch.cuda.synchronize(self.device)
-            recs = hip.prof_collect()
+            recs = hip.prof_collect_ex()
         finally:
             hip.prof_enable(False)
         assert len(recs) == len(labels), (len(recs), len(labels))

@@ -36,6 +36,11 @@ class ProfRecord(C.Structure):
     _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+class ProfRecordEx(C.Structure):
+    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double), ("n_launches", C.c_int32),
+                ("symbol", C.c_char * 236)]
+
+
 class UrsoHipError(RuntimeError):
     pass
 
@@ -129,6 +134,7 @@ _SIGS = {
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_prof_enable": (_i, [_i]),
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
+    "urso_prof_collect_ex": (_i, [C.POINTER(ProfRecordEx), _i]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 for _name, (_res, _args) in _SIGS.items():
@@ -513,6 +519,14 @@ def prof_collect(max_records=65536):
     buf = (ProfRecord * max_records)()
     n = _lib.urso_prof_collect(buf, max_records)
     return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes) for i in range(n)]
+
+
+def prof_collect_ex(max_records=65536):
+    """[(kernel_id, ms, flops, bytes, n_launches, symbol)]: symbol = the device symbol of the first kernel the call launched
+    (hipKernelNameRefByPtr: what rocprofv3 --kernel-trace prints)."""
+    buf = (ProfRecordEx * max_records)()
+    n = _lib.urso_prof_collect_ex(buf, max_records)
+    return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes, buf[i].n_launches, buf[i].symbol.decode(errors="replace")) for i in range(n)]
 
 
 COMM_ID_BYTES = 128
