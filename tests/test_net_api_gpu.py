@@ -184,3 +184,23 @@ def test_keras_h5_weight_files_through_a_stand_in_h5py(tmp_path, monkeypatch):
     m2.load_weights(path, path, by_name=True)
     w2 = m2._engine.get_weights()
     assert all(np.array_equal(w2[l][w], w0[l][w]) for l in w0 for w in w0[l])
+
+
+def test_train_with_rotation_and_sim2real_augmentation_while_the_graph_is_captured(tmp_path):
+    """UrsoNet.train() starts the feeders before set_trainable() / compile() reset the step graph, so the first eng.step() captures a
+    hipGraph while the producer threads run the augmentation third of load_image_gt ON THE GPU (ROT_AUG warp + re-encode kernels,
+    SIM2REAL stages, device-to-host copies, pinned allocations).  HIP refuses such calls from any thread during a global-mode capture:
+    the producers and the capture exclude each other through hip.capture_lock.  Several capture rounds (set_trainable
+    between epochs rebuilds the plan) with both augmentations on; losses stay finite and descend."""
+    from ursonet_amd import net
+    from ursonet_amd.dataset import SyntheticPoses
+    cfg = make_config("resnet18", 64, 128, batch=4, regress_ori=False, ori_bins=4, dtype="float32", lr=0.01)
+    cfg.NAME = "aug"
+    cfg.ROT_AUG, cfg.SIM2REAL_AUG = True, True
+    cfg.STEPS_PER_EPOCH, cfg.VALIDATION_STEPS = 5, 1
+    ds_train, ds_val = SyntheticPoses(16, 64, 128, cfg, seed=1), SyntheticPoses(8, 64, 128, cfg, seed=2)
+    model = net.UrsoNet(mode="training", config=cfg, model_dir=str(tmp_path))
+    for layers in ("heads", "all", "4+"):                # each call rebuilds the plan and captures again with the feeders running
+        hist = model.train(ds_train, ds_val, learning_rate=cfg.LEARNING_RATE, epochs=model.epoch + 1, layers=layers)
+        assert len(hist.ori_loss_acc) == 5 and np.isfinite(hist.ori_loss_acc).all() and np.isfinite(hist.loc_loss_acc).all()
+    assert model.epoch == 3

@@ -164,11 +164,17 @@ def rotate_image(image, t, q, K):
 SIM2REAL_OPS = ("noise", "blur", "add", "multiply", "dropout")
 
 
-def sim2real_draw(n, height, width, rng=np.random):
-    """The random decisions of the reference's sim2real branch for `n` samples, drawn sample by sample from `rng` (NumPy's global
-    generator by default, like net.py:395 and imgaug's seeding from it): whether the pipeline runs (p = 0.5), the random order of its
-    five stages and each stage's parameter -- AdditiveGaussianNoise(scale=0.01*255), GaussianBlur(sigma=(0, 1.5)), Add((-20, 20)),
-    Multiply((0.5, 2.0)), CoarseDropout([0.0, 0.03], size_percent=(0.02, 0.1)).  Returns a dict of arrays."""
+_PIPELINE_RNG = np.random.RandomState()      # stands for imgaug's own generator: the stage parameters never consume NumPy's global stream
+
+
+def sim2real_draw(n, height, width, rng=np.random, prng=None):
+    """The random decisions of the reference's sim2real branch for `n` samples, sample by sample: whether the pipeline runs (p = 0.5)
+    from `rng` (NumPy's global generator by default: net.py:395 `np.random.rand(1) > 0.5`), and -- only for the samples it runs on, as
+    imgaug draws when `to_deterministic()` is called (net.py:405) -- the random order of its five stages and each stage's parameter
+    from `prng` (imgaug's own generator in the reference, not NumPy's global stream; default: the same generator as `rng`, which the
+    distribution tests seed): AdditiveGaussianNoise(scale=0.01*255), GaussianBlur(sigma=(0, 1.5)), Add((-20, 20)), Multiply((0.5, 2.0)),
+    CoarseDropout([0.0, 0.03], size_percent=(0.02, 0.1)).  Returns a dict of arrays."""
+    prng = rng if prng is None else prng
     apply = np.zeros(n, dtype=bool)
     order = np.tile(np.arange(5), (n, 1))
     par = np.zeros((n, 5, 4), dtype=np.float32)
@@ -176,17 +182,21 @@ def sim2real_draw(n, height, width, rng=np.random):
     masks = []
     for i in range(n):
         apply[i] = rng.rand(1)[0] > 0.5
-        order[i] = rng.permutation(5)
         par[i, 0, 0] = 0.01 * 255
-        par[i, 1, 0] = rng.uniform(0.0, 1.5)
-        par[i, 2, 0] = float(rng.randint(-20, 21))
-        par[i, 3, 0] = rng.uniform(0.5, 2.0)
-        p = (0.0, 0.03)[rng.randint(0, 2)]                  # a LIST of two values is a choice in imgaug, not a range
-        sp = rng.uniform(0.02, 0.1)
+        par[i, 4, 0], par[i, 4, 1] = 1, 1
+        if not apply[i]:
+            masks.append(np.zeros((1, 1), dtype=bool))
+            continue
+        order[i] = prng.permutation(5)
+        par[i, 1, 0] = prng.uniform(0.0, 1.5)
+        par[i, 2, 0] = float(prng.randint(-20, 21))
+        par[i, 3, 0] = prng.uniform(0.5, 2.0)
+        p = (0.0, 0.03)[prng.randint(0, 2)]                  # a LIST of two values is a choice in imgaug, not a range
+        sp = prng.uniform(0.02, 0.1)
         dh, dw = max(int(height * sp), 1), max(int(width * sp), 1)
         par[i, 4, 0], par[i, 4, 1] = dh, dw
-        masks.append(rng.rand(dh, dw) < p)
-        seeds[i] = rng.randint(0, 2 ** 31 - 1)
+        masks.append(prng.rand(dh, dw) < p)
+        seeds[i] = prng.randint(0, 2 ** 31 - 1)
     return {"apply": apply, "order": order, "par": par, "seeds": seeds, "masks": masks}
 
 

@@ -310,15 +310,18 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
             if (tid_e == 0) __hip_atomic_store(a.flags + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (!tile_done) {
             // ---- the tile continues in the following run(s): add their accumulators in run order (fixed order: deterministic).  Those
-            //      runs BEGIN with their piece of this tile, this run ENDS with its own: the wait is short.  The spin is bounded so that
-            //      a scheduling accident shows up as a wrong result in the tests, never as a hung device
+            //      runs BEGIN with their piece of this tile, this run ENDS with its own: the wait is short.  The spin is bounded (seconds)
+            //      and ends in a trap: a scheduling accident is a loud launch failure, never a hung device and never a silently wrong tile
             const int fin = (tile + 1) * a.nchunks;
             for (int b = lid + 1; b < G && run_begin(b) < fin; ++b) {
                 if (run_begin(b) == run_begin(b + 1)) continue;              // an empty run hands nothing over
                 if (tid_e == 0) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(a.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
+                    while (__hip_atomic_load(a.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24))
                         __builtin_amdgcn_s_sleep(8);
+                    // seconds without the piece arriving: its block was never resident (another kernel holds its CU for good) -- abort the
+                    // launch (the HIP error surfaces at the next call) instead of adding partials that were never written
+                    if (spins >= (1u << 24)) __builtin_trap();
                 }
                 __syncthreads();
                 const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.part + (size_t)b * (512 * 64), 512 * 64 * 4);

@@ -170,7 +170,8 @@ class DataParallelEngine(object):
             total = torch.cuda.get_device_properties(eng.device).multi_processor_count
             usable = max(8, total - self.comm_cus)
             if hip.get_option("cus") != usable:
-                hip.set_option("cus", usable)           # split counts follow it: the plan below must be rebuilt under the new value
+                self._cus_before = hip.get_option("cus")
+                hip.set_option("cus", usable)           # split counts follow it: the plan below must be rebuilt under the new value (process-wide until close())
                 replan = True
         # the last bucket's all-reduce has nothing left to hide behind: cap it (plan_buckets) when ranks really exchange gradients.  On one
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
@@ -183,13 +184,23 @@ class DataParallelEngine(object):
             eng._build_plan()
         self._derive_cuts()
 
+    def close(self):
+        """Give the CUs reserved for the collectives back: option `cus` is process-wide, and an Engine planned after this wrapper is gone
+        would otherwise size its grids for the smaller chip."""
+        if getattr(self, "_cus_before", None) is not None:
+            hip.set_option("cus", self._cus_before)
+            self._cus_before = None
+
     def _derive_cuts(self):
         """Bucket list, reducer and the backward cut points of the engine's CURRENT plan (set_trainable / a bucket-size change
         rebuild the plan: stale cuts would start an all-reduce before its bucket's finalisation ran)."""
         eng, group = self.eng, self.group
         self.plan_version = eng.plan_version
         self.buckets = eng.buckets
+        prev = getattr(self, "reducer", None)
         self.reducer = GradReducer(eng.flat_g, self.buckets, group, compress=self.compress, comm=self.comm)
+        if prev is not None and self.compress and prev.flat_g is eng.flat_g:
+            self.reducer.resid, self.reducer.cbuf = prev.resid, prev.cbuf      # a re-plan (set_trainable) keeps the error-feedback remainder
         # split the backward op list where each bucket becomes complete
         last_op_of_layer = {}
         for i, (tag, _) in enumerate(eng.bwd_ops):
@@ -232,7 +243,7 @@ class DataParallelEngine(object):
         torch.cuda.current_stream(eng.device).wait_stream(side)
         torch.cuda.synchronize(eng.device)
         from .engine import _no_gc
-        with _no_gc():                       # no engine / graph may be garbage-collected while a stream is capturing
+        with hip.capture_lock, _no_gc():     # no engine / graph may be garbage-collected, no feeder thread may enter HIP, while a stream is capturing
             self._capture_graphs(eng, segs, last)
 
     def _capture_graphs(self, eng, segs, last):

@@ -923,7 +923,8 @@ class Engine(object):
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         gr = torch.cuda.CUDAGraph()
-        with _no_gc():                                 # see _no_gc: nothing may be destroyed while the stream is capturing
+        # hip.capture_lock: feeder threads (pinned allocations, augmentation kernels) stay out of HIP while the stream is capturing
+        with hip.capture_lock, _no_gc():               # see _no_gc: nothing may be destroyed while the stream is capturing
             with torch.cuda.graph(gr):
                 if self.mode == "training":
                     self.step_eager()

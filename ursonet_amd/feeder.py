@@ -50,9 +50,11 @@ def load_sample(dataset, config, image_id):
 
 
 def augment_samples(samples, dataset, config):
-    """The augmentation third (net.py:390-438) for a LIST of samples, in place.  Random numbers are drawn from NumPy's global
-    generator sample by sample in the reference's order (sim2real dice, then rotation dice and angles), the pixel work is batched:
-    one sim2real pass set and one warp launch for all samples of the list that need it.  Images come back as uint8 arrays."""
+    """The augmentation third (net.py:390-438) for a LIST of samples, in place.  NumPy's GLOBAL generator is consumed exactly as the
+    reference consumes it, sample by sample: the sim2real dice (net.py:395), then that sample's rotation dice (net.py:415) and angles
+    (utils.py:33 / :62) -- the imgaug stage parameters come from a separate generator, as imgaug's do, and only for the samples the dice
+    select.  The samples themselves are loaded ahead of the draws and the pixel work is batched (one sim2real pass set and one warp
+    launch for all samples of the list that need it), which changes no draw.  Images come back as uint8 arrays."""
     if not samples:
         return samples
     from . import augment
@@ -65,9 +67,11 @@ def augment_samples(samples, dataset, config):
     same_size = all(s.image.shape == samples[0].image.shape for s in samples)
     draws, pyr, warp_ids = None, np.zeros((n, 3)), []
     if config.SIM2REAL_AUG:
-        draws = [augment.sim2real_draw(1, s.image.shape[0], s.image.shape[1]) for s in samples]
-    if rot:
-        for i, s in enumerate(samples):
+        draws = []
+    for i, s in enumerate(samples):
+        if config.SIM2REAL_AUG:
+            draws.append(augment.sim2real_draw(1, s.image.shape[0], s.image.shape[1], prng=augment._PIPELINE_RNG))
+        if rot:
             dice = np.random.rand(1)
             if config.ROT_AUG and dice > 0.5:
                 pyr[i] = (np.random.rand(3) - 0.5) * 20                           # utils.rotate_cam(..., magnitude 20), utils.py:33
@@ -212,16 +216,21 @@ class DeviceFeeder(object):
         self.side = torch.cuda.Stream(device=engine.device)
         self.stage = [None, None]
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [None, None]                           # recorded on the compute stream once a slot's batch has been copied out of it
         self.k = 0
         self.pinned_bytes = 0
         gen = batches(dataset, config, shuffle, engine.B, molded=False, workers=workers)
 
         def produce():
+            from . import hip
             try:
                 while not self.stop:
-                    asm = next(gen)
-                    host = [torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in
-                            ([asm.images, asm.loc] + ([asm.k1, asm.k2] if asm.ori is None else [asm.ori]))]
+                    # everything here may enter HIP (augmentation kernels and device-to-host copies inside the generator, hipHostMalloc
+                    # in pin_memory): not while the consumer thread captures a hipGraph (hip.capture_lock; Engine.capture holds it)
+                    with hip.capture_lock:
+                        asm = next(gen)
+                        host = [torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in
+                                ([asm.images, asm.loc] + ([asm.k1, asm.k2] if asm.ori is None else [asm.ori]))]
                     self.q.put(host)
             except BaseException as e:                         # surfaced by next_into
                 self.err = e
@@ -237,6 +246,8 @@ class DeviceFeeder(object):
             raise self.err
         slot = self.k & 1
         with torch.cuda.stream(self.side):
+            if self.consumed[slot] is not None:
+                self.side.wait_event(self.consumed[slot])      # the engine's copy out of this slot (two batches ago) must have run first
             if self.stage[slot] is None:
                 self.stage[slot] = [torch.empty(h.shape, dtype=h.dtype, device=self.eng.device) for h in host]
             for d, h in zip(self.stage[slot], host):
@@ -252,6 +263,9 @@ class DeviceFeeder(object):
         torch.cuda.current_stream(eng.device).wait_event(self.events[slot])
         st = self.stage[slot]
         eng.load_batch_u8(st[0], st[1], st[2], st[3] if len(st) > 3 else None)
+        if self.consumed[slot] is None:
+            self.consumed[slot] = torch.cuda.Event()
+        self.consumed[slot].record(torch.cuda.current_stream(eng.device))
         self.k += 1
         self._upload()
 

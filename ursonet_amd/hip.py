@@ -36,6 +36,13 @@ class ProfRecord(C.Structure):
     _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+import threading
+# Held while a hipGraph is being captured (Engine.capture, DataParallelEngine.capture) AND by any other thread around its own HIP work
+# (ursonet_amd/feeder.py producers: pinned allocations, augmentation kernels, device-to-host copies): HIP refuses such calls from any
+# thread while a global-mode capture is in progress and may invalidate the capture.
+capture_lock = threading.RLock()
+
+
 class ProfRecordEx(C.Structure):
     _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double), ("n_launches", C.c_int32),
                 ("symbol", C.c_char * 236)]
