@@ -40,6 +40,9 @@ enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
 #define URSO_EPI_OUT_F32   2   /* store fp32 regardless of dt (head outputs)                              */
 #define URSO_EPI_MASK_BITS 4   /* urso_conv_igemm_ex: mask_d is a BIT mask (1 byte per 8 elements of dst) */
 #define URSO_EPI_EMIT_BITS 8   /* urso_conv_igemm_ex: also write the bit mask of (dst > 0) to bits_out_d  */
+#define URSO_EPI_ADD_SRCGRID 16 /* urso_conv_igemm_ex, 1x1 / stride-s / unpadded 16-bit layers: add_d is a [B][H][W][N] tensor on the
+                                   INPUT pixel grid, read at (oy*SH, ox*SW) -- the identity shortcut of a block whose output is only
+                                   ever sampled at stride s (net.py:121-126 reads res{2c,3d,4f}_out through stride-2 1x1 layers) */
 
 const char* urso_last_error(void);
 int         urso_abi_version(void);           /* bumped on any signature or data-format change (6: arg-max bytes of the max-pool carry the ReLU decision in bit 4) */

@@ -1241,3 +1241,40 @@ def test_big_tile_pointwise_kernel_forced(dt, form, shape):
         assert torch.equal(outs[key], outs[(0, 0)]), key
         if emit:
             assert torch.equal(obits[key], obits[(0, 0)]), key
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64, 256, 0), (3, 18, 22, 128, 512, 0), (4, 32, 40, 256, 1024, 8), (32, 128, 160, 64, 256, 0)],
+                         ids=["stage2_small", "stage3_ragged_tiles", "stage4_capped", "stage2_full_size"])
+def test_block_output_computed_at_the_sampled_pixels_only(dt, shape):
+    """urso_conv_igemm_ex with URSO_EPI_ADD_SRCGRID: a block-closing c -> 4c layer (+ identity shortcut, ReLU, emitted ReLU bit mask)
+    evaluated ONLY at the pixels the next stage's stride-2 layers read (net.py:121-126) -- a 1x1 / stride-2 conv whose residual operand
+    lives on the input grid.  Must equal, bit for bit, the even rows / columns of the dense layer's output and of its bit mask."""
+    hip = _hip()
+    B, H, W, c, N, cap = shape
+    if B * H * W * N > 60e6 and dt == 2:
+        pytest.skip("full size: bf16 only")
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(c + dt)
+    x = dev(torch.randn(B, H, W, c), dt)
+    w = torch.randn(1, 1, c, N) / c ** 0.5
+    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(N) * 0.2)
+    res = dev(torch.randn(B, H, W, N), dt)
+    gdense = hip.geom(B, H, W, c, H, W, N, 1, 1)
+    y = torch.empty(B, H, W, N, dtype=tdt, device="cuda")
+    bits = torch.empty(B * H * W * N // 8, dtype=torch.uint8, device="cuda")
+    with hip.options(pair=0, pwx=0):
+        hip.conv_igemm_ex(gdense, dt, hip.EPI_RELU | hip.EPI_EMIT_BITS, x, wf, biasf, res, None, y, bits)
+    gs = hip.geom(B, H, W, c, H // 2, W // 2, N, 1, 1, 2, 2, 0, 0)
+    ys = torch.full((B, H // 2, W // 2, N), 7.0, device="cuda").to(tdt)
+    bs = torch.full((B * (H // 2) * (W // 2) * N // 8,), 0x55, dtype=torch.uint8, device="cuda")
+    with hip.options(grid_cap=cap):
+        hip.conv_igemm_ex(gs, dt, hip.EPI_RELU | hip.EPI_EMIT_BITS | hip.EPI_ADD_SRCGRID, x, wf, biasf, res, None, ys, bs)
+        ys2 = torch.empty_like(ys)
+        hip.conv_igemm_ex(gs, dt, hip.EPI_RELU | hip.EPI_ADD_SRCGRID, x, wf, biasf, res, None, ys2, None)
+    torch.cuda.synchronize()
+    assert torch.equal(ys, y[:, ::2, ::2]) and torch.equal(ys2, ys)
+    assert torch.equal(bs.view(B, H // 2, W // 2, N // 8), bits.view(B, H, W, N // 8)[:, ::2, ::2])
+    assert 0.2 < float((ys.float() > 0).float().mean()) < 0.8
+    with pytest.raises(hip.UrsoHipError):                     # padded / masked forms are refused
+        hip.conv_igemm_ex(gs, dt, hip.EPI_ADD_SRCGRID, x, wf, biasf, res, res, ys, None)

@@ -44,6 +44,20 @@ class ReluDecisions(object):
         c = self.eng.convs[site]
         n = c.node
         B = x.shape[0]
+        if getattr(c.dst, "fwd_sampled", False):
+            # a block output the engine computes only at the pixels its stride-2 consumers read (Engine._sample_block_output): the device's
+            # decisions exist on the even grid; elsewhere nothing depends on the tensor and the oracle keeps its own
+            m = (x.detach() > 0).clone()
+            sub = c.dst.data_compact.float().cpu().view(B, n.dst.h // 2, n.dst.w // 2, c.npad)[..., :n.cout] > 0
+            m[:, :, ::2, ::2] = sub.permute(0, 3, 1, 2)
+            diff = m != (x.detach() > 0)
+            nd = int(diff.sum())
+            if nd:
+                worst = float(x.detach().abs()[diff].max() / (x.detach().abs().max() + 1e-30))
+                assert worst < self.tol, "ReLU decision differs at |pre-activation| = %.2e of max in %s" % (worst, site)
+            self.flips += nd
+            self.total += diff.numel() // 4
+            return m
         dev_act = c.dst.data.float().cpu().view(B, -1)[:, :n.dst.h * n.dst.w * c.npad]
         if x.dim() == 4:
             m = (dev_act.view(B, n.dst.h, n.dst.w, c.npad)[..., :n.cout] > 0).permute(0, 3, 1, 2)
@@ -616,12 +630,13 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
         eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
                     sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l), list(eng.shortcut_folded),
-                    sum(1 for l in eng.labels["fwd"] if l and l.endswith("+sampled"))))
+                    sum(1 for l in eng.labels["fwd"] if l and l.endswith("@sampled")), sum(1 for l in eng.labels["fwd"] if l and l.startswith("subsample:"))))
     assert res[0][5] == ["res2b_branch2a", "res2c_branch2a", "res3b_branch2a", "res3c_branch2a", "res3d_branch2a"] and res[1][5] == []
     # five fused launches forward (plus the stage-2 projection shortcut, computed inside the first of them), five backward
-    # ... and the stage-closing layers write the sampled copy for the next stage's entry layers themselves instead of a gather pass each
-    assert res[0][8] == 3 and res[1][8] == 0
-    assert res[1][0] - res[0][0] == 6 + res[0][8] and res[0][6] == 5 and res[1][6] == 0 and res[0][7] == ["res2a_branch1"] and res[1][7] == []
+    # ... and in BOTH plans the three stage-closing layers are computed at the sampled pixels only (Engine._sample_block_output): they write
+    # the compact tensor the next stage's entry layers read, no gather pass is left
+    assert res[0][8] == 3 and res[1][8] == 3 and res[0][9] == 0 and res[1][9] == 0
+    assert res[1][0] - res[0][0] == 6 and res[0][6] == 5 and res[1][6] == 0 and res[0][7] == ["res2a_branch1"] and res[1][7] == []
     tol_out = 2e-2 if dtype == "bfloat16" else 4e-3                               # the output gate of the oracle comparison above
     eo = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(res[0][2], res[1][2]))
     el = max(abs(res[0][3][k] - res[1][3][k]) / (abs(res[1][3][k]) + 1e-4) for k in res[0][3])
@@ -748,6 +763,7 @@ def test_compact_stage_boundary_gradients_equal_the_dense_path(dtype, monkeypatc
     cfg = make_config("resnet50", 128, 192, batch=2, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-3)
     img, loc, ori, _ = synthetic_batch(cfg, 2, seed=33)
     res = []
+    monkeypatch.setenv("URSO_SAMPLED_OUTPUTS", "0")        # same forward pass in both plans: this test isolates the gradient side (the next one the forward side)
     for mode in ("1", "0"):
         monkeypatch.setenv("URSO_COMPACT_GRAD", mode)
         eng = Engine(cfg, "training", seed=5, randomize_bn=True)
@@ -799,3 +815,32 @@ def test_bench_under_torchrun_with_forced_collectives_one_rank():
                    if wn not in ("moving_mean", "moving_variance"))
     assert sum(d["dp"]["bucket_bytes"]) == 4 * n_params
     assert abs(d["value"] / p["value"] - 1.0) < 0.05, (d["value"], p["value"])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_block_outputs_computed_at_sampled_pixels_change_no_result_bit(dtype, monkeypatch):
+    """Engine._sample_block_output: res{2c,3d,4f}_out are only read through stride-2 layers, so their producing layers run over the even
+    pixels only and the dense tensors / bit masks are never written.  Against the plan that computes them densely (URSO_SAMPLED_OUTPUTS=0),
+    with the layers on the same kernel in both plans (pair = 0: conv_pw.hip), NOTHING observable may change by a single bit: outputs, losses,
+    every gradient, the global norm, the post-step weights and momentum -- over two steps.  Training and inference plans."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 128, 192, batch=2, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-2)
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=41)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("URSO_SAMPLED_OUTPUTS", mode)
+        with hip.options(pair=0):
+            eng = Engine(cfg, "training", seed=5, randomize_bn=True)
+            inf = Engine(cfg, "inference", seed=5, randomize_bn=True)
+            eng.load_batch(img, loc, ori); eng.step(); eng.step(); torch.cuda.synchronize()
+            inf.load_batch(img); inf.forward(); torch.cuda.synchronize()
+        n_s = sum(1 for l in eng.labels["fwd"] if l and l.endswith("@sampled")), sum(1 for l in inf.labels["fwd"] if l and l.endswith("@sampled"))
+        res.append((n_s, [t.clone() for t in eng.outputs()], eng.losses(), eng.flat_g.clone(), eng.flat_w.clone(), eng.flat_v.clone(), float(eng.normsq),
+                    [t.clone() for t in inf.outputs()], sum(1 for l in eng.labels["bwd"] if l == "bits_subsample")))
+    assert res[0][0] == (3, 3) and res[1][0] == (0, 0) and res[0][8] == 0 and res[1][8] == 3
+    a, b = res
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and a[2] == b[2] and a[6] == b[6]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+    assert all(torch.equal(x, y) for x, y in zip(a[7], b[7]))
+    assert float(a[3].abs().max()) > 0 and all(np.isfinite(v) for v in a[2].values())

@@ -396,7 +396,7 @@ static void plan_splitk(int ntiles, int nkt, int ncu, int& S, int& kps) {
 
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
-                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st);      // conv_pw.hip
+                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, int add_src, hipStream_t st);      // conv_pw.hip
 
 bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);                         // conv_pair.hip
 int urso_pair_single_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
@@ -555,7 +555,15 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
         const bool halo_layer = dt != URSO_F32 && urso_hconv_fits(g, dt, flags, add_d);      // its workspace is the hand-over one, never split-K's
         const bool split = ws_d && !halo_layer && urso_conv_igemm_ws_bytes(g, dt) != 0 && urso_conv_igemm_ws_bytes(g, dt) <= ws_bytes;
         const bool wants_bits = (flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) != 0;
-        const bool bits_fit = !wants_bits || (a.pointwise && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&
+        // a strided, unpadded 1x1 layer (a block output that is only ever sampled: URSO_EPI_ADD_SRCGRID) may emit its bit mask as well
+        const bool s1x1 = g->KH == 1 && g->KW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 && g->FH <= 0;
+        const bool add_src = (flags & URSO_EPI_ADD_SRCGRID) != 0;
+        if (add_src && (!add_d || !s1x1 || dt == URSO_F32 || mask_d || (flags & (URSO_EPI_OUT_F32 | URSO_EPI_MASK_BITS)) || (a.Cc & 7) || (g->N % 8) ||
+                        (g->OH - 1) * g->SH >= g->H || (g->OW - 1) * g->SW >= g->W || use_pw < 2 || (size_t)g->B * g->H * g->W * g->N * es >= 0x7FFFFF00ull)) {
+            urso_set_error("urso_conv_igemm: ADD_SRCGRID needs a 16-bit unpadded 1x1 layer with C %% 64 == 0, a residual operand on the input grid and no mask");
+            return URSO_EINVAL;
+        }
+        const bool bits_fit = !wants_bits || ((a.pointwise || (s1x1 && !(flags & URSO_EPI_MASK_BITS) && (a.Cc & 7) == 0)) && !((flags & URSO_EPI_EMIT_BITS) && (mask_d || (g->N % 32))) &&
                                               !((flags & URSO_EPI_MASK_BITS) && (!mask_d || (g->N % 32))) && !((flags & URSO_EPI_EMIT_BITS) && !bits_out_d));
         const bool fits = dt != URSO_F32 && !(flags & URSO_EPI_OUT_F32) && bits_fit && (g->N % 8) == 0 &&
                           !split && (size_t)a.M < (1u << 24);
@@ -577,10 +585,11 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
             return urso_stem_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, dst_d, st);
         if (fits && !wants_bits && use_pw >= 3 && stem_ok)
             return urso_pw_launch(g, dt, 2, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
-                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, 0, nullptr, st);
-        if (fits && ((use_pw >= 1 && a.pointwise && (a.Cc & 7) == 0) || (use_pw >= 2 && taps_ok && !wants_bits)))
+                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, 0, nullptr, 0, st);
+        if (add_src && !fits) { urso_set_error("urso_conv_igemm: ADD_SRCGRID layer does not fit the DMA kernel (split-K workspace given, M >= 2^24 ...)"); return URSO_EINVAL; }
+        if (fits && ((use_pw >= 1 && a.pointwise && (a.Cc & 7) == 0) || (use_pw >= 2 && taps_ok && (!wants_bits || s1x1))))
             return urso_pw_launch(g, dt, a.pointwise ? 0 : 1, dhs, dws, (flags & URSO_EPI_RELU) ? 1 : 0,
-                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, mbits, bout, st);
+                                  src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, mbits, bout, add_src, st);
     }
     if (dt == URSO_F32) return launch_igemm<float>(g, flags, a, ws_d, ws_bytes, st);
     if (dt == URSO_BF16) return launch_igemm<__bf16>(g, flags, a, ws_d, ws_bytes, st);

@@ -23,6 +23,7 @@ struct PwArgs {
     int relu;
     void* bits_out;                    // EMIT: ReLU bit mask of the stored output (1 byte per 16-byte vector)
     int H, W, KH, KW, SH, SW, PH, PW, DHs, DWs;   // CONV: general source mapping (conv_igemm.hip), Cc % 8 == 0 so a K-tile never straddles taps
+    int add_src; uint32_t add_bytes;   // URSO_EPI_ADD_SRCGRID: the residual operand is a [B][H][W][N] tensor read at (oy*SH, ox*SW)
 };
 
 __device__ __forceinline__ void pw_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
 
     const i32x4_t rs = pw_rsrc(a.src, a.src_bytes), rw = pw_rsrc(a.wgt, a.wgt_bytes);
     const __amdgpu_buffer_rsrc_t rbi = make_rsrc(a.bias ? (const void*)a.bias : a.dst, a.bias ? (uint32_t)a.N * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.add ? a.add : a.dst, a.add ? (a.add_src ? a.add_bytes : a.dst_bytes) : 0u);
     const __amdgpu_buffer_rsrc_t rmk = make_rsrc(a.mask ? a.mask : a.dst, a.mask ? (MASKK == 2 ? a.dst_bytes / 16u : a.dst_bytes) : 0u);
     const __amdgpu_buffer_rsrc_t rmo = make_rsrc(EMIT ? a.bits_out : a.dst, EMIT ? a.dst_bytes / 16u : 0u);
     const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
@@ -169,16 +170,23 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
     };
 
     // ---- epilogue geometry of a tile: byte offset of vector v of pixel sub-tile i (OOB when outside the tensor)
-    auto tile_offs = [&](int ts, uint32_t (&eo)[TM]) {          // row base offsets (channel nb + 0); vector v adds v*4*VE*2 bytes
+    auto tile_offs = [&](int ts, uint32_t (&eo)[TM], uint32_t (&ea)[HAS_ADD ? TM : 1]) {    // row base offsets (channel nb + 0); vector v adds v*4*VE*2 bytes
         const int m0 = (ts / a.tilesN) * BM, n0 = (ts % a.tilesN) * BN;
         const int nb = n0 + wn * WN + fg * VE;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * WM + i * 16 + fr;
-            int dp = m;
-            if (a.FH != 0 && m < a.M) { int b, rem, oy, ox; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
-                                        dp = (b * a.FH + oy * a.OSH) * a.FW + ox * a.OSW; }
-            eo[i] = (m < a.M && nb < a.N) ? (uint32_t)(((size_t)dp * a.N + nb) * 2) : URSO_OOB_SHIFT;
+            int dp = m, ap = m;
+            if ((a.FH != 0 || (HAS_ADD && a.add_src)) && m < a.M) {
+                int b, rem, oy, ox; divmod(m, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox);
+                if (a.FH != 0) dp = (b * a.FH + oy * a.OSH) * a.FW + ox * a.OSW;
+                if (HAS_ADD && a.add_src) ap = (b * a.H + oy * a.SH) * a.W + ox * a.SW;       // the residual lives on the input grid
+                else ap = dp;
+            }
+            else ap = dp;
+            const bool in = m < a.M && nb < a.N;
+            eo[i] = in ? (uint32_t)(((size_t)dp * a.N + nb) * 2) : URSO_OOB_SHIFT;
+            if constexpr (HAS_ADD) ea[i] = in ? (uint32_t)(((size_t)ap * a.N + nb) * 2) : URSO_OOB_SHIFT;
         }
     };
     // N % 8 == 0 and a lane's vectors are 4*VE channels apart: vector v is inside the tensor iff nb + v*32 < N
@@ -189,14 +197,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
 
     i32x4_t radd[HAS_ADD ? TM * NV : 1], rmsk[HAS_MASK ? TM * NV : 1];
     uint32_t rbit[MASKK == 2 ? TM * NV : 1];
-    uint32_t eo_cur[TM], eo_nxt[TM];
-    tile_offs(tile, eo_cur);
+    uint32_t eo_cur[TM], eo_nxt[TM], ea_cur[HAS_ADD ? TM : 1], ea_nxt[HAS_ADD ? TM : 1];
+    tile_offs(tile, eo_cur, ea_cur);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const uint32_t o = voff(eo_cur[i], tile, v);
-            if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+            if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, voff(ea_cur[i], tile, v));
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
             if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;   // the pixel's 4 lanes read one dword; OOB >> 4 is beyond any bit mask
         }
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
             const int nq = nb + (q / JPV) * 4 * VE + (q % JPV) * 4;
             rbias[q] = buf_load16(rbi, (nq < a.N) ? (uint32_t)nq * 4u : URSO_OOB_SHIFT);
         }
-        if (has_next) tile_offs(next, eo_nxt);
+        if (has_next) tile_offs(next, eo_nxt, ea_nxt);
 
         for (int kt = 0; kt < a.nkt; ++kt) {
             const bool last = (kt + 1 == a.nkt);
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
                 }
                 if (has_next) {                          // this slot's registers are free: request the next tile's vector
                     const uint32_t o = voff(eo_nxt[i], next, v);
-                    if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
+                    if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, voff(ea_nxt[i], next, v));
                     if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
                     if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
                 }
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
         cur ^= 1;
         tile = next;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) eo_cur[i] = eo_nxt[i];
+        for (int i = 0; i < TM; ++i) { eo_cur[i] = eo_nxt[i]; if constexpr (HAS_ADD) ea_cur[i] = ea_nxt[i]; }
     }
 }
 
@@ -361,7 +369,7 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
 // Called by urso_conv_igemm_ex for qualifying geometries (conv_igemm.hip decides); returns URSO_OK after launching.
 int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, int relu,
                    const void* src, const void* wgt, const float* bias, const void* add, const void* mask, void* dst,
-                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, hipStream_t st) {
+                   uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out, int add_src, hipStream_t st) {
     if (conv == 0) {                     // the reduction-heavy pointwise layers: 8-wave big-tile kernel (conv_pwx.hip)
         const int rc = urso_pwx_try(g, dt, relu, src, wgt, bias, add, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, bits_out, st);
         if (rc != 0) return rc > 0 ? URSO_OK : rc;
@@ -374,6 +382,7 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     a.OH = g->OH; a.OW = g->OW; a.FH = g->FH > 0 ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
     a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu;
     a.H = g->H; a.W = g->W; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW; a.DHs = dhs; a.DWs = dws;
+    a.add_src = (add && add_src) ? 1 : 0; a.add_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->N * 2);
     const int N = g->N;
     // narrow tile = 48 KiB LDS / <= 154 VGPRs: 3 resident blocks per CU.  Policy 5 (default, measured inside one gpurun call):
     // N <= 64, every filter with more than one tap (MFMA-bound: +0.7 % on the step) and the pointwise layers of stages 4-5
@@ -398,7 +407,9 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
 #define URSO_PW(TT, BN_) do { if (conv) { URSO_PW2(TT, BN_, 1) } else { URSO_PW2(TT, BN_, 0) } } while (0)
     if (mask_bits || bits_out) {         // ReLU bit masks: pointwise layers only (conv_igemm.hip checked): emit = forward with residual, consume = data gradient
 #define URSO_PWB(TT, BN_) do { \
-        if (bits_out) { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, 0, true>), grid, blk, 0, st, a); \
+        if (bits_out && conv) { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, 1, true>), grid, blk, 0, st, a); \
+                                else URSO_KLAUNCH((pw_kernel<TT, BN_, false, 0, 1, true>), grid, blk, 0, st, a); } \
+        else if (bits_out) { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, 0, true>), grid, blk, 0, st, a); \
                         else URSO_KLAUNCH((pw_kernel<TT, BN_, false, 0, 0, true>), grid, blk, 0, st, a); } \
         else { if (add) URSO_KLAUNCH((pw_kernel<TT, BN_, true, 2, 0, false>), grid, blk, 0, st, a); \
                else URSO_KLAUNCH((pw_kernel<TT, BN_, false, 2, 0, false>), grid, blk, 0, st, a); } } while (0)

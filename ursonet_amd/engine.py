@@ -366,6 +366,8 @@ class Engine(object):
         self.out_ori = self.acts[g.outputs["ori"].id] if "ori" in g.outputs else None      # keypoint mode has no orientation head
         self._build_heads_io()
         if not training:
+            for X in list(self.acts.values()):
+                self._sample_block_output(X)
             return
         # ---------------------------------------------------------------- losses + backward
         self.ws = torch.empty(max_ws // 4 + 64, dtype=torch.float32, device=dev)
@@ -539,7 +541,7 @@ class Engine(object):
                 if X.compact is not None:
                     # stride-2 pointwise consumer of a block output whose gradient is kept compact: a plain pointwise GEMM over the
                     # sampled pixels (no scatter, no zero fill of a dense tensor), masked with the sampled rows of X's ReLU bit mask
-                    if not X.grad_written:
+                    if not X.grad_written and not getattr(X, "fwd_sampled", False):       # (a sampled block output wrote the compact mask in its forward pass)
                         self.bwd_ops.append((None, lambda X=X: hip.rows_subsample2(B, X.compact[0], X.compact[1], X.spec.c // 8, X.bits, X.bits_compact)))
                         self.labels["bwd"].append("bits_subsample")
                     self.bwd_ops.append((None, lambda c=c, G=G, X=X, add=(X.grad if X.grad_written else None):
@@ -815,6 +817,50 @@ class Engine(object):
                     Pc.gf_compact = hip.geom(B, H, W, pn.cin, H // 2, W // 2, Pc.npad, pn.kh, pn.kw, 2, 2, pt, pl, FH=H, FW=W, OSH=2, OSW=2)
                     Pc.splits = hip.conv_wgrad_splits(Pc.gf_compact, dt)
                     Pc.desc.splits = max(Pc.splits, 1)
+            self._sample_block_output(X)
+
+    def _sample_block_output(self, X):
+        """A block output that is only ever read through stride-2 pointwise layers (res{2c,3d,4f}_out of ResNet-50: net.py:121-126)
+        is COMPUTED only at the pixels they read: its producing c -> 4c layer runs as a 1x1 / stride-2 layer over the even pixels with
+        the identity shortcut read on the input grid (URSO_EPI_ADD_SRCGRID), writing the compact tensor the consumers take
+        (X.data_compact) and -- training -- the compact ReLU bit mask directly; the dense tensor (335 MB in stage 2 of cfg2) and its bit
+        mask are neither written nor read by anything.  Every value that any output, loss or gradient depends on is computed by the same
+        arithmetic (bit-identical: tests/test_kernels_gpu.py::test_block_output_computed_at_the_sampled_pixels_only); what is skipped
+        is dead.  Needs the compact-gradient plan in training (X.compact) so that the backward pass, too, reads only the compact forms.
+        URSO_SAMPLED_OUTPUTS=0 keeps the dense tensor (e.g. to inspect intermediate activations)."""
+        dt, B = self.dt, self.B
+        if dt == hip.F32 or os.environ.get("URSO_SAMPLED_OUTPUTS", "1") == "0" or getattr(X, "data_compact", None) is None:
+            return
+        convs = list(self.convs.values())
+        prod = [c for c in convs if c.dst is X]
+        cons = [c for c in convs if c.src is X]
+        if len(prod) != 1 or not cons or any(c.res is X for c in convs) or any(c.xin is not X.data_compact for c in cons):
+            return
+        if any(n.op == "pool" and n.src.id == X.spec.id for n in self.graph.nodes) or any(t.id == X.spec.id for t in self.graph.outputs.values()):
+            return
+        A = prod[0]
+        n = A.node
+        training = self.mode == "training"
+        if (n.stem or n.dense or n.kh != 1 or n.kw != 1 or n.stride != 1 or A.batch_bn or not hasattr(A, "fwd_index") or n.cin % 64 or A.npad % 32 or
+                A.npad != A.N or X.spec.h % 2 or X.spec.w % 2 or (A.res is not None and A.res.numel != X.numel)):
+            return
+        if training and (X.compact is None or X.bits is None or getattr(X, "bits_compact", None) is None):
+            return                                    # the backward pass would read the dense tensor / bit mask
+        H, W = X.spec.h, X.spec.w
+        gs = hip.geom(B, H, W, n.cin, H // 2, W // 2, A.npad, 1, 1, 2, 2, 0, 0)
+        flags = A.fwd_flags | (hip.EPI_ADD_SRCGRID if A.res is not None else 0) | (hip.EPI_EMIT_BITS if training else 0)
+        # (fwd_index goes stale once the pair fusion has dropped launches: the layer's launch is found by its label)
+        idx = [i for i, lab in enumerate(self.labels["fwd"]) if lab in ("fwd:%s" % A.name, "fwd:%s+sampled" % A.name)]
+        if len(idx) != 1:
+            return
+        self.fwd_ops[idx[0]] = (lambda A=A, X=X, gs=gs, flags=flags: hip.conv_igemm_ex(
+            gs, dt, flags, A.xin, A.wf, A.biasf, A.res.data if A.res is not None else None, None, X.data_compact,
+            X.bits_compact if (flags & hip.EPI_EMIT_BITS) else None))
+        self.labels["fwd"][idx[0]] = "fwd:%s@sampled" % A.name
+        gather = [i for i, lab in enumerate(self.labels["fwd"]) if lab == "subsample:T%d" % X.spec.id]
+        for i in reversed(gather):                   # the gather pass that filled X.data_compact from the dense tensor (plans without the
+            del self.fwd_ops[i]; del self.labels["fwd"][i]      # register-filter kernel's second store) has nothing to read any more
+        X.fwd_sampled = True
 
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly

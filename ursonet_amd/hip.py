@@ -13,7 +13,7 @@ _VARIANT = os.environ.get("URSO_LIB_VARIANT", "")        # kernel experiments: s
 LIB_PATH = os.path.join(_HERE, "lib", "liburso_hip%s.so" % (("_" + _VARIANT) if _VARIANT else ""))
 
 F32, BF16, F16 = 0, 1, 2
-EPI_RELU, EPI_OUT_F32, EPI_MASK_BITS, EPI_EMIT_BITS = 1, 2, 4, 8
+EPI_RELU, EPI_OUT_F32, EPI_MASK_BITS, EPI_EMIT_BITS, EPI_ADD_SRCGRID = 1, 2, 4, 8, 16
 K_IGEMM, K_WGRAD, K_PREP, K_FINALIZE, K_POOL, K_LOSS, K_OPTIM, K_DECODE, K_MOLD = range(1, 10)
 KERNEL_NAMES = {K_IGEMM: "conv_igemm", K_WGRAD: "conv_wgrad", K_PREP: "weight_prep", K_FINALIZE: "param_grad_finalize",
                 K_POOL: "maxpool", K_LOSS: "loss", K_OPTIM: "optimizer", K_DECODE: "quat_decode", K_MOLD: "mold"}
