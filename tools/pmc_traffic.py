@@ -11,7 +11,8 @@ def load(path, counter):
     tot = collections.defaultdict(float); n = collections.defaultdict(int)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            tot[r["Kernel_Name"]] += float(r["Counter_Value"]); n[r["Kernel_Name"]] += 1
+            k = r["Kernel_Name"][:-3] if r["Kernel_Name"].endswith(".kd") else r["Kernel_Name"]     # rocprofv3 -M prints the kernel DESCRIPTOR symbol (<name>.kd)
+            tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
 
