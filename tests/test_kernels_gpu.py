@@ -1278,3 +1278,32 @@ def test_block_output_computed_at_the_sampled_pixels_only(dt, shape):
     assert 0.2 < float((ys.float() > 0).float().mean()) < 0.8
     with pytest.raises(hip.UrsoHipError):                     # padded / masked forms are refused
         hip.conv_igemm_ex(gs, dt, hip.EPI_ADD_SRCGRID, x, wf, biasf, res, res, ys, None)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64, 0), (3, 18, 22, 128, 0), (4, 32, 40, 256, 8), (8, 64, 80, 128, 0)],
+                         ids=["c64", "c128_ragged_tiles", "c256_capped", "stage3_rows"])
+def test_3x3_layer_computed_at_the_even_pixels_and_scattered(dt, shape):
+    """The 3x3 layer below a sampled block output (Engine._sample_layer_below): a 3x3 / stride-2 / pad-1 conv whose results go to the
+    even pixels of the dense output buffer (destination scatter).  Even pixels: bit for bit the dense layer on the same kernel
+    (conv_pw.hip; c3 = 0, hconv = 0); the other pixels of the buffer are left untouched."""
+    hip = _hip()
+    B, H, W, c, cap = shape
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(c + dt)
+    x = dev(torch.relu(torch.randn(B, H, W, c)), dt)
+    w = torch.randn(3, 3, c, c) / (9 * c) ** 0.5
+    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(c) * 0.2)
+    gd = hip.geom(B, H, W, c, H, W, c, 3, 3, 1, 1, 1, 1)
+    y = torch.empty(B, H, W, c, dtype=tdt, device="cuda")
+    gs = hip.geom(B, H, W, c, H // 2, W // 2, c, 3, 3, 2, 2, 1, 1, FH=H, FW=W, OSH=2, OSW=2)
+    ys = torch.full((B, H, W, c), 7.0, device="cuda").to(tdt)
+    with hip.options(c3=0, hconv=0, grid_cap=cap):
+        hip.conv_igemm(gd, dt, hip.EPI_RELU, x, wf, biasf, None, None, y)
+        hip.conv_igemm(gs, dt, hip.EPI_RELU, x, wf, biasf, None, None, ys)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[:, ::2, ::2], y[:, ::2, ::2])
+    odd = torch.ones(H, W, dtype=torch.bool, device="cuda"); odd[::2, ::2] = False
+    assert bool((ys[:, odd].float() == 7.0).all())
+    ref = torch.relu(_ref_conv(x.float().cpu(), wf.float().cpu().reshape(c, 3, 3, c).permute(1, 2, 3, 0), 1, (1, 1), H, W) + biasf.cpu())     # wf: [N][ky][kx][C]
+    assert relerr(y, ref) < TOL[dt]

@@ -857,10 +857,38 @@ class Engine(object):
             gs, dt, flags, A.xin, A.wf, A.biasf, A.res.data if A.res is not None else None, None, X.data_compact,
             X.bits_compact if (flags & hip.EPI_EMIT_BITS) else None))
         self.labels["fwd"][idx[0]] = "fwd:%s@sampled" % A.name
+        self._sample_layer_below(A, X)
         gather = [i for i, lab in enumerate(self.labels["fwd"]) if lab == "subsample:T%d" % X.spec.id]
         for i in reversed(gather):                   # the gather pass that filled X.data_compact from the dense tensor (plans without the
             del self.fwd_ops[i]; del self.labels["fwd"][i]      # register-filter kernel's second store) has nothing to read any more
         X.fwd_sampled = True
+
+    def _sample_layer_below(self, A, X):
+        """One layer further down: the 3x3 layer P whose output Y only feeds the sampled layer A (res{2c,3d,4f}_branch2b, net.py:143) is
+        needed at the even pixels only as well -- A's forward pass, A's stride-2 weight gradient and the mask of A's compact-scatter data
+        gradient all read Y at those pixels.  P runs as a 3x3 / stride-2 layer whose results are SCATTERED to the even pixels of the dense
+        Y buffer (destination scatter of urso_conv_igemm): every reader finds its values where it always did, the other three quarters
+        of the buffer are never written and never read.  P's own backward pass does not involve Y's values."""
+        convs = list(self.convs.values())
+        Y = A.src
+        prod = [c for c in convs if c.dst is Y]
+        if len(prod) != 1 or any(c.src is Y and c is not A for c in convs) or any(c.res is Y for c in convs) or Y.bits is not None:
+            return
+        if any(n.op == "pool" and n.src.id == Y.spec.id for n in self.graph.nodes) or getattr(Y, "data_compact", None) is not None:
+            return
+        P = prod[0]
+        n = P.node
+        H, W = X.spec.h, X.spec.w
+        if (n.stem or n.dense or n.kh != 3 or n.kw != 3 or n.stride != 1 or tuple(n.pad) != (1, 1) or P.batch_bn or P.res is not None or n.cin % 64 or
+                P.npad != P.N or n.src.h != H or n.src.w != W or n.dst.h != H or n.dst.w != W or P.xin is not P.src.data):
+            return
+        idx = [i for i, lab in enumerate(self.labels["fwd"]) if lab == "fwd:%s" % P.name]
+        if len(idx) != 1:
+            return
+        gs = hip.geom(self.B, H, W, n.cin, H // 2, W // 2, P.npad, 3, 3, 2, 2, 1, 1, FH=H, FW=W, OSH=2, OSW=2)
+        self.fwd_ops[idx[0]] = (lambda P=P, gs=gs: hip.conv_igemm_ex(gs, self.dt, P.fwd_flags, P.xin, P.wf, P.biasf, None, None, P.dst.data, None, None))
+        self.labels["fwd"][idx[0]] = "fwd:%s@sampled" % P.name
+        Y.fwd_scattered = True
 
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly
