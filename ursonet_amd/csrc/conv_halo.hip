@@ -445,11 +445,20 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     const int cap = hc_device_cus() / 8;                   // 160 KiB of LDS: one block per CU; each block walks a contiguous run of tiles
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
-    const dim3 grid(8 * bpx), blk(512);
+    dim3 grid(8 * bpx); const dim3 blk(512);
     // stream-K needs every block resident (a finishing block waits for the pieces of the runs that follow it): one block per CU, never
     // more blocks than CUs (and than flags); it is used where it shortens the longest run: ceil(tiles x chunks / blocks) chunk units
     // against ceil(tiles / blocks) whole tiles (cfg2: stage 4 6 vs 8, stage 5 6 vs 8, stage 3 6 vs 6 -> whole tiles)
-    const int G = (int)grid.x;
+    int G = (int)grid.x;
+    // fewer tiles than CUs (stage 5 of cfg2: 180; every stage-4/5 layer at batch 16): whole tiles would leave CUs idle for the whole
+    // launch -- with the hand-over workspace the (tile, chunk) units are dealt to ALL CUs instead (cfg2 stage 5: 6 units per block
+    // instead of 8, measured 62 -> 50 us per layer)
+    if (ws && ws_bytes >= urso_hconv_ws_bytes() && !(a.dbg & 4) && g_urso_opt.grid_cap <= 0 && G < hc_device_cus()) {
+        int G2 = hc_device_cus(); const int units = a.ntiles * a.nchunks;
+        if (G2 > units) G2 = units;
+        G2 = G2 / 8 * 8;
+        if (G2 > G && G2 <= 1024 && ceil_div(units, G2) < ceil_div(a.ntiles, G) * a.nchunks) { G = G2; grid = dim3(G2); }
+    }
     const bool can = ws && ws_bytes >= urso_hconv_ws_bytes() && G <= hc_device_cus() && G <= 1024 && !(a.dbg & 4);
     const bool streamk = can && ((a.dbg & 8) || ceil_div(a.ntiles * a.nchunks, G) < ceil_div(a.ntiles, G) * a.nchunks);      // hconv_dbg bit 3: whenever a workspace is given (tests)
     a.flags = streamk ? (unsigned int*)ws : nullptr;
