@@ -1307,3 +1307,42 @@ def test_3x3_layer_computed_at_the_even_pixels_and_scattered(dt, shape):
     assert bool((ys[:, odd].float() == 7.0).all())
     ref = torch.relu(_ref_conv(x.float().cpu(), wf.float().cpu().reshape(c, 3, 3, c).permute(1, 2, 3, 0), 1, (1, 1), H, W) + biasf.cpu())     # wf: [N][ky][kx][C]
     assert relerr(y, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("case", [(32, 2560, 1024, "relu"), (32, 1024, 4096, "out_f32"), (32, 1024, 8, "out_f32"), (16, 2560, 1024, "relu"), (2, 512, 264, "relu"),
+                                  (32, 4096, 1024, "add_mask"), (32, 8, 1024, "mask"), (5, 1024, 2560, "add")],
+                         ids=["dense_0", "ori_final_f32", "loc_final_padded", "batch16", "batch2_ragged_N", "dgrad_final_add_mask", "dgrad_K8", "dgrad_add"])
+def test_dense_head_skinny_gemm(dt, case):
+    """conv_dense.hip through urso_conv_igemm (option dense, default): the Dense layers of the heads and their data gradients (at most 32
+    rows) against the CPU fp32 reference and against the general kernel (dense = 0; different summation order: tolerance, not bits)."""
+    hip = _hip()
+    M, K, N, form = case
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(K + N + dt)
+    x = dev(torch.randn(M, 1, 1, K), dt)
+    w = (torch.randn(N, K) / K ** 0.5)
+    wf = dev(w, dt)
+    bias = torch.randn(N) * 0.3 if form in ("relu", "out_f32") else None
+    add = dev(torch.randn(M, 1, 1, N), dt) if "add" in form else None
+    mask = dev(torch.randn(M, 1, 1, N), dt) if "mask" in form else None
+    flags = (hip.EPI_RELU if form == "relu" else 0) | (hip.EPI_OUT_F32 if form == "out_f32" else 0)
+    g = hip.geom(M, 1, 1, K, 1, 1, N, 1, 1)
+    ref = x.float().cpu().reshape(M, K) @ wf.float().cpu().T
+    if bias is not None:
+        ref = ref + bias
+    if add is not None:
+        ref = ref + add.float().cpu().reshape(M, N)
+    if form == "relu":
+        ref = torch.relu(ref)
+    if mask is not None:
+        ref = ref * (mask.float().cpu().reshape(M, N) > 0).float()
+    outs = []
+    for dense in (1, 0):
+        y = torch.full((M, 1, 1, N), 3.0, device="cuda", dtype=torch.float32 if form == "out_f32" else tdt)
+        with hip.options(dense=dense):
+            hip.conv_igemm(g, dt, flags, x, wf, dev(bias) if bias is not None else None, add, mask, y)
+        torch.cuda.synchronize()
+        assert relerr(y.reshape(M, N), ref) < (1.2e-2 if dt == 1 else 1.5e-3) * (1 if form != "out_f32" else 0.2), dense
+        outs.append(y.float())
+    assert float((outs[0] - outs[1]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[1].abs().max())

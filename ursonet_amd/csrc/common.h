@@ -32,6 +32,7 @@ struct UrsoOptions {
     int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);
                              // ursonet_amd/dp.py leaves the rest to the collective's resident workgroups.  0 = all of the device's
     int hconv_dbg = 0;       // kernel-development switches of conv_halo.hip (0 in production)
+    int dense = 1;           // conv_dense.hip: skinny GEMM (<= 32 rows) for the Dense heads and their data gradients
     int pwx = 1;             // conv_pwx.hip (8-wave 160-row-tile pointwise GEMM): 0 off, 1 the reduction-heavy layers (K >= 512), 2 every supported layer
     int pwx_dbg = 0;         // kernel-development switches of conv_pwx.hip (0 in production): 1 no copies after the prologue, 2 no MFMAs, 4 no epilogue
     int pwx_bn = 0;          // 128 / 256: force its tile width (tests); 0 = by tile-count rounding

@@ -411,6 +411,9 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
                       hipStream_t st);
 size_t urso_hconv_ws_bytes();
+bool urso_dense_fits(const urso_conv_geom* g, int dt, int flags, int pointwise, long long M);                                      // conv_dense.hip
+int urso_dense_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
+                      const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);
 
 static int ilog2_exact(int v) { if (v == 1) return 0; if (v == 2) return 1; if (v == 4) return 2; return -1; }
 
@@ -549,6 +552,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
                    (add_d ? dst_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? dst_elems / 8 : dst_elems * es) : 0) +
                    ((flags & URSO_EPI_EMIT_BITS) ? dst_elems / 8 : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
+    if (urso_dense_fits(g, dt, flags, a.pointwise, a.M))          // Dense heads: <= 32 rows, weights streamed once (conv_dense.hip)
+        return urso_dense_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
     // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
         const int use_pw = g_urso_opt.pw_kernel;     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem
