@@ -488,3 +488,31 @@ def test_augmentation_consumes_the_global_generator_in_the_reference_order():
     assert np.array_equal(seen["apply"], np.array(apply)) and 0 < sum(apply) < n
     assert np.allclose(seen["pyr"], np.array(pyr)) and 0 < len(pyr) < n
     assert after == np.random.rand(1)[0]                 # and nothing else was drawn from the global stream
+
+
+def test_resize_equals_scipy_ndimage_the_backend_of_skimage_resize():
+    """utils.resize_image's scale != 1 branch (utils.py:457-459: skimage.transform.resize(order=1, mode='constant', preserve_range=True)).
+    skimage is not installed here, but its resize (>= 0.19) is two scipy.ndimage calls -- gaussian_filter with sigma = (in/out - 1)/2 per
+    shrinking axis (anti_aliasing, the default), then zoom(order=1, grid_mode=True, mode='grid-constant', cval=0) -- and scipy IS
+    installed: the product's own bilinear code must reproduce exactly that, on shrinking, growing and mixed factors (real URSO / SPEED
+    frames are reduced 2-3x on this path)."""
+    import scipy.ndimage as ndi
+    from ursonet_amd.utils import _bilinear_resize, resize_image
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 255, size=(96, 128, 3))
+    for oh, ow in ((48, 64), (40, 50), (60, 100), (120, 160), (37, 200), (96, 128)):
+        fac = np.array([96 / oh, 128 / ow, 1.0])
+        sig = np.maximum(0, (fac - 1) / 2)
+        f = ndi.gaussian_filter(img, sig, cval=0, mode="grid-constant") if (sig > 0).any() else img
+        ref = ndi.zoom(f, [1 / x for x in fac], order=1, mode="grid-constant", cval=0, grid_mode=True)
+        assert ref.shape == (oh, ow, 3)
+        assert np.abs(_bilinear_resize(img, oh, ow) - ref).max() < 1e-9
+    # through the public function: a 1200 x 1920-like frame at image_scale 0.5 (cfg5), uint8 in / uint8 out, pad64
+    u8 = rng.integers(0, 256, size=(150, 240, 3), dtype=np.uint8)
+    out, window, scale, padding, crop = resize_image(u8, min_dim=64, max_dim=128, mode="pad64")
+    assert scale == 64 / 150 and out.dtype == np.uint8 and out.shape[0] % 64 == 0 and out.shape[1] % 64 == 0
+    nh, nw = round(150 * scale), round(240 * scale)
+    fac = np.array([150 / nh, 240 / nw, 1.0])
+    ref = ndi.zoom(ndi.gaussian_filter(u8.astype(np.float64), np.maximum(0, (fac - 1) / 2), cval=0, mode="grid-constant"), [1 / x for x in fac], order=1,
+                   mode="grid-constant", cval=0, grid_mode=True).astype(np.uint8)
+    assert np.array_equal(out[window[0]:window[2], window[1]:window[3]], ref)

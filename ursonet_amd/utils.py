@@ -49,7 +49,8 @@ def _bilinear_resize(image, out_h, out_w, anti_aliasing=True):
     skimage.transform.resize(order=1, mode='constant', preserve_range=True) (utils.py:457-459).  When an axis shrinks, newer
     skimage versions first smooth it with a Gaussian of sigma = (in/out - 1)/2 (anti_aliasing=True is their default):
     reproduced here because real URSO / SPEED frames (1280x960, 1920x1200) are reduced by 2-3x on this path.  skimage is not
-    installed in this image, so this path is pinned only by its own tests (scale == 1, the benchmarked path, never gets here)."""
+    installed in this image; its resize is scipy.ndimage.gaussian_filter + zoom(order=1, grid_mode=True, mode='grid-constant'), and
+    this function is pinned to exactly those two calls (tests/test_host_cpu.py::test_resize_equals_scipy_ndimage_...)."""
     h, w = image.shape[:2]
     img = image.astype(np.float64)
     if img.ndim == 2:
