@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
             const uint32_t o = voff(eo_cur[i], tile, v);
             if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, voff(ea_cur[i], tile, v));
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-            if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;   // the pixel's 4 lanes read one dword; OOB >> 4 is beyond any bit mask
+            if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0);   // the pixel's 4 lanes read one dword; the lane's byte is picked at use (no wait here)   // the pixel's 4 lanes read one dword; OOB >> 4 is beyond any bit mask
         }
     setup_src(tile);
     dma(tile, 0, 0);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
                     if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
                     y = a.relu ? fmaxf(y, 0.f) : y;
                     if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
-                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> e) & 1u) ? y : 0.f;
+                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> (8 * fg + e)) & 1u) ? y : 0.f;
                     eo[e] = Elem<T>::from_f(y);
                     if constexpr (EMIT) mbits |= (Elem<T>::to_f(eo[e]) > 0.f) ? (1u << e) : 0u;       // of the STORED value
                 }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? URSO_PW_OCC : 2)) void pw_kernel(c
                     const uint32_t o = voff(eo_nxt[i], next, v);
                     if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, voff(ea_nxt[i], next, v));
                     if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-                    if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
+                    if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0);   // the pixel's 4 lanes read one dword; the lane's byte is picked at use (no wait here)
                 }
             }
         }

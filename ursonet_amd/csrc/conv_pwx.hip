@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
             const uint32_t o = voff(eo_cur[i], tile, v);
             if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
             if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-            if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
+            if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0);   // the pixel's 4 lanes read one dword; the lane's byte is picked at use (no wait here)
         }
     // ---- block prologue: the first NST K-steps of the stream
 #pragma unroll
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
                     if constexpr (HAS_ADD) y += Elem<T>::to_f(ea[e]);
                     y = a.relu ? fmaxf(y, 0.f) : y;
                     if constexpr (HAS_MASK) y = (Elem<T>::to_f(em[e]) > 0.f) ? y : 0.f;
-                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> e) & 1u) ? y : 0.f;
+                    if constexpr (MASKK == 2) y = ((rbit[i * NV + v] >> (8 * fg + e)) & 1u) ? y : 0.f;
                     eo[e] = Elem<T>::from_f(y);
                     if constexpr (EMIT) mbits |= (Elem<T>::to_f(eo[e]) > 0.f) ? (1u << e) : 0u;       // of the STORED value
                 }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
                     const uint32_t o = voff(eo_nxt[i], next, v);
                     if constexpr (HAS_ADD) radd[i * NV + v] = buf_load16(rad, o);
                     if constexpr (HAS_MASK) rmsk[i * NV + v] = buf_load16(rmk, o);
-                    if constexpr (MASKK == 2) rbit[i * NV + v] = (__builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0) >> (8 * fg)) & 0xFFu;
+                    if constexpr (MASKK == 2) rbit[i * NV + v] = __builtin_amdgcn_raw_buffer_load_b32(rmk, (o >> 4) & ~3u, 0, 0);   // the pixel's 4 lanes read one dword; the lane's byte is picked at use (no wait here)
                 }
             }
         }
