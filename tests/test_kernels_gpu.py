@@ -1346,3 +1346,36 @@ def test_dense_head_skinny_gemm(dt, case):
         assert relerr(y.reshape(M, N), ref) < (1.2e-2 if dt == 1 else 1.5e-3) * (1 if form != "out_f32" else 0.2), dense
         outs.append(y.float())
     assert float((outs[0] - outs[1]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[1].abs().max())
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 20, 128, 128), (3, 17, 23, 256, 128), (2, 9, 15, 64, 192), (4, 32, 40, 256, 256), (8, 64, 80, 128, 128),
+                                   (2, 16, 20, 512, 512), (1, 7, 94, 128, 64)],
+                         ids=["c128", "ragged_c256_n128", "c64_n192", "stage4_rows", "stage3_rows", "stage5_64_groups", "widest_row"])
+def test_3x3_weight_gradient_halo_run_kernel(dt, shape):
+    """conv_hwgrad.hip (option hwgrad, default) through urso_conv_wgrad: the 3x3 / stride-1 weight gradient with the gradient held in
+    registers per (64-channel, 64-filter) group over virtual-pixel tiles -- against the CPU fp32 reference (torch autograd) and against the
+    general kernel (hwgrad = 0), weights and column sums; image sizes that are not multiples of anything (zero column / row of the virtual
+    grid, ragged last tile), 4 to 64 groups, splits from 4 to 64 per group."""
+    hip = _hip()
+    B, H, W, C, N = shape
+    torch.manual_seed(C + N + dt)
+    x = rnd(torch.relu(torch.randn(B, H, W, C)), dt)
+    dz = rnd(torch.randn(B, H, W, N), dt)
+    w = torch.zeros(3, 3, C, N, requires_grad=True)
+    y = _ref_conv(x, w, 1, (1, 1), H, W)
+    (y * dz).sum().backward()
+    g = hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
+    outs = []
+    for opt in (1, 0):
+        with hip.options(hwgrad=opt):
+            ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
+            dw = torch.full((3, 3, C, N), 9.0, dtype=torch.float32, device="cuda")
+            cs = torch.full((N,), 9.0, dtype=torch.float32, device="cuda")
+            hip.conv_wgrad(g, dt, dev(x, dt), dev(dz, dt), ws, dw, cs)
+            splits = hip.conv_wgrad_splits(g, dt)
+        torch.cuda.synchronize()
+        assert relerr(dw, w.grad) < TOL[dt] * 0.5, (opt, relerr(dw, w.grad))
+        assert relerr(cs, dz.sum(dim=(0, 1, 2))) < 1e-4
+        outs.append((dw, splits))
+    assert outs[0][1] >= 1 and relerr(outs[0][0], outs[1][0].cpu()) < 1e-3       # fp32 accumulation in another order

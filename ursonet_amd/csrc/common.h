@@ -32,6 +32,7 @@ struct UrsoOptions {
     int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);
                              // ursonet_amd/dp.py leaves the rest to the collective's resident workgroups.  0 = all of the device's
     int hconv_dbg = 0;       // kernel-development switches of conv_halo.hip (0 in production)
+    int hwgrad = 1;          // conv_hwgrad.hip: halo-run weight gradient of the 3x3 layers with >= 128 channels (gradient groups in registers); 0 off, 1 on; 3 / 5 / 7: timing switches (tools/hwgrad_probe.py)
     int dense = 1;           // conv_dense.hip: skinny GEMM (<= 32 rows) for the Dense heads and their data gradients
     int pwx = 1;             // conv_pwx.hip (8-wave 160-row-tile pointwise GEMM): 0 off, 1 the reduction-heavy layers (K >= 512), 2 every supported layer
     int pwx_dbg = 0;         // kernel-development switches of conv_pwx.hip (0 in production): 1 no copies after the prologue, 2 no MFMAs, 4 no epilogue

@@ -680,6 +680,10 @@ struct WgradPlan { int VE, RM, Cc, Kc, K, M, ktiles, ntiles, splits, m_per_split
 bool urso_c3g_fits(const urso_conv_geom* g, int dt);
 int urso_c3g_splits(const urso_conv_geom* g);
 int urso_c3g_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
+// conv_hwgrad.hip: the same scheme for the 3x3 layers with >= 128 channels, one (64-channel, 64-filter) group of the gradient per block
+bool urso_hwg_fits(const urso_conv_geom* g, int dt);
+int urso_hwg_splits(const urso_conv_geom* g);
+int urso_hwg_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
 
 static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int es = (int)dt_size(dt);
@@ -708,6 +712,7 @@ static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     int steps_per = ceil_div(steps, splits);
     splits = ceil_div(steps, steps_per);
     if (urso_c3g_fits(g, dt)) splits = urso_c3g_splits(g);      // that kernel: one partial per block
+    else if (urso_hwg_fits(g, dt)) splits = urso_hwg_splits(g);  // conv_hwgrad.hip: one partial per block and (64 x 64) group
     p.splits = splits; p.m_per_split = steps_per * p.RM;
     p.part_elems = (size_t)splits * ((size_t)p.K * g->N + URSO_WGRAD_PART_PAD);
     p.col_elems = (size_t)splits * g->N;
@@ -802,6 +807,10 @@ static int wgrad_impl(const urso_conv_geom* g, int dt, const void* x_d, const vo
                          else URSO_KLAUNCH((wgrad_tr_kernel<TT, 2, true>), grid, dim3(256), 0, st, a); } while (0)
     if (!zscat && urso_c3g_fits(g, dt)) {
         int rc3 = urso_c3g_launch(g, dt, x_d, dz_d, a.part, a.colpart, (size_t)p.K * g->N + URSO_WGRAD_PART_PAD, st);
+        if (rc3 != URSO_OK) return rc3;
+    }
+    else if (!zscat && urso_hwg_fits(g, dt)) {
+        int rc3 = urso_hwg_launch(g, dt, x_d, dz_d, a.part, a.colpart, (size_t)p.K * g->N + URSO_WGRAD_PART_PAD, st);
         if (rc3 != URSO_OK) return rc3;
     }
     else if (dt == URSO_F32) URSO_WG(wgrad_kernel, float, mode);
