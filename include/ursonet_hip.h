@@ -221,6 +221,17 @@ int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_
 size_t urso_conv_igemm_halo_ws_bytes(void);
 
 /*
+ * Winograd F(2x2, 3x3) evaluation of a 3x3 / stride-1 / pad-1 forward conv (net.py:106,143: res{2..5}x_branch2b), 16-bit dtypes, epilogue
+ * bias + optional ReLU: filter transform G g G^T and input transform B^T d B (fp32 arithmetic, stored in dt), sixteen frequency-domain
+ * GEMMs on MFMA with fp32 outputs, output transform A^T M A.  wgt_d is the same folded [N][3][3][C] filter urso_conv_igemm takes.
+ * Opt-in (ursonet_amd.engine: URSO_WINOGRAD=1): on MI355X the direct kernels are faster on every layer of the network (DESIGN.md
+ * section 14.6).  urso_conv_winograd_ws_bytes() = the workspace it needs (0: geometry not supported).
+ */
+size_t urso_conv_winograd_ws_bytes(const urso_conv_geom* g, int dt);
+int urso_conv_winograd_fwd(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
+                           void* dst_d, void* ws_d, size_t ws_bytes, void* stream);
+
+/*
  * Weight gradient (TF Conv2DBackpropFilter / MatMul grad for every layer above):
  *   dw_raw[ky][kx][c][n] = sum_{b,oy,ox} x[b,iy,ix,c] * dz[b,oy,ox,n]      (fp32, HWIO)
  *   colsum[n]            = sum_{b,oy,ox} dz[b,oy,ox,n]                     (fp32, optional)

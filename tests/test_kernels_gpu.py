@@ -1379,3 +1379,36 @@ def test_3x3_weight_gradient_halo_run_kernel(dt, shape):
         assert relerr(cs, dz.sum(dim=(0, 1, 2))) < 1e-4
         outs.append((dw, splits))
     assert outs[0][1] >= 1 and relerr(outs[0][0], outs[1][0].cpu()) < 1e-3       # fp32 accumulation in another order
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 20, 64, 64, True), (3, 17, 23, 128, 72, True), (2, 9, 15, 64, 128, False), (4, 32, 40, 256, 256, True)],
+                         ids=["c64", "odd_sizes_ragged_N", "no_relu", "stage4_rows"])
+def test_winograd_f2x2_3x3_forward(dt, shape):
+    """urso_conv_winograd_fwd (conv_winograd.hip): the Winograd F(2x2, 3x3) evaluation of a 3x3 / stride-1 / pad-1 layer -- filter and input
+    transforms, sixteen frequency GEMMs on MFMA with fp32 outputs, output transform -- against the CPU fp32 conv and against the direct
+    kernel.  Tolerance: the transformed operands V = B^T d B and U = G g G^T are stored in 16 bits (their products and sums are fp32), which
+    costs about twice the direct kernel's error at bf16.  Odd image sizes: the second row / column of the last tiles is dropped."""
+    hip = _hip()
+    B, H, W, C, N, relu = shape
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(C + N + dt)
+    x = dev(torch.relu(torch.randn(B, H, W, C)), dt)
+    w = torch.randn(3, 3, C, N) / (9 * C) ** 0.5
+    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(N) * 0.2)
+    g = hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
+    ref = _ref_conv(x.float().cpu(), wf.float().cpu().reshape(N, 3, 3, C).permute(1, 2, 3, 0), 1, (1, 1), H, W) + biasf.cpu()
+    if relu:
+        ref = torch.relu(ref)
+    nbytes = hip.conv_winograd_ws_bytes(g, dt)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device="cuda")
+    y = torch.full((B, H, W, N), 5.0, device="cuda").to(tdt); yd = torch.empty_like(y)
+    hip.conv_winograd_fwd(g, dt, hip.EPI_RELU if relu else 0, x, wf, biasf, y, ws)
+    hip.conv_igemm(g, dt, hip.EPI_RELU if relu else 0, x, wf, biasf, None, None, yd)
+    torch.cuda.synchronize()
+    e_w, e_d = relerr(y, ref), relerr(yd, ref)
+    assert e_w < (3e-2 if dt == 1 else 4e-3) and e_d < TOL[dt], (e_w, e_d)
+    with pytest.raises(hip.UrsoHipError):
+        hip.conv_winograd_fwd(hip.geom(B, H, W, C, H // 2, W // 2, N, 3, 3, 2, 2, 1, 1), dt, 0, x, wf, biasf, y, ws)     # stride 2: refused
+    assert hip.conv_winograd_ws_bytes(hip.geom(B, H, W, C, H, W, N, 1, 1), dt) == 0

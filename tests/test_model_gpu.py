@@ -850,3 +850,22 @@ def test_block_outputs_computed_at_sampled_pixels_change_no_result_bit(dtype, mo
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
     assert all(torch.equal(x, y) for x, y in zip(a[7], b[7]))
     assert float(a[3].abs().max()) > 0 and all(np.isfinite(v) for v in a[2].values())
+
+
+def test_training_step_with_winograd_forward_layers(monkeypatch):
+    """URSO_WINOGRAD=1: every 3x3 / stride-1 layer of the forward pass runs the Winograd F(2x2, 3x3) evaluation (conv_winograd.hip);
+    backward pass and everything else unchanged.  One bf16 training step against the rounding-aware oracle at the 16-bit gates
+    (the sampled block-output plan is switched off so that all sixteen 3x3 layers of ResNet-50 take the Winograd path)."""
+    import ursonet_amd.hip as hip
+    from oracle import graph_ref as G
+    monkeypatch.setenv("URSO_WINOGRAD", "1")
+    monkeypatch.setenv("URSO_SAMPLED_OUTPUTS", "0")
+    cfg = make_config(dtype="bfloat16", backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=1)
+    eng, w0 = _run_engine(cfg, img, loc, ori)
+    assert sum(1 for c in eng.convs.values() if getattr(c, "winograd", False)) == 16
+    q = G.StorageRounding(torch.bfloat16)
+    dec = ReluDecisions(eng, tol=8e-2)
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+    assert dec.flips <= 4e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
+    _compare_step(eng, ref, newW, 3e-2, 6e-2, 1e-3)

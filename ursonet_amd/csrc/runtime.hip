@@ -72,7 +72,10 @@ static hipEvent_t get_event() {
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 
+static thread_local int g_prof_depth = 0;      // nested entry points (urso_conv_winograd_fwd -> urso_conv_igemm_ex): only the outermost call is a record
+
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes) {
+    if (g_prof_depth++ > 0) return;
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
     ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event(); r.fn = nullptr; r.st = s; r.nl = 0; r.open = true;
@@ -80,6 +83,7 @@ void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes) 
     g_recs.push_back(r);
 }
 void urso_prof_after(hipStream_t s) {
+    if (--g_prof_depth > 0) return;
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
     if (!g_recs.empty()) { (void)hipEventRecord(g_recs.back().e1, s); g_recs.back().open = false; }

@@ -180,6 +180,7 @@ class Engine(object):
         VE = 16 // (4 if dt == hip.F32 else 2)
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
+        self.wino_ws = None
         self.loss_pre_ops = []     # DP_EXACT_REL_LOSS: the part of the loss that precedes the cross-rank sum of the two norms
         self.labels = {"prep": [], "fwd": [], "loss": [], "bwd": [], "opt": []}
         self.convs = OrderedDict()
@@ -345,6 +346,18 @@ class Engine(object):
                 self.fwd_ops.append(lambda c=c, n=node: hip.bn_apply(c.Mpix, c.N, dt, c.z, c.bmean, c.bvar, c.bn_gamma, c.bn_beta, BN_EPS,
                                                                      c.res.data if c.res is not None else None, n.relu, c.dst.data))
                 self.labels["fwd"].append("bn_apply:" + node.name)
+            elif (os.environ.get("URSO_WINOGRAD", "0") == "1" and dt != hip.F32 and not node.stem and not node.dense and node.kh == 3 and node.kw == 3 and
+                  node.stride == 1 and tuple(node.pad) == (1, 1) and c.res is None and not (flags & ~hip.EPI_RELU) and c.npad == c.N and
+                  hip.conv_winograd_ws_bytes(c.gf, dt) > 0):
+                # opt-in: the 3x3 / stride-1 layers through the Winograd F(2x2, 3x3) evaluation (conv_winograd.hip; north_star names it; slower
+                # than the direct kernels on MI355X).  One shared workspace, sized for the largest layer.
+                need_ws = hip.conv_winograd_ws_bytes(c.gf, dt) // 4 + 64
+                if getattr(self, "wino_ws", None) is None or self.wino_ws.numel() < need_ws:
+                    self.wino_ws = torch.empty(need_ws, dtype=torch.float32, device=dev)
+                c.fwd_index = len(self.fwd_ops)
+                self.fwd_ops.append(lambda c=c, f=flags: hip.conv_winograd_fwd(c.gf, dt, f, c.xin, c.wf, c.biasf, c.dst.data, self.wino_ws))
+                self.labels["fwd"].append("fwd:" + node.name)
+                c.winograd = True
             else:
                 c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(

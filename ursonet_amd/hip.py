@@ -139,6 +139,8 @@ _SIGS = {
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "urso_conv_winograd_ws_bytes": (_sz, [_gp, _i]),
+    "urso_conv_winograd_fwd": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _sz, _vp]),
     "urso_prof_enable": (_i, [_i]),
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
     "urso_prof_collect_ex": (_i, [C.POINTER(ProfRecordEx), _i]),
@@ -220,6 +222,16 @@ def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1, FH
 def conv_igemm(g, dt, flags, src, wgt, bias, add, mask, dst, stream=None):
     _chk(_lib.urso_conv_igemm(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
                               stream_ptr(stream)), "urso_conv_igemm")
+
+
+def conv_winograd_ws_bytes(g, dt):
+    return int(_lib.urso_conv_winograd_ws_bytes(C.byref(g), dt))
+
+
+def conv_winograd_fwd(g, dt, flags, src, wgt, bias, dst, ws, stream=None):
+    """urso_conv_winograd_fwd: Winograd F(2x2, 3x3) evaluation of a 3x3 / stride-1 / pad-1 forward conv (opt-in; slower than the direct kernels)."""
+    _chk(_lib.urso_conv_winograd_fwd(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(dst), ptr(ws), ws.numel() * ws.element_size(),
+                                     stream_ptr(stream)), "urso_conv_winograd_fwd")
 
 
 def conv_igemm_ws_bytes(g, dt):
