@@ -30,19 +30,19 @@ __global__ __launch_bounds__(512) void dense_kernel(const DnArgs a) {
     const int nslabs = ceil_div(a.K, 32);
     f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     // lane (fr, fg): weight row n0 + fr, activation rows fr and 16 + fr, the 8 k starting at 32 slab + 8 fg
-    const uint32_t wrow = (n0 + fr < a.N) ? (uint32_t)(n0 + fr) * (uint32_t)a.K * 2u : URSO_OOB_SHIFT;
-    const uint32_t arow0 = (fr < a.M) ? (uint32_t)fr * (uint32_t)a.K * 2u : URSO_OOB_SHIFT;
-    const uint32_t arow1 = (16 + fr < a.M) ? (uint32_t)(16 + fr) * (uint32_t)a.K * 2u : URSO_OOB_SHIFT;
+    const bool wok = n0 + fr < a.N, a0ok = fr < a.M, a1ok = 16 + fr < a.M;
+    const uint32_t wrow = (uint32_t)(n0 + fr) * (uint32_t)a.K * 2u, arow0 = (uint32_t)fr * (uint32_t)a.K * 2u, arow1 = (uint32_t)(16 + fr) * (uint32_t)a.K * 2u;
     constexpr int UN = 4;
     for (int s0 = wave; s0 < nslabs; s0 += 8 * UN) {
         i32x4_t fw[UN], fa0[UN], fa1[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = (s0 + 8 * u) * 32 + fg * 8;
-            const uint32_t ko = (k + 8 <= a.K) ? (uint32_t)k * 2u : URSO_OOB_SHIFT;      // K % 8 == 0: a chunk is whole or absent (a row's tail must not read the next row)
-            fw[u] = buf_load16(rw, wrow + ko);
-            fa0[u] = buf_load16(rs, arow0 + ko);
-            fa1[u] = buf_load16(rs, arow1 + ko);
+            const bool kok = k + 8 <= a.K;                     // K % 8 == 0: a chunk is whole or absent (a row's tail must not read the next row)
+            const uint32_t ko = (uint32_t)k * 2u;              // absent row or chunk: ONE out-of-range marker (two added would wrap to offset 0)
+            fw[u] = buf_load16(rw, (wok && kok) ? wrow + ko : URSO_OOB_SHIFT);
+            fa0[u] = buf_load16(rs, (a0ok && kok) ? arow0 + ko : URSO_OOB_SHIFT);
+            fa1[u] = buf_load16(rs, (a1ok && kok) ? arow1 + ko : URSO_OOB_SHIFT);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
