@@ -333,6 +333,33 @@ int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32
 int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream);
 
 /*
+ * Weight gradients of SEVERAL pointwise (1x1 / stride 1) 16-bit layers in one launch -- the grouped form of
+ * urso_conv_wgrad_partial (same kernel body, same partial layout, Conv2DBackpropFilter of net.py:85-158).  A layer launched on
+ * its own is split over ~2 blocks per CU whatever its size, so it writes (and the split reduction re-reads) CUs x 128 KiB of fp32
+ * partials: as many bytes as its operands in the late stages.  n layers sharing a launch get 1/n of the splits each.
+ *   urso_wgrad_group_fits : 1 when the layer qualifies (pointwise geometry, 16-bit, C % 8 == N % 8 == 0, N > 64, M >= 4096)
+ *   urso_wgrad_group_plan : host; fills ktiles/ntiles/splits/m_per_split of items_h[0..n) from their M, C, N (one common number
+ *                           of pixels per block, at most `wgrad_blocks` x CUs / device CUs blocks) and writes the block map
+ *                           (2 x int32 per block: item, work id; XCD-contiguous); returns the block count, 0 when the group does
+ *                           not fit the resident slots (call with blockmap_h = NULL to size it); items_h[0].reserved receives the
+ *                           plan's fill in 1/1000: tile-steps of work / (resident slots x the longest block).  The caller then sets
+ *                           part / colpart (colpart = part + splits * (C*N + URSO_WGRAD_PART_PAD)) and copies both tables to the device.
+ *   urso_wgrad_group_run  : device; one launch over items_d / blockmap_d.
+ */
+typedef struct urso_wgrad_item {
+    const void* x;                         /* [M][C] layer input */
+    const void* dz;                        /* [M][N] gradient w.r.t. the layer output */
+    float* part;                           /* [splits][C*N + URSO_WGRAD_PART_PAD] fp32 partials */
+    float* colpart;                        /* [splits][N] column sums of dz (may be NULL) */
+    int32_t M, C, N;
+    int32_t ktiles, ntiles, splits, m_per_split, reserved;
+} urso_wgrad_item;
+int urso_wgrad_group_fits(const urso_conv_geom* g, int dt);
+int urso_wgrad_group_plan(int n, urso_wgrad_item* items_h, int dt, int32_t* blockmap_h, int cap_blocks);
+int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, const urso_wgrad_item* items_h, int n,
+                         const int32_t* blockmap_d, int nblocks, void* stream);
+
+/*
  * Batch-statistics BatchNorm (TRAIN_BN = None, "Train BN layers": the BatchNorm wrapper net.py:60-76 forwards
  * training=None, i.e. Keras' learning phase).  Secondary mode of the reference (config.py:146 defaults to frozen and the
  * CLI never changes it): the BN cannot be folded into the filter, so the conv writes its raw output z [M pixels][N] and

@@ -869,3 +869,37 @@ def test_training_step_with_winograd_forward_layers(monkeypatch):
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 4e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
     _compare_step(eng, ref, newW, 3e-2, 6e-2, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_grouped_pointwise_weight_gradients_in_the_plan(dtype, monkeypatch):
+    """URSO_WGRAD_GROUP (default 8): consecutive pointwise layers of a gradient bucket share one weight-gradient launch with 1/n of the splits
+    each (urso_wgrad_group_run).  Against the per-layer plan (URSO_WGRAD_GROUP=0) on the same step: forward outputs, losses and every
+    data gradient are the same launches (bit-identical losses), the weight gradients are the same fp32 sums cut into fewer, longer pieces --
+    equal to a few fp32 ulps of the largest entry of their layer; the grouped layers' split counts shrink; a two-bucket plan never lets a
+    group straddle the bucket's reduction."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 256, 320, batch=8, regress_ori=False, ori_bins=4, dtype=dtype, lr=1e-2)
+    img, loc, ori, _ = synthetic_batch(cfg, 8, seed=43)
+    res = []
+    for mode in ("8", "0"):
+        monkeypatch.setenv("URSO_WGRAD_GROUP", mode)
+        eng = Engine(cfg, "training", seed=5, randomize_bn=True, grad_bucket_bytes=24 << 20)
+        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+        grouped = [l for l in eng.labels["bwd"] if l and l.startswith("wgrad:") and "+" in l]
+        res.append((eng, grouped, eng.flat_g.clone(), eng.losses(), {n: c.splits for n, c in eng.convs.items()}))
+    (e1, g1, fg1, l1, s1), (e0, g0, fg0, l0, s0) = res
+    assert len(g1) >= 4 and not g0 and e1.n_wgrad_groups == len(g1) and e0.n_wgrad_groups == 0
+    assert l1 == l0
+    names = [n for l in g1 for n in l[len("wgrad:"):].split("+")]
+    assert len(names) == len(set(names)) >= 16 and all(s1[n] <= s0[n] for n in names) and sum(s1[n] for n in names) * 2 <= sum(s0[n] for n in names)
+    # no group straddles a bucket: all members of a launch finalise in the same bucket
+    bucket_of = {n: k for k, (_, _, ns) in enumerate(e1.buckets) for n in ns}
+    assert len(e1.buckets) >= 3 and all(len({bucket_of[n] for n in l[len("wgrad:"):].split("+")}) == 1 for l in g1)
+    for name, (off, n, _) in e1.slices.items():
+        a, b = fg1[off:off + n], fg0[off:off + n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-12, name
+    assert float(fg1.abs().max()) > 0

@@ -240,11 +240,12 @@ template <typename T> struct OnesFrag;
 template <> struct OnesFrag<__bf16> { static constexpr int W = 0x3F803F80; };
 template <> struct OnesFrag<_Float16> { static constexpr int W = 0x3C003C00; };
 
-template <typename T, int MODE, bool PIPE = false>
-__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
+// The block's work: tile `wid % tiles` of split `wid / tiles` of the layer described by `a` (called by the per-layer kernel and by
+// the grouped one below, which takes `a` from a device table).
+template <typename T, int MODE, bool PIPE>
+__device__ __forceinline__ void wgrad_tr_body(const WgradArgs& a, const int wid, char* smem) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int VE = 8, RM = 64, ITEMS = 4;          // 64 pixels x 128 channels per operand per step; 4 x 16 B per thread
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * RM * 256];
     auto sX = [&](int buf) -> char* { return smem + buf * 2 * RM * 256; };
     auto sZ = [&](int buf) -> char* { return smem + buf * 2 * RM * 256 + RM * 256; };
 
@@ -253,7 +254,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     // blocks are dispatched round-robin over the 8 XCDs; give each XCD a CONTIGUOUS run of the split-major work list, so
     // that the tiles sharing a pixel range (same x / dz chunks) sit behind one L2 instead of being fetched by all eight
     const int tiles = a.ktiles * a.ntiles;
-    const int wid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * a.splits);
     const int sp = wid / tiles, tile = wid - sp * tiles;
     const int kt = tile % a.ktiles, nt = tile / a.ktiles;
     const int k0c = kt * 16, n0 = nt * 128;
@@ -442,6 +442,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
             if (nb < a.N) *(f32x4_t*)(a.colpart + (size_t)sp * a.N + nb) = accc[j];
         }
     }
+}
+
+template <typename T, int MODE, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 256];
+    wgrad_tr_body<T, MODE, PIPE>(a, xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, a.ktiles * a.ntiles * a.splits), smem);
+}
+
+// Several pointwise layers' weight gradients in ONE launch (urso_wgrad_group_run).  A layer on its own is cut into ~2 blocks per CU,
+// i.e. CUs x 128 KiB of fp32 partials written at the end of the launch and read again by the split reduction -- as many bytes as
+// the layer's operands in stages 4-5.  With G layers sharing the launch every layer gets 1/G of the splits: the blocks run G times
+// longer over their pixels and the partial traffic (and the write burst that nothing overlaps) drops by G.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const urso_wgrad_item* __restrict__ items, const int32_t* __restrict__ map) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 256];
+    const int li = map[2 * blockIdx.x], wid = map[2 * blockIdx.x + 1];
+    const urso_wgrad_item& it = items[li];
+    WgradArgs a;
+    a.x = it.x; a.dz = it.dz; a.part = it.part; a.colpart = it.colpart;
+    a.x_bytes = (uint32_t)it.M * (uint32_t)it.C * 2u; a.dz_bytes = (uint32_t)it.M * (uint32_t)it.N * 2u;
+    a.C = it.C; a.N = it.N; a.M = it.M; a.Cc = it.C / 8; a.Kc = a.Cc; a.K = it.C;
+    a.ktiles = it.ktiles; a.ntiles = it.ntiles; a.splits = it.splits; a.m_per_split = it.m_per_split;
+    a.KW = 1; a.OH = 1; a.OW = 1; a.zs = 0;              // (unused by the pointwise form)
+    wgrad_tr_body<T, 0, true>(a, wid, smem);
 }
 
 // Narrow form for layers with at most 64 filters (the 3x3 convs of stage 2, the stem): 128(k) x 64(n) output tile, so no
@@ -864,4 +888,95 @@ extern "C" int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const voi
     URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((cnt / 4 + rcols - 1) / rcols)), dim3(256), 0, st, part, dw_raw_d, cnt, splits, pstride);
     if (colsum_d) URSO_KLAUNCH(reduce_partials_kernel, dim3((int)((64 / 4 + rcols - 1) / rcols)), dim3(256), 0, st, colpart, colsum_d, (size_t)64, splits, (size_t)64);
     return urso_check_launch("urso_stem_wgrad_pooled(reduce)");
+}
+
+// ---- grouped pointwise weight gradients (see wgrad_group_kernel) ----
+extern "C" int urso_wgrad_group_fits(const urso_conv_geom* g, int dt) {
+    if (!g || (dt != URSO_BF16 && dt != URSO_F16)) return 0;
+    const bool pointwise = g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW &&
+                           g->DH == 1 && g->DW == 1 && g->FH == 0;
+    const long long M = (long long)g->B * g->OH * g->OW;
+    if (!pointwise || g->C % 8 || g->N % 8 || g->N <= 64 || M < 4096 || M >= (1 << 24)) return 0;
+    if ((unsigned long long)M * g->C * 2 >= 0x7FFFFF00ull || (unsigned long long)M * g->N * 2 >= 0x7FFFFF00ull) return 0;
+    return 1;
+}
+
+static int xcd_remap_host(int bid, int nblk) {
+    const int NX = 8;
+    if (nblk < NX) return bid;
+    const int xcd = bid % NX, idx = bid / NX, q = nblk / NX, r = nblk % NX;
+    return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t* blockmap_h, int cap_blocks) {
+    if (n <= 0 || !it || (dt != URSO_BF16 && dt != URSO_F16)) { urso_set_error("urso_wgrad_group_plan: bad argument"); return -1; }
+    const int target = (int)((long long)g_urso_opt.wgrad_blocks * urso_usable_cus() / urso_device_cus());
+    long long work = 0; int tiles_all = 0, steps_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (it[i].M < 64 || it[i].C <= 0 || it[i].N <= 0 || it[i].C % 8 || it[i].N % 8) { urso_set_error("urso_wgrad_group_plan: item %d: bad M/C/N", i); return -1; }
+        it[i].ktiles = ceil_div(it[i].C, 128); it[i].ntiles = ceil_div(it[i].N, 128);
+        const int tiles = it[i].ktiles * it[i].ntiles, steps = ceil_div(it[i].M, 64);
+        tiles_all += tiles; work += (long long)tiles * steps; steps_max = steps > steps_max ? steps : steps_max;
+    }
+    if (tiles_all > target) return 0;                     // even one split per layer overflows the resident slots
+    // one common number of 64-pixel steps per block: the smallest that keeps every block resident (no second wave)
+    int s = (int)((work + target - 1) / target); if (s < 8) s = 8;
+    for (;; ++s) {
+        long long blocks = 0;
+        for (int i = 0; i < n; ++i) blocks += (long long)it[i].ktiles * it[i].ntiles * ceil_div(ceil_div(it[i].M, 64), s);
+        if (blocks <= target || s >= steps_max) break;
+    }
+    int nblk = 0;
+    for (int i = 0; i < n; ++i) {
+        const int steps = ceil_div(it[i].M, 64);
+        int splits = ceil_div(steps, s);
+        const int per = ceil_div(steps, splits);              // balanced within the layer
+        splits = ceil_div(steps, per);
+        it[i].splits = splits; it[i].m_per_split = per * 64; it[i].reserved = 0;
+        nblk += it[i].ktiles * it[i].ntiles * splits;
+    }
+    // how well the plan fills the resident slots: (tile-steps of work) / (slots x the longest block), in 1/1000
+    int longest = 0;
+    for (int i = 0; i < n; ++i) longest = it[i].m_per_split / 64 > longest ? it[i].m_per_split / 64 : longest;
+    it[0].reserved = (int32_t)(work * 1000 / ((long long)target * longest));
+    if (!blockmap_h) return nblk;
+    if (cap_blocks < nblk) { urso_set_error("urso_wgrad_group_plan: block map too small"); return -1; }
+    // logical work list: item-major, then split, then tile (the tiles of one pixel range are neighbours); physical block b takes
+    // the logical entry xcd_remap(b), so every XCD gets a contiguous run of the list
+    int32_t* lay = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nblk);
+    if (!lay) { urso_set_error("urso_wgrad_group_plan: out of memory"); return -1; }
+    int j = 0;
+    for (int i = 0; i < n; ++i) {
+        const int cnt = it[i].ktiles * it[i].ntiles * it[i].splits;
+        for (int w = 0; w < cnt; ++w, ++j) { lay[2 * j] = i; lay[2 * j + 1] = w; }
+    }
+    for (int b = 0; b < nblk; ++b) {
+        const int l = xcd_remap_host(b, nblk);
+        blockmap_h[2 * b] = lay[2 * l]; blockmap_h[2 * b + 1] = lay[2 * l + 1];
+    }
+    free(lay);
+    return nblk;
+}
+
+extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, const urso_wgrad_item* items_h, int n,
+                                    const int32_t* blockmap_d, int nblocks, void* stream) {
+    if (!items_d || !items_h || !blockmap_d || n <= 0 || nblocks <= 0) { urso_set_error("urso_wgrad_group_run: bad argument"); return URSO_EINVAL; }
+    if (dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_wgrad_group_run: 16-bit dtypes only"); return URSO_EINVAL; }
+    double flops = 0, bytes = 0; int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const urso_wgrad_item& t = items_h[i];
+        if (!t.x || !t.dz || !t.part || t.splits < 1 || t.m_per_split < 64 || t.m_per_split % 64 || (long long)t.splits * t.m_per_split < t.M ||
+            ((uintptr_t)t.x | (uintptr_t)t.dz | (uintptr_t)t.part | (uintptr_t)t.colpart) & 15) {
+            urso_set_error("urso_wgrad_group_run: item %d is not planned (urso_wgrad_group_plan) or misaligned", i); return URSO_EINVAL;
+        }
+        flops += 2.0 * t.M * (double)t.N * t.C;
+        bytes += 2.0 * t.M * ((double)t.C + t.N) + 4.0 * t.C * t.N;
+        cnt += t.ktiles * t.ntiles * t.splits;
+    }
+    if (cnt != nblocks) { urso_set_error("urso_wgrad_group_run: block map has %d blocks, the items need %d", nblocks, cnt); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
+    if (dt == URSO_BF16) URSO_KLAUNCH(wgrad_group_kernel<__bf16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
+    else URSO_KLAUNCH(wgrad_group_kernel<_Float16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
+    return urso_check_launch("urso_wgrad_group_run");
 }

@@ -394,6 +394,44 @@ class Engine(object):
         # their weight-gradient partials is enqueued; ursonet_amd/dp.py starts the bucket's all-reduce right after.
         from .dp import plan_buckets
         pending_groups = []
+        # Grouped pointwise weight gradients (urso_wgrad_group_run): a layer launched alone is cut into ~2 blocks per CU whatever its
+        # size, so it writes -- and the bucket's split reduction re-reads -- CUs x 128 KiB of fp32 partials (32 MB a layer, as much as
+        # its operands in stages 4-5), in a burst at the end of the launch that nothing overlaps.  Up to URSO_WGRAD_GROUP consecutive
+        # pointwise layers of a bucket share one launch instead: each gets 1/n of the splits, its blocks run n times longer.
+        wg_max = int(os.environ.get("URSO_WGRAD_GROUP", "8")) if dt != hip.F32 else 0
+        wg_fill = float(os.environ.get("URSO_WGRAD_GROUP_FILL", "0.7"))
+        pend_wg = []
+        self.n_wgrad_groups = 0
+
+        def emit_wgrad(c, name, xw, G, gf_w):
+            self.bwd_ops.append((name, lambda: hip.conv_wgrad_partial(gf_w, dt, xw, G, c.wg_ws)))
+            self.labels["bwd"].append("wgrad:" + name)
+
+        def flush_wgrads():
+            items = list(pend_wg)
+            del pend_wg[:]
+            while items:
+                take = items
+                grp = None
+                while len(take) > 1:
+                    grp = hip.WgradGroup([(g.B * g.OH * g.OW, g.C, g.N) for (_, _, _, _, g) in take], dt)
+                    if grp.nblocks:
+                        break
+                    take, grp = take[:len(take) - 1], None           # more tiles than resident blocks: a smaller group
+                items = items[len(take):]
+                if grp is None:
+                    emit_wgrad(*take[0])
+                    continue
+                for (c, _, _, _, _), s in zip(take, grp.splits):
+                    assert s <= c.splits
+                    c.splits = c.desc.splits = s
+                    c.wg_npart = s * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
+                    c.desc.part, c.desc.colpart = c.wg_ws.data_ptr(), c.wg_ws.data_ptr() + 4 * c.wg_npart
+                grp.bind([t[2] for t in take], [t[3] for t in take], [t[0].wg_ws for t in take], dev)
+                names = tuple(t[1] for t in take)
+                self.bwd_ops.append((names, lambda grp=grp: grp.run()))
+                self.labels["bwd"].append("wgrad:" + "+".join(names))
+                self.n_wgrad_groups += 1
         ext = {}
         for (ln, wn), (o, n, _) in self.slices.items():
             s0, e0 = ext.get(ln, (o, o))
@@ -513,9 +551,21 @@ class Engine(object):
                 d.ggamma = hip.ptr(self.gview(node.bn, "gamma").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 if not by_pair:
-                    self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w: hip.conv_wgrad_partial(gf_w, dt, c.xin if gf_w is c.gf else c.src.data, G, c.wg_ws)))
-                    self.labels["bwd"].append("wgrad:" + node.name)
+                    xw = c.xin if gf_w is c.gf else c.src.data
+                    if wg_max > 1 and hip.wgrad_group_fits(gf_w, dt) and gf_w.C == c.K_raw and gf_w.N == c.npad:
+                        # a pointwise layer: its weight gradient waits for company (see flush_wgrads); every tensor has a gradient
+                        # buffer of its own, so G is still there when the launch comes
+                        cand = pend_wg + [(c, node.name, xw, G, gf_w)]
+                        if len(cand) > 1 and hip.WgradGroup([(g.B * g.OH * g.OW, g.C, g.N) for (_, _, _, _, g) in cand], dt).fill < wg_fill:
+                            flush_wgrads()                 # the newcomer's tile count / pixel count does not divide the slots well
+                        pend_wg.append(cand[-1])
+                        if len(pend_wg) >= wg_max:
+                            flush_wgrads()
+                    else:
+                        self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w, xw=xw: hip.conv_wgrad_partial(gf_w, dt, xw, G, c.wg_ws)))
+                        self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
+                    flush_wgrads()                         # the bucket's reduction reads every partial of the bucket
                     k = last_of_group[node.name]
                     pending_groups.append((k, tuple(groups[k]), len(self.bwd_ops)))
                     for ph, nm in ((hip.PB_REDUCE, "reduce"), (hip.PB_FINALIZE_MAT, "finalize_mat"), (hip.PB_FINALIZE_VEC, "finalize_vec")):
@@ -628,6 +678,7 @@ class Engine(object):
                                                        self.halo_ws if (c.halo_d and add is None and not mflag) else (self.igemm_ws if c.ws_d else None))))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
+        flush_wgrads()
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
         self._upload_param_table()
         resolved, labels = [], []

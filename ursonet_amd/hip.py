@@ -90,6 +90,9 @@ _SIGS = {
     "urso_conv_wgrad_partial": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _vp]),
     "urso_param_desc_init": (_i, [_dp, _i, _i, _i, _i, _i, _i, _f, _f]),
     "urso_param_batch_plan": (_i, [_i, _dp, C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _i]),
+    "urso_wgrad_group_fits": (_i, [_gp, _i]),
+    "urso_wgrad_group_plan": (_i, [_i, _vp, _i, C.POINTER(C.c_int32), _i]),
+    "urso_wgrad_group_run": (_i, [_i, _vp, _vp, _i, _vp, _i, _vp]),
     "urso_param_batch_run": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "urso_conv_weight_prep": (_i, [_i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _vp, _fp, _fp, _vp]),
     "urso_stem_weight_pack": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f, _vp, _fp, _fp, _vp]),
@@ -309,6 +312,54 @@ class ParamBatch(object):
         t, nb = self.maps[(phase, key)]
         if nb:
             _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
+
+
+class WgradItem(C.Structure):
+    """urso_wgrad_item (include/ursonet_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("part", C.c_void_p), ("colpart", C.c_void_p),
+                ("M", C.c_int32), ("C", C.c_int32), ("N", C.c_int32),
+                ("ktiles", C.c_int32), ("ntiles", C.c_int32), ("splits", C.c_int32), ("m_per_split", C.c_int32), ("reserved", C.c_int32)]
+
+
+def wgrad_group_fits(g, dt):
+    return bool(_lib.urso_wgrad_group_fits(C.byref(g), dt))
+
+
+class WgradGroup(object):
+    """The weight gradients of several pointwise 16-bit layers in one launch (urso_wgrad_group_plan / _run).
+
+    shapes: [(M, C, N)].  After construction .splits[i] holds each layer's partial count (0 blocks: .nblocks == 0, the group does
+    not fit one residency); bind() takes the operand / workspace tensors (partials laid out as urso_conv_wgrad_partial does)."""
+
+    def __init__(self, shapes, dt):
+        self.n, self.dt = len(shapes), dt
+        self.host = (WgradItem * self.n)()
+        for it, (M, Cin, N) in zip(self.host, shapes):
+            it.M, it.C, it.N = int(M), int(Cin), int(N)
+        nb = _lib.urso_wgrad_group_plan(self.n, self.host, dt, None, 0)
+        if nb < 0:
+            raise UrsoHipError("urso_wgrad_group_plan: " + last_error())
+        self.nblocks = nb
+        self.splits = [int(it.splits) for it in self.host] if nb else []
+        self.fill = self.host[0].reserved / 1000.0 if nb else 0.0     # work / (resident slots x the longest block)
+        self.dev = self.map = None
+
+    def bind(self, xs, dzs, wss, device):
+        buf = (C.c_int32 * (2 * self.nblocks))()
+        if _lib.urso_wgrad_group_plan(self.n, self.host, self.dt, buf, self.nblocks) != self.nblocks:
+            raise UrsoHipError("urso_wgrad_group_plan: " + last_error())
+        for it, x, dz, ws in zip(self.host, xs, dzs, wss):
+            n_part = it.splits * (it.C * it.N + WGRAD_PART_PAD)
+            if ws.numel() * ws.element_size() < 4 * (n_part + it.splits * it.N):
+                raise UrsoHipError("WgradGroup.bind: workspace too small")
+            it.x, it.dz, it.part, it.colpart = x.data_ptr(), dz.data_ptr(), ws.data_ptr(), ws.data_ptr() + 4 * n_part
+        self.keep = (list(xs), list(dzs), list(wss))
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+        self.map = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.int32).to(device)
+
+    def run(self, stream=None):
+        _chk(_lib.urso_wgrad_group_run(self.dt, ptr(self.dev), C.cast(self.host, C.c_void_p), self.n, ptr(self.map), self.nblocks,
+                                       stream_ptr(stream)), "urso_wgrad_group_run")
 
 
 def bn_ws_bytes(M, N):
