@@ -333,26 +333,28 @@ int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32
 int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream);
 
 /*
- * Weight gradients of SEVERAL pointwise (1x1 / stride 1) 16-bit layers in one launch -- the grouped form of
- * urso_conv_wgrad_partial (same kernel body, same partial layout, Conv2DBackpropFilter of net.py:85-158).  A layer launched on
- * its own is split over ~2 blocks per CU whatever its size, so it writes (and the split reduction re-reads) CUs x 128 KiB of fp32
- * partials: as many bytes as its operands in the late stages.  n layers sharing a launch get 1/n of the splits each.
- *   urso_wgrad_group_fits : 1 when the layer qualifies (pointwise geometry, 16-bit, C % 8 == N % 8 == 0, N > 64, M >= 4096)
- *   urso_wgrad_group_plan : host; fills ktiles/ntiles/splits/m_per_split of items_h[0..n) from their M, C, N (one common number
+ * Weight gradients of SEVERAL 16-bit layers in one launch -- the grouped form of urso_conv_wgrad_partial (same kernel body, same
+ * partial layout, Conv2DBackpropFilter of net.py:85-158).  A layer launched on its own is split over ~2 blocks per CU whatever
+ * its size, so it writes (and the split reduction re-reads) CUs x 128 KiB of fp32 partials: as many bytes as its operands in
+ * the late stages.  n layers sharing a launch get 1/n of the splits each.
+ *   urso_wgrad_group_fits : 1 when the layer qualifies: a 16-bit layer of the general 128 x 128-tile kernel (not the stem, not the
+ *                           <= 64-filter narrow form, not the register-resident 3x3 kernels), >= 4096 output pixels
+ *   urso_wgrad_group_plan : host; fills M/ktiles/ntiles/splits/m_per_split/mode of items_h[0..n) from their g (one common number
  *                           of pixels per block, at most `wgrad_blocks` x CUs / device CUs blocks) and writes the block map
  *                           (2 x int32 per block: item, work id; XCD-contiguous); returns the block count, 0 when the group does
- *                           not fit the resident slots (call with blockmap_h = NULL to size it); items_h[0].reserved receives the
+ *                           not fit the resident slots (call with blockmap_h = NULL to size it); items_h[0].fill receives the
  *                           plan's fill in 1/1000: tile-steps of work / (resident slots x the longest block).  The caller then sets
- *                           part / colpart (colpart = part + splits * (C*N + URSO_WGRAD_PART_PAD)) and copies both tables to the device.
+ *                           part / colpart (colpart = part + splits * (K*N + URSO_WGRAD_PART_PAD), K = KH*KW*C) and copies both
+ *                           tables to the device.
  *   urso_wgrad_group_run  : device; one launch over items_d / blockmap_d.
  */
 typedef struct urso_wgrad_item {
-    const void* x;                         /* [M][C] layer input */
-    const void* dz;                        /* [M][N] gradient w.r.t. the layer output */
-    float* part;                           /* [splits][C*N + URSO_WGRAD_PART_PAD] fp32 partials */
+    const void* x;                         /* layer input [B][H][W][C] */
+    const void* dz;                        /* gradient w.r.t. the layer output [B][OH][OW][N] ([B][FH][FW][N] when g.FH > 0) */
+    float* part;                           /* [splits][K*N + URSO_WGRAD_PART_PAD] fp32 partials */
     float* colpart;                        /* [splits][N] column sums of dz (may be NULL) */
-    int32_t M, C, N;
-    int32_t ktiles, ntiles, splits, m_per_split, reserved;
+    urso_conv_geom g;                      /* forward geometry, as urso_conv_wgrad takes it */
+    int32_t M, ktiles, ntiles, splits, m_per_split, mode, fill;
 } urso_wgrad_item;
 int urso_wgrad_group_fits(const urso_conv_geom* g, int dt);
 int urso_wgrad_group_plan(int n, urso_wgrad_item* items_h, int dt, int32_t* blockmap_h, int cap_blocks);

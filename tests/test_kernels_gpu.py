@@ -1414,42 +1414,52 @@ def test_winograd_f2x2_3x3_forward(dt, shape):
     assert hip.conv_winograd_ws_bytes(hip.geom(B, H, W, C, H, W, N, 1, 1), dt) == 0
 
 
+def _pw(M, C, N):
+    return (1, 1, M, C, 1, M, N, 1, 1, 1, 1, 0, 0)
+
+
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("layers", [[(4096, 256, 128), (4096, 128, 256)],
-                                    [(8200, 1024, 256), (8200, 256, 1024), (4160, 136, 72), (16384, 128, 512)],
-                                    [(40960, 256, 1024)] * 2 + [(10240, 2048, 512), (10240, 512, 2048)]],
-                         ids=["pair", "ragged_mixed", "stage4_stage5_mix"])
-def test_grouped_pointwise_weight_gradients(dt, layers):
-    """urso_wgrad_group_plan / _run (conv_wgrad.hip): several 1x1 layers' weight gradients in one launch -- each layer's partials land in
+@pytest.mark.parametrize("layers", [[_pw(4096, 256, 128), _pw(4096, 128, 256)],
+                                    [_pw(8200, 1024, 256), _pw(8200, 256, 1024), _pw(4160, 136, 72), _pw(16384, 128, 512),
+                                     (4, 65, 81, 128, 33, 41, 136, 3, 3, 2, 2, 1, 1), (4, 64, 80, 256, 32, 40, 128, 1, 1, 2, 2, 0, 0),
+                                     (3, 40, 9, 128, 40, 9, 192, 3, 3, 1, 1, 1, 1)],
+                                    [_pw(40960, 256, 1024)] * 2 + [_pw(10240, 2048, 512), _pw(10240, 512, 2048)]],
+                         ids=["pair", "ragged_mixed_geometries", "stage4_stage5_mix"])
+def test_grouped_weight_gradients(dt, layers):
+    """urso_wgrad_group_plan / _run (conv_wgrad.hip): several layers' weight gradients in one launch -- each layer's partials land in
     its own workspace with the layout of urso_conv_wgrad_partial, only with fewer splits; reduced in the fixed order they must match the
-    fp64 product of the same 16-bit operands, the column sums, and the per-layer launch (fp32 sums in another grouping).  Ragged pixel counts
-    and channel counts that leave partial tiles; layers of different pixel counts in one group (one common pixels-per-block)."""
+    per-layer launch (itself checked against autograd above; fp32 sums in another grouping) and, for the pointwise layers, the fp64 product
+    of the same 16-bit operands and the column sums.  Ragged pixel counts and channel counts that leave partial tiles; layers of different
+    pixel counts in one group (one common pixels-per-block); pointwise, strided 1x1, strided 3x3 and narrow-row 3x3 layers side by side
+    (the kernel's three addressing modes in one launch)."""
     hip = _hip()
     torch.manual_seed(len(layers) + dt)
-    xs = [dev(torch.relu(torch.randn(M, C)), dt) for M, C, N in layers]
-    dzs = [dev(torch.randn(M, N), dt) for M, C, N in layers]
-    grp = hip.WgradGroup(layers, dt)
-    assert grp.nblocks > 0 and grp.nblocks <= 512 and all(s >= 1 for s in grp.splits)
-    solo = [hip.conv_wgrad_splits(hip.geom(1, 1, M, C, 1, M, N, 1, 1, 1, 1, 0, 0), dt) for M, C, N in layers]
-    assert all(s <= t for s, t in zip(grp.splits, solo)) and (sum(grp.splits) < sum(solo) or layers[0][0] <= 4096)   # (short layers: 8 steps per block either way)
-    wss = [torch.full((s * (C * N + hip.WGRAD_PART_PAD) + s * N + 64,), 7.0, dtype=torch.float32, device="cuda") for s, (M, C, N) in zip(grp.splits, layers)]
+    geoms = [hip.geom(*l) for l in layers]
+    xs = [dev(torch.relu(torch.randn(g.B, g.H, g.W, g.C)), dt) for g in geoms]
+    dzs = [dev(torch.randn(g.B, g.OH, g.OW, g.N), dt) for g in geoms]
+    grp = hip.WgradGroup(geoms, dt)
+    assert grp.nblocks > 0 and grp.nblocks <= 512 and all(s >= 1 for s in grp.splits) and 0.0 < grp.fill <= 1.0
+    assert grp.fill > 0.6 or layers[0][2] < 40960              # (the small groups cannot fill 512 slots with >= 8 steps per block)
+    solo = [hip.conv_wgrad_splits(g, dt) for g in geoms]
+    assert all(s <= t for s, t in zip(grp.splits, solo)) and (sum(grp.splits) < sum(solo) or layers[0][2] <= 4096)   # (short layers: 8 steps per block either way)
+    KN = [g.KH * g.KW * g.C * g.N for g in geoms]
+    wss = [torch.full((s * (kn + hip.WGRAD_PART_PAD) + s * g.N + 64,), 7.0, dtype=torch.float32, device="cuda") for s, kn, g in zip(grp.splits, KN, geoms)]
     grp.bind(xs, dzs, wss, "cuda")
     grp.run()
     torch.cuda.synchronize()
-    for i, (M, C, N) in enumerate(layers):
-        s = grp.splits[i]
-        stride = C * N + hip.WGRAD_PART_PAD
-        part = torch.stack([wss[i][k * stride:k * stride + C * N] for k in range(s)]).double().sum(0).reshape(C, N)
-        col = wss[i][s * stride:s * stride + s * N].reshape(s, N).double().sum(0)
-        ref = xs[i].double().t() @ dzs[i].double()
-        assert relerr(part, ref) < 5e-5, (i, relerr(part, ref))
-        assert relerr(col, dzs[i].double().sum(0)) < 5e-5
-        g = hip.geom(1, 1, M, C, 1, M, N, 1, 1, 1, 1, 0, 0)
+    for i, g in enumerate(geoms):
+        s, stride = grp.splits[i], KN[i] + hip.WGRAD_PART_PAD
+        part = torch.stack([wss[i][k * stride:k * stride + KN[i]] for k in range(s)]).double().sum(0).reshape(-1, g.N)
+        col = wss[i][s * stride:s * stride + s * g.N].reshape(s, g.N).double().sum(0)
+        assert relerr(col, dzs[i].double().sum(dim=(0, 1, 2))) < 5e-5
+        if g.KH == 1 and g.SH == 1:
+            ref = xs[i].double().reshape(-1, g.C).t() @ dzs[i].double().reshape(-1, g.N)
+            assert relerr(part, ref) < 5e-5, (i, relerr(part, ref))
         ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
-        dw = torch.empty(C, N, dtype=torch.float32, device="cuda"); cs = torch.empty(N, dtype=torch.float32, device="cuda")
+        dw = torch.empty(part.shape, dtype=torch.float32, device="cuda"); cs = torch.empty(g.N, dtype=torch.float32, device="cuda")
         hip.conv_wgrad(g, dt, xs[i], dzs[i], ws, dw, cs)
         torch.cuda.synchronize()
-        assert relerr(part, dw.double()) < 5e-5
+        assert float(dw.abs().max()) > 0 and relerr(part, dw.double()) < 5e-5, (i, relerr(part, dw.double()))
     # the same launch again gives the same bits (fixed work list, no atomics)
     before = [w.clone() for w in wss]
     grp.run()
@@ -1459,8 +1469,9 @@ def test_grouped_pointwise_weight_gradients(dt, layers):
 
 def test_grouped_weight_gradient_plan_refuses_what_cannot_be_resident():
     hip = _hip()
-    assert hip.WgradGroup([(4096, 2048, 2048)] * 3, 1).nblocks == 0          # 3 x 256 tiles > 512 resident blocks
+    assert hip.WgradGroup([hip.geom(*_pw(4096, 2048, 2048))] * 3, 1).nblocks == 0          # 3 x 256 tiles > 512 resident blocks
     g = hip.geom(32, 32, 40, 256, 32, 40, 1024, 1, 1, 1, 1, 0, 0)
     assert hip.wgrad_group_fits(g, 1) and not hip.wgrad_group_fits(g, 0)
-    assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 256, 3, 3, 1, 1, 1, 1), 1)
-    assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 64, 1, 1, 1, 1, 0, 0), 1)
+    assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 256, 3, 3, 1, 1, 1, 1), 1)     # conv_hwgrad.hip's layer
+    assert hip.wgrad_group_fits(hip.geom(32, 64, 80, 256, 32, 40, 256, 3, 3, 2, 2, 1, 1), 1)         # a strided 3x3 layer
+    assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 64, 1, 1, 1, 1, 0, 0), 1)      # <= 64 filters: the narrow kernel

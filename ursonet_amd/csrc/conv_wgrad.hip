@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     wgrad_tr_body<T, MODE, PIPE>(a, xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, a.ktiles * a.ntiles * a.splits), smem);
 }
 
-// Several pointwise layers' weight gradients in ONE launch (urso_wgrad_group_run).  A layer on its own is cut into ~2 blocks per CU,
+// Several layers' weight gradients in ONE launch (urso_wgrad_group_run).  A layer on its own is cut into ~2 blocks per CU,
 // i.e. CUs x 128 KiB of fp32 partials written at the end of the launch and read again by the split reduction -- as many bytes as
 // the layer's operands in stages 4-5.  With G layers sharing the launch every layer gets 1/G of the splits: the blocks run G times
 // longer over their pixels and the partial traffic (and the write burst that nothing overlaps) drops by G.
@@ -459,13 +459,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const urso_wgrad_it
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 256];
     const int li = map[2 * blockIdx.x], wid = map[2 * blockIdx.x + 1];
     const urso_wgrad_item& it = items[li];
+    const urso_conv_geom& g = it.g;
     WgradArgs a;
     a.x = it.x; a.dz = it.dz; a.part = it.part; a.colpart = it.colpart;
-    a.x_bytes = (uint32_t)it.M * (uint32_t)it.C * 2u; a.dz_bytes = (uint32_t)it.M * (uint32_t)it.N * 2u;
-    a.C = it.C; a.N = it.N; a.M = it.M; a.Cc = it.C / 8; a.Kc = a.Cc; a.K = it.C;
+    a.B = g.B; a.H = g.H; a.W = g.W; a.C = g.C; a.OH = g.OH; a.OW = g.OW; a.N = g.N;
+    a.KH = g.KH; a.KW = g.KW; a.SH = g.SH; a.SW = g.SW; a.PH = g.PH; a.PW = g.PW;
+    a.zs = g.FH > 0 ? 1 : 0; a.ZH = g.FH; a.ZW = g.FW; a.zsh = g.OSH; a.zsw = g.OSW;
+    a.x_bytes = (uint32_t)g.B * (uint32_t)g.H * (uint32_t)g.W * (uint32_t)g.C * 2u;
+    a.dz_bytes = (a.zs ? (uint32_t)g.B * (uint32_t)g.FH * (uint32_t)g.FW : (uint32_t)it.M) * (uint32_t)g.N * 2u;
+    a.M = it.M; a.Cc = g.C / 8; a.Kc = g.KH * g.KW * a.Cc; a.K = a.Kc * 8;
     a.ktiles = it.ktiles; a.ntiles = it.ntiles; a.splits = it.splits; a.m_per_split = it.m_per_split;
-    a.KW = 1; a.OH = 1; a.OW = 1; a.zs = 0;              // (unused by the pointwise form)
-    wgrad_tr_body<T, 0, true>(a, wid, smem);
+    a.rcp_ohw = 1.0f / (float)(g.OH * g.OW); a.rcp_ow = 1.0f / (float)g.OW;
+    if (it.mode == 0) wgrad_tr_body<T, 0, true>(a, wid, smem);
+    else if (it.mode == 1) wgrad_tr_body<T, 1, true>(a, wid, smem);
+    else wgrad_tr_body<T, 2, true>(a, wid, smem);
 }
 
 // Narrow form for layers with at most 64 filters (the 3x3 convs of stage 2, the stem): 128(k) x 64(n) output tile, so no
@@ -890,14 +897,24 @@ extern "C" int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const voi
     return urso_check_launch("urso_stem_wgrad_pooled(reduce)");
 }
 
-// ---- grouped pointwise weight gradients (see wgrad_group_kernel) ----
+// ---- grouped weight gradients (see wgrad_group_kernel) ----
+static bool wg_pointwise(const urso_conv_geom* g) {
+    return g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW;
+}
+static bool wg_zscat_ok(const urso_conv_geom* g) {
+    if (g->FH <= 0) return true;
+    return g->FW > 0 && g->OSH > 0 && g->OSW > 0 && (g->OH - 1) * g->OSH < g->FH && (g->OW - 1) * g->OSW < g->FW && !wg_pointwise(g);
+}
+
 extern "C" int urso_wgrad_group_fits(const urso_conv_geom* g, int dt) {
     if (!g || (dt != URSO_BF16 && dt != URSO_F16)) return 0;
-    const bool pointwise = g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->H == g->OH && g->W == g->OW &&
-                           g->DH == 1 && g->DW == 1 && g->FH == 0;
+    WgradPlan p;
+    if (g->DH != 1 || g->DW != 1 || plan_wgrad(g, dt, p) != URSO_OK || p.narrow || !wg_zscat_ok(g)) return 0;
+    if (urso_stemw_fits(g, dt) || (g->FH <= 0 && (urso_c3g_fits(g, dt) || urso_hwg_fits(g, dt)))) return 0;     // kernels of their own
     const long long M = (long long)g->B * g->OH * g->OW;
-    if (!pointwise || g->C % 8 || g->N % 8 || g->N <= 64 || M < 4096 || M >= (1 << 24)) return 0;
-    if ((unsigned long long)M * g->C * 2 >= 0x7FFFFF00ull || (unsigned long long)M * g->N * 2 >= 0x7FFFFF00ull) return 0;
+    if (M < 4096 || M >= (1 << 24)) return 0;
+    const unsigned long long zpix = g->FH > 0 ? (unsigned long long)g->B * g->FH * g->FW : (unsigned long long)M;
+    if ((unsigned long long)g->B * g->H * g->W * g->C * 2 >= 0x7FFFFF00ull || zpix * g->N * 2 >= 0x7FFFFF00ull) return 0;
     return 1;
 }
 
@@ -913,8 +930,14 @@ extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t
     const int target = (int)((long long)g_urso_opt.wgrad_blocks * urso_usable_cus() / urso_device_cus());
     long long work = 0; int tiles_all = 0, steps_max = 0;
     for (int i = 0; i < n; ++i) {
-        if (it[i].M < 64 || it[i].C <= 0 || it[i].N <= 0 || it[i].C % 8 || it[i].N % 8) { urso_set_error("urso_wgrad_group_plan: item %d: bad M/C/N", i); return -1; }
-        it[i].ktiles = ceil_div(it[i].C, 128); it[i].ntiles = ceil_div(it[i].N, 128);
+        const urso_conv_geom& g = it[i].g;
+        const long long M = (long long)g.B * g.OH * g.OW;
+        if (M < 64 || M >= (1 << 24) || g.C <= 0 || g.N <= 0 || g.C % 8 || g.N % 8 || g.KH < 1 || g.KW < 1 || g.DH != 1 || g.DW != 1 || !wg_zscat_ok(&g)) {
+            urso_set_error("urso_wgrad_group_plan: item %d: geometry outside the 16-bit general kernel", i); return -1;
+        }
+        it[i].M = (int32_t)M;
+        it[i].mode = wg_pointwise(&g) ? 0 : ((64 / g.OW + 1 <= g.OH) ? 1 : 2);       // as urso_conv_wgrad picks it
+        it[i].ktiles = ceil_div(g.KH * g.KW * g.C, 128); it[i].ntiles = ceil_div(g.N, 128);
         const int tiles = it[i].ktiles * it[i].ntiles, steps = ceil_div(it[i].M, 64);
         tiles_all += tiles; work += (long long)tiles * steps; steps_max = steps > steps_max ? steps : steps_max;
     }
@@ -926,19 +949,18 @@ extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t
         for (int i = 0; i < n; ++i) blocks += (long long)it[i].ktiles * it[i].ntiles * ceil_div(ceil_div(it[i].M, 64), s);
         if (blocks <= target || s >= steps_max) break;
     }
-    int nblk = 0;
+    int nblk = 0, longest = 0;
     for (int i = 0; i < n; ++i) {
         const int steps = ceil_div(it[i].M, 64);
         int splits = ceil_div(steps, s);
         const int per = ceil_div(steps, splits);              // balanced within the layer
         splits = ceil_div(steps, per);
-        it[i].splits = splits; it[i].m_per_split = per * 64; it[i].reserved = 0;
+        it[i].splits = splits; it[i].m_per_split = per * 64; it[i].fill = 0;
         nblk += it[i].ktiles * it[i].ntiles * splits;
+        longest = per > longest ? per : longest;
     }
     // how well the plan fills the resident slots: (tile-steps of work) / (slots x the longest block), in 1/1000
-    int longest = 0;
-    for (int i = 0; i < n; ++i) longest = it[i].m_per_split / 64 > longest ? it[i].m_per_split / 64 : longest;
-    it[0].reserved = (int32_t)(work * 1000 / ((long long)target * longest));
+    it[0].fill = (int32_t)(work * 1000 / ((long long)target * longest));
     if (!blockmap_h) return nblk;
     if (cap_blocks < nblk) { urso_set_error("urso_wgrad_group_plan: block map too small"); return -1; }
     // logical work list: item-major, then split, then tile (the tiles of one pixel range are neighbours); physical block b takes
@@ -965,12 +987,15 @@ extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, cons
     double flops = 0, bytes = 0; int cnt = 0;
     for (int i = 0; i < n; ++i) {
         const urso_wgrad_item& t = items_h[i];
+        const urso_conv_geom& g = t.g;
         if (!t.x || !t.dz || !t.part || t.splits < 1 || t.m_per_split < 64 || t.m_per_split % 64 || (long long)t.splits * t.m_per_split < t.M ||
-            ((uintptr_t)t.x | (uintptr_t)t.dz | (uintptr_t)t.part | (uintptr_t)t.colpart) & 15) {
+            t.M != g.B * g.OH * g.OW || (((uintptr_t)t.x | (uintptr_t)t.dz | (uintptr_t)t.part | (uintptr_t)t.colpart) & 15)) {
             urso_set_error("urso_wgrad_group_run: item %d is not planned (urso_wgrad_group_plan) or misaligned", i); return URSO_EINVAL;
         }
-        flops += 2.0 * t.M * (double)t.N * t.C;
-        bytes += 2.0 * t.M * ((double)t.C + t.N) + 4.0 * t.C * t.N;
+        const double K = (double)g.KH * g.KW * g.C;
+        flops += 2.0 * t.M * (double)g.N * K;
+        const double x_alg = (g.KH == 1 && g.KW == 1 && (g.SH > 1 || g.SW > 1)) ? (double)t.M * g.C * 2 : (double)g.B * g.H * g.W * g.C * 2;
+        bytes += x_alg + 2.0 * t.M * g.N + 4.0 * K * g.N;
         cnt += t.ktiles * t.ntiles * t.splits;
     }
     if (cnt != nblocks) { urso_set_error("urso_wgrad_group_run: block map has %d blocks, the items need %d", nblocks, cnt); return URSO_EINVAL; }

@@ -414,7 +414,7 @@ class Engine(object):
                 take = items
                 grp = None
                 while len(take) > 1:
-                    grp = hip.WgradGroup([(g.B * g.OH * g.OW, g.C, g.N) for (_, _, _, _, g) in take], dt)
+                    grp = hip.WgradGroup([t[4] for t in take], dt)
                     if grp.nblocks:
                         break
                     take, grp = take[:len(take) - 1], None           # more tiles than resident blocks: a smaller group
@@ -552,11 +552,11 @@ class Engine(object):
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 if not by_pair:
                     xw = c.xin if gf_w is c.gf else c.src.data
-                    if wg_max > 1 and hip.wgrad_group_fits(gf_w, dt) and gf_w.C == c.K_raw and gf_w.N == c.npad:
-                        # a pointwise layer: its weight gradient waits for company (see flush_wgrads); every tensor has a gradient
+                    if wg_max > 1 and hip.wgrad_group_fits(gf_w, dt) and gf_w.KH * gf_w.KW * gf_w.C == c.K_raw and gf_w.N == c.npad:
+                        # a layer of the general kernel: its weight gradient waits for company (see flush_wgrads); every tensor has a gradient
                         # buffer of its own, so G is still there when the launch comes
                         cand = pend_wg + [(c, node.name, xw, G, gf_w)]
-                        if len(cand) > 1 and hip.WgradGroup([(g.B * g.OH * g.OW, g.C, g.N) for (_, _, _, _, g) in cand], dt).fill < wg_fill:
+                        if len(cand) > 1 and hip.WgradGroup([t[4] for t in cand], dt).fill < wg_fill:
                             flush_wgrads()                 # the newcomer's tile count / pixel count does not divide the slots well
                         pend_wg.append(cand[-1])
                         if len(pend_wg) >= wg_max:

@@ -316,9 +316,9 @@ class ParamBatch(object):
 
 class WgradItem(C.Structure):
     """urso_wgrad_item (include/ursonet_hip.h)."""
-    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("part", C.c_void_p), ("colpart", C.c_void_p),
-                ("M", C.c_int32), ("C", C.c_int32), ("N", C.c_int32),
-                ("ktiles", C.c_int32), ("ntiles", C.c_int32), ("splits", C.c_int32), ("m_per_split", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("part", C.c_void_p), ("colpart", C.c_void_p), ("g", ConvGeom),
+                ("M", C.c_int32), ("ktiles", C.c_int32), ("ntiles", C.c_int32), ("splits", C.c_int32), ("m_per_split", C.c_int32),
+                ("mode", C.c_int32), ("fill", C.c_int32)]
 
 
 def wgrad_group_fits(g, dt):
@@ -326,22 +326,23 @@ def wgrad_group_fits(g, dt):
 
 
 class WgradGroup(object):
-    """The weight gradients of several pointwise 16-bit layers in one launch (urso_wgrad_group_plan / _run).
+    """The weight gradients of several 16-bit layers in one launch (urso_wgrad_group_plan / _run).
 
-    shapes: [(M, C, N)].  After construction .splits[i] holds each layer's partial count (0 blocks: .nblocks == 0, the group does
-    not fit one residency); bind() takes the operand / workspace tensors (partials laid out as urso_conv_wgrad_partial does)."""
+    geoms: the layers' forward geometries.  After construction .splits[i] holds each layer's partial count and .fill the fraction of
+    the resident block slots the plan keeps busy (.nblocks == 0: the group does not fit one residency); bind() takes the operand /
+    workspace tensors (partials laid out as urso_conv_wgrad_partial does)."""
 
-    def __init__(self, shapes, dt):
-        self.n, self.dt = len(shapes), dt
+    def __init__(self, geoms, dt):
+        self.n, self.dt = len(geoms), dt
         self.host = (WgradItem * self.n)()
-        for it, (M, Cin, N) in zip(self.host, shapes):
-            it.M, it.C, it.N = int(M), int(Cin), int(N)
+        for it, g in zip(self.host, geoms):
+            C.memmove(C.byref(it.g), C.byref(g), C.sizeof(ConvGeom))
         nb = _lib.urso_wgrad_group_plan(self.n, self.host, dt, None, 0)
         if nb < 0:
             raise UrsoHipError("urso_wgrad_group_plan: " + last_error())
         self.nblocks = nb
         self.splits = [int(it.splits) for it in self.host] if nb else []
-        self.fill = self.host[0].reserved / 1000.0 if nb else 0.0     # work / (resident slots x the longest block)
+        self.fill = self.host[0].fill / 1000.0 if nb else 0.0     # work / (resident slots x the longest block)
         self.dev = self.map = None
 
     def bind(self, xs, dzs, wss, device):
@@ -349,8 +350,8 @@ class WgradGroup(object):
         if _lib.urso_wgrad_group_plan(self.n, self.host, self.dt, buf, self.nblocks) != self.nblocks:
             raise UrsoHipError("urso_wgrad_group_plan: " + last_error())
         for it, x, dz, ws in zip(self.host, xs, dzs, wss):
-            n_part = it.splits * (it.C * it.N + WGRAD_PART_PAD)
-            if ws.numel() * ws.element_size() < 4 * (n_part + it.splits * it.N):
+            n_part = it.splits * (it.g.KH * it.g.KW * it.g.C * it.g.N + WGRAD_PART_PAD)
+            if ws.numel() * ws.element_size() < 4 * (n_part + it.splits * it.g.N):
                 raise UrsoHipError("WgradGroup.bind: workspace too small")
             it.x, it.dz, it.part, it.colpart = x.data_ptr(), dz.data_ptr(), ws.data_ptr(), ws.data_ptr() + 4 * n_part
         self.keep = (list(xs), list(dzs), list(wss))
