@@ -362,6 +362,17 @@ int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, const urso_wgra
                          const int32_t* blockmap_d, int nblocks, void* stream);
 
 /*
+ * Two 3x3 / stride-1 layers of the register-resident weight-gradient kernel (conv_hwgrad.hip; C and N multiples of 64) in one launch,
+ * the CUs shared in proportion to their work: each layer writes half as many partials as urso_conv_wgrad_partial would.
+ *   urso_conv_wgrad_pair_splits : 1 and the two partial counts when the layers qualify as a pair, else 0
+ *   urso_conv_wgrad_partial2    : the launch; workspaces laid out as urso_conv_wgrad_partial does, with those partial counts
+ */
+int urso_conv_wgrad_pair_splits(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, int* splits0, int* splits1);
+int urso_conv_wgrad_partial2(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt,
+                             const void* x0_d, const void* dz0_d, void* ws0_d, size_t ws0_bytes,
+                             const void* x1_d, const void* dz1_d, void* ws1_d, size_t ws1_bytes, void* stream);
+
+/*
  * Batch-statistics BatchNorm (TRAIN_BN = None, "Train BN layers": the BatchNorm wrapper net.py:60-76 forwards
  * training=None, i.e. Keras' learning phase).  Secondary mode of the reference (config.py:146 defaults to frozen and the
  * CLI never changes it): the BN cannot be folded into the filter, so the conv writes its raw output z [M pixels][N] and

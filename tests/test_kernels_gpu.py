@@ -1475,3 +1475,35 @@ def test_grouped_weight_gradient_plan_refuses_what_cannot_be_resident():
     assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 256, 3, 3, 1, 1, 1, 1), 1)     # conv_hwgrad.hip's layer
     assert hip.wgrad_group_fits(hip.geom(32, 64, 80, 256, 32, 40, 256, 3, 3, 2, 2, 1, 1), 1)         # a strided 3x3 layer
     assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 64, 1, 1, 1, 1, 0, 0), 1)      # <= 64 filters: the narrow kernel
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shapes", [((4, 32, 40, 256, 256), (4, 32, 40, 256, 256)), ((4, 33, 41, 128, 128), (3, 17, 23, 256, 128)),
+                                    ((8, 64, 80, 128, 128), (8, 32, 40, 256, 256))],
+                         ids=["twins", "ragged_unequal", "stage3_with_stage4"])
+def test_two_3x3_weight_gradients_in_one_launch(dt, shapes):
+    """urso_conv_wgrad_partial2 (conv_hwgrad.hip: hwgrad2_kernel): two register-resident 3x3 weight gradients share a launch, the CUs split in
+    proportion to their work; each layer's partials (fewer than alone) reduce to what urso_conv_wgrad gives for the layer alone."""
+    hip = _hip()
+    torch.manual_seed(dt + shapes[0][3])
+    gs = [hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1) for (B, H, W, C, N) in shapes]
+    sp = hip.conv_wgrad_pair_splits(gs[0], gs[1], dt)
+    assert sp is not None and all(1 <= s <= hip.conv_wgrad_splits(g, dt) for s, g in zip(sp, gs))
+    assert sum(sp) < sum(hip.conv_wgrad_splits(g, dt) for g in gs)
+    xs = [dev(torch.relu(torch.randn(g.B, g.H, g.W, g.C)), dt) for g in gs]
+    dzs = [dev(torch.randn(g.B, g.H, g.W, g.N), dt) for g in gs]
+    KN = [9 * g.C * g.N for g in gs]
+    wss = [torch.full((s * (kn + hip.WGRAD_PART_PAD) + s * g.N + 64,), 7.0, dtype=torch.float32, device="cuda") for s, kn, g in zip(sp, KN, gs)]
+    hip.conv_wgrad_partial2(gs[0], gs[1], dt, xs[0], dzs[0], wss[0], xs[1], dzs[1], wss[1])
+    torch.cuda.synchronize()
+    for i, g in enumerate(gs):
+        s, stride = sp[i], KN[i] + hip.WGRAD_PART_PAD
+        part = torch.stack([wss[i][k * stride:k * stride + KN[i]] for k in range(s)]).double().sum(0).reshape(-1, g.N)
+        col = wss[i][s * stride:s * stride + s * g.N].reshape(s, g.N).double().sum(0)
+        ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 16, dtype=torch.float32, device="cuda")
+        dw = torch.empty(part.shape, dtype=torch.float32, device="cuda"); cs = torch.empty(g.N, dtype=torch.float32, device="cuda")
+        hip.conv_wgrad(g, dt, xs[i], dzs[i], ws, dw, cs)
+        torch.cuda.synchronize()
+        assert float(dw.abs().max()) > 0 and relerr(part, dw.double()) < 5e-5, (i, relerr(part, dw.double()))
+        assert relerr(col, cs.double()) < 5e-5
+    assert hip.conv_wgrad_pair_splits(gs[0], hip.geom(4, 32, 40, 64, 32, 40, 64, 3, 3, 1, 1, 1, 1), dt) is None      # conv_c3g.hip's layer

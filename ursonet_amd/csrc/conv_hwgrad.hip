@@ -56,7 +56,9 @@ __device__ __forceinline__ void hw_dma16(const i32x4_t& rsrc, uint32_t lds_byte,
 }
 __device__ __forceinline__ i32x4_t hw_rsrc(const void* p, uint32_t bytes) {
     const uint64_t a = (uint64_t)p;
-    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+    // (readfirstlane: the paired launch selects its argument set per block, and the selects are not always proven wave-uniform)
+    return i32x4_t{__builtin_amdgcn_readfirstlane((int)(uint32_t)a), __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu)),
+                   __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
 }
 
 // one tile's 8 reduction steps (16 pixels each) for a wave of tap group TG; abase[i] = this lane's read base of tap 5 TG + i.  The
@@ -98,16 +100,15 @@ __device__ __forceinline__ void hw_tile(const char* st, f32x16_t (&acc)[5], cons
 }
 
 template <typename T>
-__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgArgs a) {
+__device__ __forceinline__ void hwgrad_body(const HwgArgs& a, const int bid, const int nblk, char* smem) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ __attribute__((aligned(1024))) char smem[HW_LDS + 2 * HW_TBL * 4];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ct = wave & 1, nt = (wave >> 1) & 1, tg = wave >> 2;
     const int l31 = lane & 31, h = lane >> 5, l15 = lane & 15, g = lane >> 4;
 
     // logical id (XCD-contiguous), group index fastest: the groups of one split (same pixels) run side by side behind one L2
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = xcd_remap(bid, nblk);
     const int grp = lid % a.G, sp = lid / a.G;
     const int cg = grp / a.Gn, ng = grp - cg * a.Gn;
     const int t0 = (int)(((long long)sp * a.T) / a.S), t1 = (int)(((long long)(sp + 1) * a.T) / a.S);
@@ -231,6 +232,40 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgArgs a) {
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[HW_LDS + 2 * HW_TBL * 4];
+    hwgrad_body<T>(a, blockIdx.x, gridDim.x, smem);
+}
+
+// Two layers in one launch, half of the CUs each (urso_hwg_launch2): a layer on its own writes one fp32 partial of its (64 x 64 x 9)
+// group per CU -- 38 MB however small the layer, re-read by the split reduction; two layers sharing the CUs write half of that each, and
+// the write burst at the end of the launch comes once for both.  (Two, not more: the block's pixel-offset tables hold two layers' share
+// of the pixels, not three.)
+template <typename T>
+__global__ __launch_bounds__(512, 2) void hwgrad2_kernel(const HwgArgs a0, const HwgArgs a1, const int n0) {
+    __shared__ __attribute__((aligned(1024))) char smem[HW_LDS + 2 * HW_TBL * 4];
+    const bool second = (int)blockIdx.x >= n0;
+    // field-by-field scalar selects (a select of the whole struct goes through a stack copy)
+    auto pi = [&](int u, int v) { return __builtin_amdgcn_readfirstlane(second ? v : u); };
+    auto pf = [&](float u, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, second ? v : u))); };
+    auto pp = [&](const void* u, const void* v) {
+        const uint64_t w = (uint64_t)(second ? v : u);
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32)) << 32);
+    };
+    HwgArgs a;
+    a.x = (const void*)pp(a0.x, a1.x); a.dz = (const void*)pp(a0.dz, a1.dz);
+    a.part = (float*)pp(a0.part, a1.part); a.colpart = (float*)pp(a0.colpart, a1.colpart);
+    a.part_stride = (size_t)pp((const void*)a0.part_stride, (const void*)a1.part_stride);
+    a.x_bytes = (uint32_t)pi((int)a0.x_bytes, (int)a1.x_bytes); a.dz_bytes = (uint32_t)pi((int)a0.dz_bytes, (int)a1.dz_bytes);
+    a.B = pi(a0.B, a1.B); a.H = pi(a0.H, a1.H); a.W = pi(a0.W, a1.W); a.C = pi(a0.C, a1.C); a.N = pi(a0.N, a1.N);
+    a.Vw = pi(a0.Vw, a1.Vw); a.Vh = pi(a0.Vh, a1.Vh); a.Mv = pi(a0.Mv, a1.Mv); a.dbg = pi(a0.dbg, a1.dbg);
+    a.T = pi(a0.T, a1.T); a.G = pi(a0.G, a1.G); a.Gn = pi(a0.Gn, a1.Gn); a.S = pi(a0.S, a1.S); a.R = pi(a0.R, a1.R);
+    a.rcp_vw = pf(a0.rcp_vw, a1.rcp_vw); a.rcp_vh = pf(a0.rcp_vh, a1.rcp_vh);
+    hwgrad_body<T>(a, second ? (int)blockIdx.x - n0 : (int)blockIdx.x, second ? (int)gridDim.x - n0 : n0, smem);
+}
+
+
 // 3x3 / stride 1 / pad 1, C and N multiples of 64 (not both 64: conv_c3g.hip), dense dz, 16-bit, halo run within the LDS budget, at least
 // one block per group (option hwgrad, default 1)
 bool urso_hwg_fits(const urso_conv_geom* g, int dt) {
@@ -254,17 +289,60 @@ int urso_hwg_splits(const urso_conv_geom* g) {
     if (S > T) S = T;
     return S < 1 ? 1 : S;
 }
-int urso_hwg_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st) {
-    HwgArgs a;
+static void hwg_fill(HwgArgs& a, const urso_conv_geom* g, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, int S) {
     a.x = x; a.dz = dz; a.part = part; a.colpart = colpart; a.part_stride = part_stride;
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.N = g->N;
     a.x_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2); a.dz_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->N * 2);
     a.Vw = g->W + 1; a.Vh = g->H + 1; a.Mv = g->B * a.Vh * a.Vw;
-    a.T = ceil_div(a.Mv, HW_TP); a.Gn = g->N / 64; a.G = (g->C / 64) * a.Gn; a.S = urso_hwg_splits(g);
+    a.T = ceil_div(a.Mv, HW_TP); a.Gn = g->N / 64; a.G = (g->C / 64) * a.Gn; a.S = S;
     a.R = HW_TP + 2 * (a.Vw + 1);
     a.rcp_vw = 1.0f / (float)a.Vw; a.rcp_vh = 1.0f / (float)a.Vh; a.dbg = g_urso_opt.hwgrad >> 1;
+}
+int urso_hwg_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st) {
+    HwgArgs a;
+    hwg_fill(a, g, x, dz, part, colpart, part_stride, urso_hwg_splits(g));
     const dim3 grid(a.G * a.S), blk(512);
     if (dt == URSO_BF16) URSO_KLAUNCH((hwgrad_kernel<__bf16>), grid, blk, 0, st, a);
     else URSO_KLAUNCH((hwgrad_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_wgrad(halo)");
+}
+
+// The pair: the CUs are shared in proportion to the layers' work (tiles x groups), rounded to whole splits; 0 splits = the pair does not
+// qualify (a layer alone does not, a share smaller than one split per group, or a block's pixel range beyond its offset tables).
+bool urso_hwg_pair_splits(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, int* s0, int* s1) {
+    *s0 = *s1 = 0;
+    if (!urso_hwg_fits(g0, dt) || !urso_hwg_fits(g1, dt)) return false;
+    const int cus = urso_usable_cus();
+    const urso_conv_geom* gs[2] = {g0, g1};
+    long long w[2]; int G[2], T[2], S[2];
+    for (int i = 0; i < 2; ++i) {
+        G[i] = (gs[i]->C / 64) * (gs[i]->N / 64);
+        T[i] = ceil_div(gs[i]->B * (gs[i]->H + 1) * (gs[i]->W + 1), HW_TP);
+        w[i] = (long long)G[i] * T[i];
+    }
+    S[0] = (int)((cus * w[0] / (w[0] + w[1])) / G[0]);
+    if (S[0] > T[0]) S[0] = T[0];
+    // the second layer's blocks should start on XCD 0 (its own XCD-contiguous order assumes block i sits on XCD i % 8)
+    for (int k = 0; k < 7 && S[0] > 1 && (G[0] * S[0]) % 8; ++k) --S[0];
+    S[1] = (cus - S[0] * G[0]) / G[1];
+    for (int i = 0; i < 2; ++i) {
+        if (S[i] > T[i]) S[i] = T[i];
+        if (S[i] < 1) return false;
+        if (ceil_div(T[i], S[i]) * HW_TP + HW_TP + 2 * (gs[i]->W + 2) + 8 > HW_TBL) return false;
+    }
+    *s0 = S[0]; *s1 = S[1];
+    return true;
+}
+int urso_hwg_launch2(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, const void* x0, const void* dz0, float* part0, float* colpart0,
+                     const void* x1, const void* dz1, float* part1, float* colpart1, hipStream_t st) {
+    int s0, s1;
+    if (!urso_hwg_pair_splits(g0, g1, dt, &s0, &s1)) { urso_set_error("urso_conv_wgrad_partial2: the two layers do not qualify as a pair"); return URSO_EINVAL; }
+    HwgArgs a0, a1;
+    hwg_fill(a0, g0, x0, dz0, part0, colpart0, (size_t)9 * g0->C * g0->N + URSO_WGRAD_PART_PAD, s0);
+    hwg_fill(a1, g1, x1, dz1, part1, colpart1, (size_t)9 * g1->C * g1->N + URSO_WGRAD_PART_PAD, s1);
+    const int n0 = a0.G * a0.S;
+    const dim3 grid(n0 + a1.G * a1.S), blk(512);
+    if (dt == URSO_BF16) URSO_KLAUNCH((hwgrad2_kernel<__bf16>), grid, blk, 0, st, a0, a1, n0);
+    else URSO_KLAUNCH((hwgrad2_kernel<_Float16>), grid, blk, 0, st, a0, a1, n0);
+    return urso_check_launch("urso_conv_wgrad_partial2");
 }

@@ -715,6 +715,9 @@ int urso_c3g_launch(const urso_conv_geom* g, int dt, const void* x, const void* 
 bool urso_hwg_fits(const urso_conv_geom* g, int dt);
 int urso_hwg_splits(const urso_conv_geom* g);
 int urso_hwg_launch(const urso_conv_geom* g, int dt, const void* x, const void* dz, float* part, float* colpart, size_t part_stride, hipStream_t st);
+bool urso_hwg_pair_splits(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, int* s0, int* s1);
+int urso_hwg_launch2(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, const void* x0, const void* dz0, float* part0, float* colpart0,
+                     const void* x1, const void* dz1, float* part1, float* colpart1, hipStream_t st);
 
 static int plan_wgrad(const urso_conv_geom* g, int dt, WgradPlan& p) {
     const int es = (int)dt_size(dt);
@@ -1004,4 +1007,38 @@ extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, cons
     if (dt == URSO_BF16) URSO_KLAUNCH(wgrad_group_kernel<__bf16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
     else URSO_KLAUNCH(wgrad_group_kernel<_Float16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
     return urso_check_launch("urso_wgrad_group_run");
+}
+
+// ---- two register-resident 3x3 weight gradients in one launch (conv_hwgrad.hip: hwgrad2_kernel) ----
+extern "C" int urso_conv_wgrad_pair_splits(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt, int* splits0, int* splits1) {
+    int s0 = 0, s1 = 0;
+    const bool ok = g0 && g1 && urso_hwg_pair_splits(g0, g1, dt, &s0, &s1);
+    if (splits0) *splits0 = s0;
+    if (splits1) *splits1 = s1;
+    return ok ? 1 : 0;
+}
+
+extern "C" int urso_conv_wgrad_partial2(const urso_conv_geom* g0, const urso_conv_geom* g1, int dt,
+                                        const void* x0_d, const void* dz0_d, void* ws0_d, size_t ws0_bytes,
+                                        const void* x1_d, const void* dz1_d, void* ws1_d, size_t ws1_bytes, void* stream) {
+    if (!g0 || !g1 || !x0_d || !dz0_d || !ws0_d || !x1_d || !dz1_d || !ws1_d) { urso_set_error("urso_conv_wgrad_partial2: null argument"); return URSO_EINVAL; }
+    int s[2];
+    if (!urso_hwg_pair_splits(g0, g1, dt, &s[0], &s[1])) { urso_set_error("urso_conv_wgrad_partial2: the two layers do not qualify as a pair (urso_conv_wgrad_pair_splits)"); return URSO_EINVAL; }
+    const urso_conv_geom* gs[2] = {g0, g1};
+    void* ws[2] = {ws0_d, ws1_d}; const size_t wb[2] = {ws0_bytes, ws1_bytes};
+    float* part[2]; float* colpart[2];
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+        const size_t kn = (size_t)9 * gs[i]->C * gs[i]->N;
+        const size_t need = ((size_t)s[i] * (kn + URSO_WGRAD_PART_PAD) + (size_t)s[i] * gs[i]->N) * sizeof(float);
+        if (wb[i] < need) { urso_set_error("urso_conv_wgrad_partial2: workspace %d: %zu < %zu", i, wb[i], need); return URSO_EWORKSPACE; }
+        if (((uintptr_t)ws[i]) & 15) { urso_set_error("urso_conv_wgrad_partial2: workspaces must be 16-byte aligned"); return URSO_EINVAL; }
+        part[i] = (float*)ws[i]; colpart[i] = part[i] + (size_t)s[i] * (kn + URSO_WGRAD_PART_PAD);
+        const double M = (double)gs[i]->B * gs[i]->H * gs[i]->W;
+        flops += 2.0 * M * gs[i]->N * 9.0 * gs[i]->C;
+        bytes += 2.0 * M * (gs[i]->C + gs[i]->N) + 4.0 * kn;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
+    return urso_hwg_launch2(g0, g1, dt, x0_d, dz0_d, part[0], colpart[0], x1_d, dz1_d, part[1], colpart[1], st);
 }

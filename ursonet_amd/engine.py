@@ -407,6 +407,27 @@ class Engine(object):
             self.bwd_ops.append((name, lambda: hip.conv_wgrad_partial(gf_w, dt, xw, G, c.wg_ws)))
             self.labels["bwd"].append("wgrad:" + name)
 
+        pend_hw = []
+        wg_pair3 = wg_max > 1 and int(os.environ.get("URSO_WGRAD_PAIR3X3", "1")) != 0
+
+        def flush_hw_pair():
+            items = list(pend_hw)
+            del pend_hw[:]
+            sp = hip.conv_wgrad_pair_splits(items[0][4], items[1][4], dt) if len(items) == 2 else None
+            if sp is None:
+                for t in items:
+                    emit_wgrad(*t)
+                return
+            for (c, _, _, _, _), s_ in zip(items, sp):
+                assert s_ <= c.splits
+                c.splits = c.desc.splits = s_
+                c.wg_npart = s_ * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
+                c.desc.part, c.desc.colpart = c.wg_ws.data_ptr(), c.wg_ws.data_ptr() + 4 * c.wg_npart
+            (c0, n0, x0, G0, g0), (c1, n1, x1, G1, g1) = items
+            self.bwd_ops.append(((n0, n1), lambda: hip.conv_wgrad_partial2(g0, g1, dt, x0, G0, c0.wg_ws, x1, G1, c1.wg_ws)))
+            self.labels["bwd"].append("wgrad:%s+%s" % (n0, n1))
+            self.n_wgrad_groups += 1
+
         def flush_wgrads():
             items = list(pend_wg)
             del pend_wg[:]
@@ -552,7 +573,12 @@ class Engine(object):
                 d.gbeta = hip.ptr(self.gview(node.bn, "beta").reshape(-1)) if (node.bn and not c.batch_bn) else None
                 if not by_pair:
                     xw = c.xin if gf_w is c.gf else c.src.data
-                    if wg_max > 1 and hip.wgrad_group_fits(gf_w, dt) and gf_w.KH * gf_w.KW * gf_w.C == c.K_raw and gf_w.N == c.npad:
+                    if wg_pair3 and gf_w.KH * gf_w.KW * gf_w.C == c.K_raw and gf_w.N == c.npad and hip.conv_wgrad_pair_splits(gf_w, gf_w, dt):
+                        # a 3x3 layer of the register-resident kernel: two of them share a launch and the CUs (urso_conv_wgrad_partial2)
+                        pend_hw.append((c, node.name, xw, G, gf_w))
+                        if len(pend_hw) == 2:
+                            flush_hw_pair()
+                    elif wg_max > 1 and hip.wgrad_group_fits(gf_w, dt) and gf_w.KH * gf_w.KW * gf_w.C == c.K_raw and gf_w.N == c.npad:
                         # a layer of the general kernel: its weight gradient waits for company (see flush_wgrads); every tensor has a gradient
                         # buffer of its own, so G is still there when the launch comes
                         cand = pend_wg + [(c, node.name, xw, G, gf_w)]
@@ -566,6 +592,7 @@ class Engine(object):
                         self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
                     flush_wgrads()                         # the bucket's reduction reads every partial of the bucket
+                    flush_hw_pair()
                     k = last_of_group[node.name]
                     pending_groups.append((k, tuple(groups[k]), len(self.bwd_ops)))
                     for ph, nm in ((hip.PB_REDUCE, "reduce"), (hip.PB_FINALIZE_MAT, "finalize_mat"), (hip.PB_FINALIZE_VEC, "finalize_vec")):
@@ -644,6 +671,7 @@ class Engine(object):
                             Sc.wgrad_by_pair = Sc.dgrad_done_by_pair = True
                             dxin = Sc.src.grad_buf()
                             Sc.src.grad_written = True
+                            dstg.zero_()                   # dL/dX never reaches memory in this form: the buffer stays what it is (zeros, not whatever the allocator left)
                             self.bwd_ops.append((None, lambda c=c, A=A, Sc=Sc, G=G, add=add, X=X, dst2=dst2, dxin=dxin:
                                                  hip.conv_pair_wgrad_entry(A.Mpix, dt, G, c.wd, add, X.bits, A.wd, A.src.data, dst2, Sc.wd, Sc.src.data, Sc.src.spec.relu, dxin,
                                                                            A.wg_ws, A.wg_ws[A.wg_npart:], Sc.wg_ws, Sc.wg_ws[Sc.wg_npart:],
@@ -679,6 +707,7 @@ class Engine(object):
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         flush_wgrads()
+        flush_hw_pair()
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
         self._upload_param_table()
         resolved, labels = [], []

@@ -91,6 +91,8 @@ _SIGS = {
     "urso_param_desc_init": (_i, [_dp, _i, _i, _i, _i, _i, _i, _f, _f]),
     "urso_param_batch_plan": (_i, [_i, _dp, C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _i]),
     "urso_wgrad_group_fits": (_i, [_gp, _i]),
+    "urso_conv_wgrad_pair_splits": (_i, [_gp, _gp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "urso_conv_wgrad_partial2": (_i, [_gp, _gp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     "urso_wgrad_group_plan": (_i, [_i, _vp, _i, C.POINTER(C.c_int32), _i]),
     "urso_wgrad_group_run": (_i, [_i, _vp, _vp, _i, _vp, _i, _vp]),
     "urso_param_batch_run": (_i, [_i, _i, _vp, _vp, _i, _vp]),
@@ -312,6 +314,18 @@ class ParamBatch(object):
         t, nb = self.maps[(phase, key)]
         if nb:
             _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
+
+
+def conv_wgrad_pair_splits(g0, g1, dt):
+    """(splits0, splits1) of urso_conv_wgrad_partial2 for two 3x3 layers of conv_hwgrad.hip, or None when they do not pair."""
+    a, b = C.c_int(0), C.c_int(0)
+    ok = _lib.urso_conv_wgrad_pair_splits(C.byref(g0), C.byref(g1), dt, C.byref(a), C.byref(b))
+    return (a.value, b.value) if ok else None
+
+
+def conv_wgrad_partial2(g0, g1, dt, x0, dz0, ws0, x1, dz1, ws1, stream=None):
+    _chk(_lib.urso_conv_wgrad_partial2(C.byref(g0), C.byref(g1), dt, ptr(x0), ptr(dz0), ptr(ws0), ws0.numel() * ws0.element_size(),
+                                       ptr(x1), ptr(dz1), ptr(ws1), ws1.numel() * ws1.element_size(), stream_ptr(stream)), "urso_conv_wgrad_partial2")
 
 
 class WgradItem(C.Structure):
