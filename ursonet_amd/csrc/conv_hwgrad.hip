@@ -32,7 +32,7 @@ struct HwgArgs {
 
 constexpr int HW_TP = 128;                                    // virtual pixels per tile
 constexpr int HW_AROWS = 320, HW_ABUF = HW_AROWS * 128, HW_ZOFF = HW_ABUF, HW_STAGE = HW_ABUF + HW_TP * 128, HW_LDS = 2 * HW_STAGE;   // 40 + 16 KiB, twice
-constexpr int HW_TBL = 5888;                                  // entries of the block's pixel-offset tables (2 x 23 KiB behind the stages)
+constexpr int HW_TBL = 6144;                                  // entries of the block's pixel-offset tables (2 x 23 KiB behind the stages)
 #define HW_SWZ(r) ((((r) >> 1) & 1) << 2)                     // conv_c3g.hip: the four rows of a transposing read land on four bank quarters
 
 template <typename T> struct HwMma;
