@@ -1423,9 +1423,12 @@ def _pw(M, C, N):
                                     [_pw(8200, 1024, 256), _pw(8200, 256, 1024), _pw(4160, 136, 72), _pw(16384, 128, 512),
                                      (4, 65, 81, 128, 33, 41, 136, 3, 3, 2, 2, 1, 1), (4, 64, 80, 256, 32, 40, 128, 1, 1, 2, 2, 0, 0),
                                      (3, 40, 9, 128, 40, 9, 192, 3, 3, 1, 1, 1, 1)],
-                                    [_pw(40960, 256, 1024)] * 2 + [_pw(10240, 2048, 512), _pw(10240, 512, 2048)]],
-                         ids=["pair", "ragged_mixed_geometries", "stage4_stage5_mix"])
-def test_grouped_weight_gradients(dt, layers):
+                                    [_pw(40960, 256, 1024)] * 2 + [_pw(10240, 2048, 512), _pw(10240, 512, 2048)],
+                                    [_pw(8200, 1024, 264), _pw(4160, 264, 520), (4, 65, 81, 256, 33, 41, 328, 3, 3, 2, 2, 1, 1),
+                                     (4, 64, 80, 512, 32, 40, 256, 1, 1, 2, 2, 0, 0), (3, 40, 9, 128, 40, 9, 256, 3, 3, 1, 1, 1, 1)]],
+                         ids=["pair", "ragged_mixed_geometries", "stage4_stage5_mix", "wide_ragged_mixed_geometries"])
+@pytest.mark.parametrize("ring", [0, 4, 5], ids=["double_buffer", "ring4", "ring5"])
+def test_grouped_weight_gradients(dt, layers, ring):
     """urso_wgrad_group_plan / _run (conv_wgrad.hip): several layers' weight gradients in one launch -- each layer's partials land in
     its own workspace with the layout of urso_conv_wgrad_partial, only with fewer splits; reduced in the fixed order they must match the
     per-layer launch (itself checked against autograd above; fp32 sums in another grouping) and, for the pointwise layers, the fp64 product
@@ -1437,15 +1440,20 @@ def test_grouped_weight_gradients(dt, layers):
     geoms = [hip.geom(*l) for l in layers]
     xs = [dev(torch.relu(torch.randn(g.B, g.H, g.W, g.C)), dt) for g in geoms]
     dzs = [dev(torch.randn(g.B, g.OH, g.OW, g.N), dt) for g in geoms]
-    grp = hip.WgradGroup(geoms, dt)
+    wide = all(g.KH * g.KW * g.C >= 256 and g.N >= 256 for g in geoms)       # -> 256 x 256 tiles, one 8-wave block per CU (wgrad_group_big_kernel)
+    with hip.options(wgrad_big=0 if ring else 1):          # (the ring variants belong to the 128 x 128 kernel: they also cover the wide groups on it)
+        grp = hip.WgradGroup(geoms, dt)
+    assert bool(grp.host[0].mode & 4) == (wide and not ring)
     assert grp.nblocks > 0 and grp.nblocks <= 512 and all(s >= 1 for s in grp.splits) and 0.0 < grp.fill <= 1.0
     assert grp.fill > 0.6 or layers[0][2] < 40960              # (the small groups cannot fill 512 slots with >= 8 steps per block)
     solo = [hip.conv_wgrad_splits(g, dt) for g in geoms]
     assert all(s <= t for s, t in zip(grp.splits, solo)) and (sum(grp.splits) < sum(solo) or layers[0][2] <= 4096)   # (short layers: 8 steps per block either way)
     KN = [g.KH * g.KW * g.C * g.N for g in geoms]
     wss = [torch.full((s * (kn + hip.WGRAD_PART_PAD) + s * g.N + 64,), 7.0, dtype=torch.float32, device="cuda") for s, kn, g in zip(grp.splits, KN, geoms)]
-    grp.bind(xs, dzs, wss, "cuda")
-    grp.run()
+    with hip.options(wgrad_big=0 if ring else 1):
+        grp.bind(xs, dzs, wss, "cuda")
+    with hip.options(wgrad_ring=ring):                     # 0: 64-pixel double buffer; 4 / 5: stages of the 32-pixel deep ring
+        grp.run()
     torch.cuda.synchronize()
     for i, g in enumerate(geoms):
         s, stride = grp.splits[i], KN[i] + hip.WGRAD_PART_PAD
@@ -1462,14 +1470,18 @@ def test_grouped_weight_gradients(dt, layers):
         assert float(dw.abs().max()) > 0 and relerr(part, dw.double()) < 5e-5, (i, relerr(part, dw.double()))
     # the same launch again gives the same bits (fixed work list, no atomics)
     before = [w.clone() for w in wss]
-    grp.run()
+    with hip.options(wgrad_ring=ring):
+        grp.run()
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(before, wss))
 
 
 def test_grouped_weight_gradient_plan_refuses_what_cannot_be_resident():
     hip = _hip()
-    assert hip.WgradGroup([hip.geom(*_pw(4096, 2048, 2048))] * 3, 1).nblocks == 0          # 3 x 256 tiles > 512 resident blocks
+    with hip.options(wgrad_big=0):
+        assert hip.WgradGroup([hip.geom(*_pw(4096, 2048, 2048))] * 3, 1).nblocks == 0      # 3 x 256 tiles of 128 x 128 > 512 resident blocks
+    assert hip.WgradGroup([hip.geom(*_pw(4096, 2048, 2048))] * 3, 1).nblocks > 0           # 3 x 64 tiles of 256 x 256: one 8-wave block per CU
+    assert hip.WgradGroup([hip.geom(*_pw(4096, 2048, 2048))] * 5, 1).nblocks == 0          # 5 x 64 > 256
     g = hip.geom(32, 32, 40, 256, 32, 40, 1024, 1, 1, 1, 1, 0, 0)
     assert hip.wgrad_group_fits(g, 1) and not hip.wgrad_group_fits(g, 0)
     assert not hip.wgrad_group_fits(hip.geom(32, 32, 40, 256, 32, 40, 256, 3, 3, 1, 1, 1, 1), 1)     # conv_hwgrad.hip's layer

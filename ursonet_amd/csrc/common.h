@@ -24,6 +24,8 @@ struct UrsoOptions {
     int wgrad_narrow = 1;    // 128x64 weight-gradient tile for N <= 64
     int wgrad_blocks = 512;  // resident-block target of the weight-gradient split
     int wgrad_pipe = 1;      // scheduler-interleaved fragment reads in wgrad_tr_kernel
+    int wgrad_big = 1;       // grouped weight gradients of layers with >= 256 channels and filters on 256 x 256 tiles (wgrad_group_big_kernel)
+    int wgrad_ring = 0;      // grouped weight gradients (wgrad_group_kernel): 0 = 64-pixel double buffer, 4 / 5 = stages of the 32-pixel ring
     int grid_cap = 0;        // > 0: cap the block count of the persistent conv kernels (tests: forces the multi-tile stream on small shapes)
     int hconv = 1;           // conv_halo.hip (8-wave halo-tile kernel) for qualifying 3x3 layers
     int pair = 1;            // conv_pair.hip: fused pointwise pairs of stages 2-3 (read by the host plan, ursonet_amd/engine.py)

@@ -444,6 +444,308 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& a, const int wid,
     }
 }
 
+// The same work on a DEEP ring: NST stages of 32 pixels (16 KiB each), the copies of NST - 1 steps in flight, hand-counted vmcnt, one
+// barrier per step.  A block of the 64-pixel double buffer above has ONE step of copies in flight while it multiplies (0.2 us of MFMAs
+// against >= 1.5 us of latency to HBM): two such blocks per CU keep 64 KiB in flight, which bounds a long-running block (grouped launches:
+// 80-160 steps) at ~3.3 TB/s chip-wide.  Four or five stages keep 96-128 KiB in flight in the same or 1.25x the LDS.  Beyond the end of
+// the block's pixel range the copies go on as out-of-range dummies (zeros into stages nobody reads) so that the counts stay fixed.
+template <typename T, int MODE, int NST>
+__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& a, const int wid, char* smem) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int VE = 8, RM = 32, ITEMS = 2, STAGE = 2 * RM * 256;      // 32 pixels x 128 channels per operand per step; 2 x 16 B per thread and operand
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int tiles = a.ktiles * a.ntiles;
+    const int sp = wid / tiles, tile = wid - sp * tiles;
+    const int kt = tile % a.ktiles, nt = tile / a.ktiles;
+    const int k0c = kt * 16, n0 = nt * 128;
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const i32x4_t rx = raw_rsrc(a.x, a.x_bytes), rz = raw_rsrc(a.dz, a.dz_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int prow = tid >> 4, ch = (tid & 15) ^ ((prow & 7) << 1);       // rows prow, prow + 16 of a stage (see wgrad_tr_body)
+    const int kc = k0c + ch;
+    const bool kvalid = kc < a.Kc;
+    int ky = 0, kx = 0, cc = 0;
+    if (kvalid) { int tap = kc / a.Cc; cc = kc - tap * a.Cc; ky = tap / a.KW; kx = tap - ky * a.KW; }
+    const int ncol = n0 + ch * VE;
+    const bool nvalid = ncol < a.N;
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    int mcur = m_begin;
+    int pb[ITEMS], poy[ITEMS], pox[ITEMS];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            int rem;
+            divmod(m_begin + prow + 16 * e, ohw, a.rcp_ohw, pb[e], rem);
+            divmod(rem, a.OW, a.rcp_ow, poy[e], pox[e]);
+        }
+    }
+    const int dq = RM / a.OW, dr = RM - dq * a.OW;
+    const uint32_t xc_off = (uint32_t)(cc * VE) * 2u, z_off0 = (uint32_t)ncol * 2u;
+
+    auto dma = [&](int buf) {
+        const uint32_t dx = lds0 + buf * STAGE + wave * 1024, dz = dx + RM * 256;
+#pragma unroll
+        for (int e = 0; e < ITEMS; ++e) {
+            const int m = mcur + prow + 16 * e;
+            const bool mvalid = m < m_end;
+            uint32_t zp = (uint32_t)m;
+            uint32_t off; bool ok;
+            if constexpr (MODE == 0) { off = (uint32_t)(m * a.C) * 2u + xc_off; ok = mvalid && kvalid; }
+            else {
+                int b, oy, ox;
+                if constexpr (MODE == 1) {
+                    b = pb[e]; oy = poy[e]; ox = pox[e];
+                    int nx = ox + dr; const bool w1 = nx >= a.OW; nx -= w1 ? a.OW : 0;
+                    int ny = oy + dq + (w1 ? 1 : 0); const bool w2 = ny >= a.OH; ny -= w2 ? a.OH : 0;
+                    pox[e] = nx; poy[e] = ny; pb[e] = b + (w2 ? 1 : 0);
+                } else { int rem; divmod(mvalid ? m : 0, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); }
+                const int iy = oy * a.SH - a.PH + ky, ix = ox * a.SW - a.PW + kx;
+                ok = mvalid && kvalid && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off;
+                if (a.zs) zp = (uint32_t)((b * a.ZH + oy * a.zsh) * a.ZW + ox * a.zsw);
+            }
+            lds_dma16(rx, dx + e * 16 * 256, ok ? off : URSO_OOB_SHIFT);
+            const uint32_t zoff = zp * (uint32_t)a.N * 2u + z_off0;
+            lds_dma16(rz, dz + e * 16 * 256, (mvalid && nvalid) ? zoff : URSO_OOB_SHIFT);
+        }
+        mcur += RM;
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frow = fg * 4 + (fr >> 2), fsw = frow & 7;
+    const int fbase = frow * 256 + (fr & 3) * 8;
+    int offx[4], offz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offx[i] = fbase + (((wk * 4 + i) ^ fsw) << 5);
+        offz[i] = fbase + (((wn * 4 + i) ^ fsw) << 5);
+    }
+    f32x4_t acc[4][4], accc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_col = (kt == 0) && (wk == 0) && a.colpart;
+    const i32x4_t ones = {OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W};
+
+    constexpr int NDMA = 2 * ITEMS;                        // copies per thread and step
+    const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) dma(p);              // (steps past the range: out-of-range dummies)
+    int stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // this thread's copies of step s have landed (NST - 2 younger steps stay in flight); after the barrier every thread's have, and
+        // every wave is done reading the stage of step s - 1: the copies of step s + NST - 1 go there
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(stage == 0 ? NST - 1 : stage - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bx = smem + stage * STAGE; const char* bz = bx + RM * 256;
+        i32x4_t fz[4], fx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i32x2_t lo = lds_read_tr16(bz + offz[j]), hi = lds_read_tr16(bz + offz[j] + 16 * 256);
+            fz[j] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i32x2_t lo = lds_read_tr16(bx + offx[i]), hi = lds_read_tr16(bx + offx[i] + 16 * 256);
+            fx[i] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], fx[i], acc[i][j]);
+        if (do_col) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], ones, accc[j]);
+        }
+        stage = (stage + 1 == NST) ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummies past the end must not outlive the block's LDS
+
+    float* out = a.part + (size_t)sp * ((size_t)a.K * a.N + URSO_WGRAD_PART_PAD);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kt * 128 + wk * 64 + i * 16 + fr;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb >= a.N) continue;
+            *(f32x4_t*)(out + (size_t)k * a.N + nb) = acc[i][j];
+        }
+    }
+    if (do_col && fr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb < a.N) *(f32x4_t*)(a.colpart + (size_t)sp * a.N + nb) = accc[j];
+        }
+    }
+}
+
+// 256 (k) x 256 (n) tile, 8 waves (2 x 4, wave tile 128 x 64), one block per CU: the form for grouped launches of wide layers (every
+// layer of the group with >= 256 channels and filters).  The 128 x 128 blocks above pull (128 + 128) channels per pixel and tile through
+// L2 -> LDS: a stage-4 layer's operands cross that path 3.2 times (x once per 128 filters, dz once per 128 channels), 2.7 GB per group
+// of eight layers, ~11 TB/s -- the L2's bandwidth, which is what bounded those launches (MFMA pipe 26 % busy, HBM at 3.3 TB/s, and a
+// deeper ring changed nothing).  256 x 256 tiles halve that traffic.  Stages of 32 pixels: four half-tiles (x0, x1, z0, z1: 128 channels
+// each, the 256-byte-row layout and swizzle of wgrad_tr_body) = 32 KiB; four stages, three steps of copies in flight, one barrier per step.
+template <typename T, int MODE>
+__device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int wid, char* smem) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    constexpr int VE = 8, RM = 32, NST = 4, HALF = RM * 256, STAGE = 4 * HALF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;                               // 128 k-rows (x half-tile wk); 64 filters (z half-tile wn >> 1, blocks 4 (wn & 1) ..)
+    const int tiles = a.ktiles * a.ntiles;
+    const int sp = wid / tiles, tile = wid - sp * tiles;
+    const int kt = tile % a.ktiles, nt = tile / a.ktiles;
+    const int k0c = kt * 32, n0 = nt * 256;
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const i32x4_t rx = raw_rsrc(a.x, a.x_bytes), rz = raw_rsrc(a.dz, a.dz_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // staging: the thread copies 16-byte chunk ch of pixel row prow (= 4 wave + lane / 16: the wave's 1 KiB of a half-tile) of all four half-tiles
+    const int prow = tid >> 4, ch = (tid & 15) ^ ((prow & 7) << 1);
+    int ky[2], kx[2], cc[2]; bool kvalid[2], nvalid[2]; uint32_t xc_off[2], z_off0[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kc = k0c + 16 * h + ch;
+        kvalid[h] = kc < a.Kc; ky[h] = kx[h] = cc[h] = 0;
+        if (kvalid[h]) { int tap = kc / a.Cc; cc[h] = kc - tap * a.Cc; ky[h] = tap / a.KW; kx[h] = tap - ky[h] * a.KW; }
+        xc_off[h] = (uint32_t)(cc[h] * VE) * 2u;
+        const int ncol = n0 + 128 * h + ch * VE;
+        nvalid[h] = ncol < a.N; z_off0[h] = (uint32_t)ncol * 2u;
+    }
+    const int ohw = a.OH * a.OW;
+    auto divmod = [](int n, int d, float rcp, int& q, int& r) {
+        q = (int)((float)n * rcp);
+        r = n - q * d;
+        const bool lo = r < 0, hi = r >= d;
+        q += hi ? 1 : (lo ? -1 : 0);
+        r += hi ? -d : (lo ? d : 0);
+    };
+    int mcur = m_begin;
+    int pb = 0, poy = 0, pox = 0;
+    if constexpr (MODE == 1) { int rem; divmod(m_begin + prow, ohw, a.rcp_ohw, pb, rem); divmod(rem, a.OW, a.rcp_ow, poy, pox); }
+    const int dq = RM / a.OW, dr = RM - dq * a.OW;
+
+    auto dma = [&](int buf) {
+        const uint32_t d0 = lds0 + buf * STAGE + wave * 1024;
+        const int m = mcur + prow;
+        const bool mvalid = m < m_end;
+        uint32_t zp = (uint32_t)m;
+        int b = 0, oy = 0, ox = 0;
+        if constexpr (MODE == 1) {
+            b = pb; oy = poy; ox = pox;
+            int nx = ox + dr; const bool w1 = nx >= a.OW; nx -= w1 ? a.OW : 0;
+            int ny = oy + dq + (w1 ? 1 : 0); const bool w2 = ny >= a.OH; ny -= w2 ? a.OH : 0;
+            pox = nx; poy = ny; pb = b + (w2 ? 1 : 0);
+        } else if constexpr (MODE == 2) { int rem; divmod(mvalid ? m : 0, ohw, a.rcp_ohw, b, rem); divmod(rem, a.OW, a.rcp_ow, oy, ox); }
+        if constexpr (MODE != 0) { if (a.zs) zp = (uint32_t)((b * a.ZH + oy * a.zsh) * a.ZW + ox * a.zsw); }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t off; bool ok;
+            if constexpr (MODE == 0) { off = (uint32_t)(m * a.C) * 2u + xc_off[h]; ok = mvalid && kvalid[h]; }
+            else {
+                const int iy = oy * a.SH - a.PH + ky[h], ix = ox * a.SW - a.PW + kx[h];
+                ok = mvalid && kvalid[h] && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+                off = (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C) * 2u + xc_off[h];
+            }
+            lds_dma16(rx, d0 + h * HALF, ok ? off : URSO_OOB_SHIFT);
+            const uint32_t zoff = zp * (uint32_t)a.N * 2u + z_off0[h];
+            lds_dma16(rz, d0 + (2 + h) * HALF, (mvalid && nvalid[h]) ? zoff : URSO_OOB_SHIFT);
+        }
+        mcur += RM;
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frow = fg * 4 + (fr >> 2), fsw = frow & 7;
+    const int fbase = frow * 256 + (fr & 3) * 8;
+    int offx[8], offz[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) offx[i] = wk * HALF + fbase + ((i ^ fsw) << 5);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offz[j] = (2 + (wn >> 1)) * HALF + fbase + ((((wn & 1) * 4 + j) ^ fsw) << 5);
+
+    f32x4_t acc[8][4], accc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_col = (kt == 0) && (wk == 0) && a.colpart;
+    const i32x4_t ones = {OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W, OnesFrag<T>::W};
+
+    constexpr int NDMA = 4;
+    const int nsteps = (m_end > m_begin) ? ceil_div(m_end - m_begin, RM) : 0;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) dma(p);
+    int stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(stage == 0 ? NST - 1 : stage - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sb = smem + stage * STAGE;
+        i32x4_t fz[4], fx[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i32x2_t lo = lds_read_tr16(sb + offz[j]), hi = lds_read_tr16(sb + offz[j] + 16 * 256);
+            fz[j] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const i32x2_t lo = lds_read_tr16(sb + offx[i]), hi = lds_read_tr16(sb + offx[i] + 16 * 256);
+            fx[i] = i32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], fx[i], acc[i][j]);
+        if (do_col) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<T>::run(fz[j], ones, accc[j]);
+        }
+        stage = (stage + 1 == NST) ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float* out = a.part + (size_t)sp * ((size_t)a.K * a.N + URSO_WGRAD_PART_PAD);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kt * 256 + wk * 128 + i * 16 + fr;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb >= a.N) continue;
+            *(f32x4_t*)(out + (size_t)k * a.N + nb) = acc[i][j];
+        }
+    }
+    if (do_col && fr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + fg * 4;
+            if (nb < a.N) *(f32x4_t*)(a.colpart + (size_t)sp * a.N + nb) = accc[j];
+        }
+    }
+}
+
 template <typename T, int MODE, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 256];
@@ -454,9 +756,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WgradArgs a) {
 // i.e. CUs x 128 KiB of fp32 partials written at the end of the launch and read again by the split reduction -- as many bytes as
 // the layer's operands in stages 4-5.  With G layers sharing the launch every layer gets 1/G of the splits: the blocks run G times
 // longer over their pixels and the partial traffic (and the write burst that nothing overlaps) drops by G.
-template <typename T>
+template <typename T, int NST>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const urso_wgrad_item* __restrict__ items, const int32_t* __restrict__ map) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 256];
+    __shared__ __attribute__((aligned(16))) char smem[NST ? NST * 2 * 32 * 256 : 2 * 2 * 64 * 256];
     const int li = map[2 * blockIdx.x], wid = map[2 * blockIdx.x + 1];
     const urso_wgrad_item& it = items[li];
     const urso_conv_geom& g = it.g;
@@ -470,9 +772,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const urso_wgrad_it
     a.M = it.M; a.Cc = g.C / 8; a.Kc = g.KH * g.KW * a.Cc; a.K = a.Kc * 8;
     a.ktiles = it.ktiles; a.ntiles = it.ntiles; a.splits = it.splits; a.m_per_split = it.m_per_split;
     a.rcp_ohw = 1.0f / (float)(g.OH * g.OW); a.rcp_ow = 1.0f / (float)g.OW;
-    if (it.mode == 0) wgrad_tr_body<T, 0, true>(a, wid, smem);
-    else if (it.mode == 1) wgrad_tr_body<T, 1, true>(a, wid, smem);
-    else wgrad_tr_body<T, 2, true>(a, wid, smem);
+    if constexpr (NST == 0) {
+        if ((it.mode & 3) == 0) wgrad_tr_body<T, 0, true>(a, wid, smem);
+        else if ((it.mode & 3) == 1) wgrad_tr_body<T, 1, true>(a, wid, smem);
+        else wgrad_tr_body<T, 2, true>(a, wid, smem);
+    } else {
+        if ((it.mode & 3) == 0) wgrad_ring_body<T, 0, NST>(a, wid, smem);
+        else if ((it.mode & 3) == 1) wgrad_ring_body<T, 1, NST>(a, wid, smem);
+        else wgrad_ring_body<T, 2, NST>(a, wid, smem);
+    }
+}
+
+// The grouped launch on 256 x 256 tiles (wgrad_big_body): items planned with mode bit 2 set.
+template <typename T>
+__global__ __launch_bounds__(512, 1) void wgrad_group_big_kernel(const urso_wgrad_item* __restrict__ items, const int32_t* __restrict__ map) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 4 * 32 * 256];
+    const int li = map[2 * blockIdx.x], wid = map[2 * blockIdx.x + 1];
+    const urso_wgrad_item& it = items[li];
+    const urso_conv_geom& g = it.g;
+    WgradArgs a;
+    a.x = it.x; a.dz = it.dz; a.part = it.part; a.colpart = it.colpart;
+    a.B = g.B; a.H = g.H; a.W = g.W; a.C = g.C; a.OH = g.OH; a.OW = g.OW; a.N = g.N;
+    a.KH = g.KH; a.KW = g.KW; a.SH = g.SH; a.SW = g.SW; a.PH = g.PH; a.PW = g.PW;
+    a.zs = g.FH > 0 ? 1 : 0; a.ZH = g.FH; a.ZW = g.FW; a.zsh = g.OSH; a.zsw = g.OSW;
+    a.x_bytes = (uint32_t)g.B * (uint32_t)g.H * (uint32_t)g.W * (uint32_t)g.C * 2u;
+    a.dz_bytes = (a.zs ? (uint32_t)g.B * (uint32_t)g.FH * (uint32_t)g.FW : (uint32_t)it.M) * (uint32_t)g.N * 2u;
+    a.M = it.M; a.Cc = g.C / 8; a.Kc = g.KH * g.KW * a.Cc; a.K = a.Kc * 8;
+    a.ktiles = it.ktiles; a.ntiles = it.ntiles; a.splits = it.splits; a.m_per_split = it.m_per_split;
+    a.rcp_ohw = 1.0f / (float)(g.OH * g.OW); a.rcp_ow = 1.0f / (float)g.OW;
+    const int mode = it.mode & 3;
+    if (mode == 0) wgrad_big_body<T, 0>(a, wid, smem);
+    else if (mode == 1) wgrad_big_body<T, 1>(a, wid, smem);
+    else wgrad_big_body<T, 2>(a, wid, smem);
 }
 
 // Narrow form for layers with at most 64 filters (the 3x3 convs of stage 2, the stem): 128(k) x 64(n) output tile, so no
@@ -930,7 +1261,11 @@ static int xcd_remap_host(int bid, int nblk) {
 
 extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t* blockmap_h, int cap_blocks) {
     if (n <= 0 || !it || (dt != URSO_BF16 && dt != URSO_F16)) { urso_set_error("urso_wgrad_group_plan: bad argument"); return -1; }
-    const int target = (int)((long long)g_urso_opt.wgrad_blocks * urso_usable_cus() / urso_device_cus());
+    // 256 x 256 tiles, one 8-wave block per CU, when every layer of the group is at least that wide (option wgrad_big)
+    bool big = g_urso_opt.wgrad_big != 0;
+    for (int i = 0; i < n; ++i) big = big && it[i].g.KH * it[i].g.KW * it[i].g.C >= 256 && it[i].g.N >= 256;
+    const int TS = big ? 256 : 128;
+    const int target = big ? urso_usable_cus() : (int)((long long)g_urso_opt.wgrad_blocks * urso_usable_cus() / urso_device_cus());
     long long work = 0; int tiles_all = 0, steps_max = 0;
     for (int i = 0; i < n; ++i) {
         const urso_conv_geom& g = it[i].g;
@@ -939,8 +1274,8 @@ extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t
             urso_set_error("urso_wgrad_group_plan: item %d: geometry outside the 16-bit general kernel", i); return -1;
         }
         it[i].M = (int32_t)M;
-        it[i].mode = wg_pointwise(&g) ? 0 : ((64 / g.OW + 1 <= g.OH) ? 1 : 2);       // as urso_conv_wgrad picks it
-        it[i].ktiles = ceil_div(g.KH * g.KW * g.C, 128); it[i].ntiles = ceil_div(g.N, 128);
+        it[i].mode = (wg_pointwise(&g) ? 0 : ((64 / g.OW + 1 <= g.OH) ? 1 : 2)) | (big ? 4 : 0);       // addressing as urso_conv_wgrad picks it; bit 2: 256 x 256 tiles
+        it[i].ktiles = ceil_div(g.KH * g.KW * g.C, TS); it[i].ntiles = ceil_div(g.N, TS);
         const int tiles = it[i].ktiles * it[i].ntiles, steps = ceil_div(it[i].M, 64);
         tiles_all += tiles; work += (long long)tiles * steps; steps_max = steps > steps_max ? steps : steps_max;
     }
@@ -956,6 +1291,8 @@ extern "C" int urso_wgrad_group_plan(int n, urso_wgrad_item* it, int dt, int32_t
     for (int i = 0; i < n; ++i) {
         const int steps = ceil_div(it[i].M, 64);
         int splits = ceil_div(steps, s);
+        const int maxs = steps / 8 < 1 ? 1 : steps / 8;       // never more partials than the layer alone would write (>= 8 steps per block there too)
+        if (splits > maxs) splits = maxs;
         const int per = ceil_div(steps, splits);              // balanced within the layer
         splits = ceil_div(steps, per);
         it[i].splits = splits; it[i].m_per_split = per * 64; it[i].fill = 0;
@@ -1004,8 +1341,19 @@ extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, cons
     if (cnt != nblocks) { urso_set_error("urso_wgrad_group_run: block map has %d blocks, the items need %d", nblocks, cnt); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
-    if (dt == URSO_BF16) URSO_KLAUNCH(wgrad_group_kernel<__bf16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
-    else URSO_KLAUNCH(wgrad_group_kernel<_Float16>, dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d);
+    const bool big = (items_h[0].mode & 4) != 0;
+    for (int i = 0; i < n; ++i) if (((items_h[i].mode & 4) != 0) != big) { urso_set_error("urso_wgrad_group_run: items planned for different tile shapes"); return URSO_EINVAL; }
+    if (big) {
+        if (dt == URSO_BF16) URSO_KLAUNCH(wgrad_group_big_kernel<__bf16>, dim3(nblocks), dim3(512), 0, st, items_d, blockmap_d);
+        else URSO_KLAUNCH(wgrad_group_big_kernel<_Float16>, dim3(nblocks), dim3(512), 0, st, items_d, blockmap_d);
+        return urso_check_launch("urso_wgrad_group_run");
+    }
+    const int ring = g_urso_opt.wgrad_ring;              // 0: 64-pixel double buffer; 4 / 5: stages of the 32-pixel ring
+#define URSO_WGG(TT) do { if (ring == 4) URSO_KLAUNCH((wgrad_group_kernel<TT, 4>), dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d); \
+                          else if (ring == 5) URSO_KLAUNCH((wgrad_group_kernel<TT, 5>), dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d); \
+                          else URSO_KLAUNCH((wgrad_group_kernel<TT, 0>), dim3(nblocks), dim3(256), 0, st, items_d, blockmap_d); } while (0)
+    if (dt == URSO_BF16) URSO_WGG(__bf16); else URSO_WGG(_Float16);
+#undef URSO_WGG
     return urso_check_launch("urso_wgrad_group_run");
 }
 

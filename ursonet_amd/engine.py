@@ -80,7 +80,7 @@ class Engine(object):
         assert mode in ("training", "inference")
         # gradient buckets: one batched reduction / finalisation per bucket.  One GPU: few big buckets (128 MiB: 8 launches and 0.45 ms against 13
         # and 0.52 ms at 32 MiB, 41 and 0.68 ms at 8 MiB); ursonet_amd/dp.py re-plans with 32 MiB buckets, which the all-reduces overlap behind
-        self.grad_bucket_bytes = int(grad_bucket_bytes)
+        self.grad_bucket_bytes = int(os.environ.get("URSO_GRAD_BUCKET_MIB", 0)) << 20 or int(grad_bucket_bytes)     # (env: A/B only)
         self.grad_tail_bytes = 0                       # > 0: the last bucket (stem side) is capped at this size; set by ursonet_amd/dp.py (plan_buckets)
         if not torch.cuda.is_available():
             raise RuntimeError("ursonet_amd.Engine needs an AMD GPU (MI355X / gfx950); there is no CPU fallback")
@@ -444,7 +444,13 @@ class Engine(object):
                     emit_wgrad(*take[0])
                     continue
                 for (c, _, _, _, _), s in zip(take, grp.splits):
-                    assert s <= c.splits
+                    need_f = s * (c.K_raw * c.npad + hip.WGRAD_PART_PAD) + s * c.npad + 64
+                    if c.wg_ws.numel() < need_f:           # (the workspace was sized for the layer alone)
+                        c.wg_ws = torch.empty(need_f, dtype=torch.float32, device=dev)
+                    if s > 1 and c.dw_raw is None:
+                        c.dw_raw = torch.empty(c.K_raw * c.npad, dtype=torch.float32, device=dev)
+                        c.colsum = torch.empty(c.npad, dtype=torch.float32, device=dev)
+                        c.desc.dw_raw, c.desc.colsum = hip.ptr(c.dw_raw), hip.ptr(c.colsum)
                     c.splits = c.desc.splits = s
                     c.wg_npart = s * (c.K_raw * c.npad + hip.WGRAD_PART_PAD)
                     c.desc.part, c.desc.colpart = c.wg_ws.data_ptr(), c.wg_ws.data_ptr() + 4 * c.wg_npart
@@ -582,8 +588,9 @@ class Engine(object):
                         # a layer of the general kernel: its weight gradient waits for company (see flush_wgrads); every tensor has a gradient
                         # buffer of its own, so G is still there when the launch comes
                         cand = pend_wg + [(c, node.name, xw, G, gf_w)]
-                        if len(cand) > 1 and hip.WgradGroup([t[4] for t in cand], dt).fill < wg_fill:
-                            flush_wgrads()                 # the newcomer's tile count / pixel count does not divide the slots well
+                        wide = lambda g: g.KH * g.KW * g.C >= 256 and g.N >= 256      # (256 x 256 tiles when every layer of the group is this wide)
+                        if len(cand) > 1 and (wide(cand[-1][4]) != wide(cand[0][4]) or hip.WgradGroup([t[4] for t in cand], dt).fill < wg_fill):
+                            flush_wgrads()                 # another tile shape, or the newcomer's tile count / pixel count does not divide the slots well
                         pend_wg.append(cand[-1])
                         if len(pend_wg) >= wg_max:
                             flush_wgrads()
