@@ -24,6 +24,7 @@ timeout 300 python tools/layer_profile.py > "$O/${TAG}_layer_profile.txt" 2>&1
 timeout 900 python tools/config_sweep.py 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_config_sweep.txt"
 timeout 600 python bench.py > "$O/${TAG}_bench.json" 2> "$O/bench.err"
 timeout 600 python tools/dp_dryrun.py 2>/dev/null | grep "^{" | tail -1 > "$O/${TAG}_dp_dryrun.json"
+timeout 300 python tools/kernels_md.py > "$O/KERNELS.md" 2> "$O/kernels_md.err"      # -> KERNELS.md at the repo root
 rm -rf "$O/stats" "$O/pmcF" "$O/pmcW" "$O/pmcM"
 cut -c1-300 "$O/${TAG}_bench.json"
 echo "copy $O/${TAG}_* into profiles/ and commit"

@@ -24,6 +24,7 @@ FAMILIES = [
     ("pair_kernel", "conv_pair.hip", "64 / 32-px tiles, 4 / 8 waves, both filter matrices in registers, 80-144 KiB LDS", "fused pointwise pairs of stages 2-3; single c -> 4c layers of stages 2-5"),
     ("stemw_kernel", "conv_stemw.hip", "8x32 output px, 4 waves, un-pool in LDS", "7x7 stem weight gradient (+ max-pool backward)"),
     ("stem_kernel", "conv_stem.hip", "8x32 output px x 64 filters, 4 waves, filters in registers", "7x7 / stride-2 stem"),
+    ("wgrad_group_big_kernel", "conv_wgrad.hip", "256 (k) x 256 (n) tile, 8 waves (128 x 64 wave tiles), 4-stage ring of 32-pixel steps 128 KiB, 1 block/CU, over a device table of layers: up to 8 layers per launch, 1/n of the splits each", "weight gradients of consecutive wide layers (>= 256 channels and filters) of a bucket, grouped"),
     ("wgrad_group_kernel", "conv_wgrad.hip", "the 128 x 128 body of wgrad_tr_kernel over a device table of layers: up to 8 layers per launch, 512 blocks shared, 1/n of the splits each", "weight gradients of consecutive 1x1 / strided layers of a bucket, grouped"),
     ("hwgrad2_kernel", "conv_hwgrad.hip", "hwgrad_kernel for two layers, the CUs shared in proportion to their work", "3x3 weight gradients (>= 128 channels), two layers per launch"),
     ("hwgrad_kernel", "conv_hwgrad.hip", "one (64 ch, 64 filters) x 9 taps gradient group per block in registers, 8 waves, 128-virtual-pixel tiles, halo run + offset tables 160 KiB, 1 block/CU", "3x3 weight gradients (>= 128 channels)"),
