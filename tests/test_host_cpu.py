@@ -394,6 +394,54 @@ def test_cabi_argument_validation_without_gpu():
     assert hip._lib.urso_sgd_momentum_clip(16, None, None, None, None, None, None) == -1
 
 
+def test_grouped_weight_gradient_plans_are_consistent_without_gpu():
+    """urso_wgrad_group_plan / urso_conv_wgrad_pair_splits are host code: for groups like the engine's (ResNet-50 / 101 stages 3-5 at
+    cfg2 and at a small batch, mixed geometries, both tile shapes) the plan never asks for more blocks than stay resident, covers every
+    pixel of every layer, hands out every (layer, work id) exactly once in the block map, never splits a layer into blocks of fewer
+    than 8 steps, and reports its fill; a pair of 3x3 layers shares the CUs without exceeding them."""
+    import ursonet_amd.hip as hip
+    dt = hip.BF16
+    pw = lambda M, C, N: hip.geom(1, 1, M, C, 1, M, N, 1, 1)
+    groups = {
+        "stage4 x8": [pw(40960, 256, 1024), pw(40960, 1024, 256)] * 4,
+        "stage5 + entry": [pw(10240, 512, 2048), pw(10240, 2048, 512), pw(10240, 1024, 2048), hip.geom(32, 32, 40, 1024, 16, 20, 512, 1, 1, 2, 2, 0, 0)],
+        "stage3": [pw(163840, 128, 512), pw(163840, 512, 128)] * 3 + [hip.geom(32, 64, 80, 128, 32, 40, 128, 3, 3, 2, 2, 1, 1)],
+        "small batch": [pw(10240, 256, 1024), pw(10240, 512, 1024), pw(10240, 512, 256)],
+        "ragged": [pw(8200, 1024, 264), pw(4160, 264, 520), hip.geom(4, 65, 81, 256, 33, 41, 328, 3, 3, 2, 2, 1, 1)],
+    }
+    for name, gs in groups.items():
+        for big in (0, 1):
+            with hip.options(wgrad_big=big):
+                grp = hip.WgradGroup(gs, dt)
+                assert grp.nblocks > 0, name
+                is_big = bool(grp.host[0].mode & 4)
+                assert all(bool(it.mode & 4) == is_big for it in grp.host) and (is_big <= bool(big))
+                ts = 256 if is_big else 128
+                assert grp.nblocks <= (256 if is_big else 512) and 0.0 < grp.fill <= 1.0, (name, grp.nblocks, grp.fill)
+                buf = (ctypes.c_int32 * (2 * grp.nblocks))()
+                assert hip._lib.urso_wgrad_group_plan(grp.n, grp.host, dt, buf, grp.nblocks) == grp.nblocks
+            seen = set()
+            for b in range(grp.nblocks):
+                seen.add((buf[2 * b], buf[2 * b + 1]))
+            want = set()
+            for i, (it, g) in enumerate(zip(grp.host, gs)):
+                K, M = g.KH * g.KW * g.C, g.B * g.OH * g.OW
+                assert it.M == M and it.ktiles == -(-K // ts) and it.ntiles == -(-g.N // ts)
+                assert it.splits >= 1 and it.m_per_split % 64 == 0 and it.splits * it.m_per_split >= M > (it.splits - 1) * it.m_per_split
+                assert it.m_per_split >= 8 * 64 or it.splits == 1
+                want |= {(i, w) for w in range(it.ktiles * it.ntiles * it.splits)}
+            assert seen == want and len(want) == grp.nblocks, name
+    assert hip.WgradGroup([pw(4096, 2048, 2048)] * 5, dt).nblocks == 0                  # does not fit one residency in either tile shape
+    # two 3x3 layers in one launch: stage 4 + stage 4, stage 3 + stage 4, stage 5 + stage 5
+    c3 = lambda B, H, W, C, N: hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
+    for a, b in ((c3(32, 32, 40, 256, 256),) * 2, (c3(32, 64, 80, 128, 128), c3(32, 32, 40, 256, 256)), (c3(32, 16, 20, 512, 512),) * 2):
+        sp = hip.conv_wgrad_pair_splits(a, b, dt)
+        assert sp is not None
+        blocks = sum(s * (g.C // 64) * (g.N // 64) for s, g in zip(sp, (a, b)))
+        assert 200 <= blocks <= 256 and all(1 <= s <= hip.conv_wgrad_splits(g, dt) for s, g in zip(sp, (a, b)))
+    assert hip.conv_wgrad_pair_splits(c3(32, 32, 40, 256, 256), c3(32, 128, 160, 64, 64), dt) is None      # the 64-channel layer has a kernel of its own
+
+
 # ------------------------------------------------------------------ layout rules
 def test_product_never_imports_the_oracle_or_reference():
     bad = []
