@@ -398,14 +398,6 @@ int urso_bn_backward(int M, int N, int dt, const void* g_d, const void* z_d, con
 int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, const float* mean3_d,
                      int dt, void* dst_d, void* stream);
 
-/* The stem and the max-pool behind it in one launch (conv_stem.hip: stemp_kernel): ZeroPadding2D(3) + Conv2D(64, 7, strides 2) + BatchNorm
- * (folded) + ReLU + MaxPooling2D(3, strides 2, 'same') of net.py:170-176, 254-255.  g is the packed stem geometry of urso_conv_igemm
- * (OH, OW even), src_d the molded input, wgt_d / bias_d as urso_conv_igemm takes them; y_d receives the POOLED tensor [B][OH/2][OW/2][64]
- * and argmax_d (may be NULL) its arg-max bytes -- bit for bit what urso_conv_igemm followed by urso_maxpool3x3s2_fwd produce; conv1's own
- * output (read by nothing else) never reaches memory.  flags: URSO_EPI_RELU or 0. */
-int urso_stem_conv_pool_fwd(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
-                            void* y_d, uint8_t* argmax_d, void* stream);
-
 /* The stem's weight gradient taken straight from the gradient of the max-pool output behind it (conv_stemw.hip): g is the packed stem
  * geometry of urso_conv_igemm / urso_conv_wgrad (net.py:170-176), x_d the molded input, dpool_d the gradient w.r.t. the pool OUTPUT
  * [B][OH/2][OW/2][64] and argmax_d the bytes urso_maxpool3x3s2_fwd stored.  Result = urso_maxpool3x3s2_bwd(relu_mask = 1) followed by

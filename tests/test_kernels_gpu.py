@@ -1519,49 +1519,3 @@ def test_two_3x3_weight_gradients_in_one_launch(dt, shapes):
         assert float(dw.abs().max()) > 0 and relerr(part, dw.double()) < 5e-5, (i, relerr(part, dw.double()))
         assert relerr(col, cs.double()) < 5e-5
     assert hip.conv_wgrad_pair_splits(gs[0], hip.geom(4, 32, 40, 64, 32, 40, 64, 3, 3, 1, 1, 1, 1), dt) is None      # conv_c3g.hip's layer
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("size", [(2, 64, 128, True, 0), (3, 36, 76, True, 0), (2, 20, 64, False, 0), (1, 132, 188, True, 8), (4, 256, 320, True, 0)],
-                         ids=["one_tile_column", "ragged", "no_relu", "capped_grid_several_tiles_per_block", "many_tiles"])
-def test_stem_and_max_pool_in_one_launch(dt, size):
-    """urso_stem_conv_pool_fwd (conv_stem.hip: stemp_kernel): conv1 + ReLU + 3x3 / stride-2 'same' max-pool without conv1's output in
-    memory, on 9 x 32 conv tiles with a stride of 8 x 30.  Pooled tensor and arg-max bytes must be BIT-IDENTICAL to urso_conv_igemm
-    followed by urso_maxpool3x3s2_fwd (same MFMA order per output, same rounding, taps scanned in the same order, first maximum wins).
-    Pooled sizes that are not multiples of the 4 x 15 pooled pixels of a tile; windows clipped at the bottom / right image border; with and
-    without ReLU (negative maxima: bit 4 of the arg-max byte); a grid cap that makes every block walk several tiles."""
-    hip = _hip()
-    B, H, W, relu, cap = size
-    N = 64
-    torch.manual_seed(H + W + dt)
-    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
-    meanp = torch.tensor([123.7, 116.8, 103.9])
-    molded = torch.empty(B, H, W, 4, dtype=hip.TORCH_DT[dt], device="cuda")
-    hip.mold_images(B, H, W, img.cuda(), meanp.cuda(), dt, molded)
-    w = torch.randn(7, 7, 3, N) / 12
-    bias = torch.randn(N) * 0.1
-    bn = (torch.rand(N) + 0.5, torch.randn(N) * 0.1, torch.randn(N) * 0.1, torch.rand(N) + 0.5)
-    wf = torch.empty(N * 7 * 4 * 8, dtype=hip.TORCH_DT[dt], device="cuda")
-    biasf = torch.empty(N, dtype=torch.float32, device="cuda"); scale = torch.empty_like(biasf)
-    hip.stem_weight_pack(N, dt, dev(w), dev(bias), dev(bn[0]), dev(bn[1]), dev(bn[2]), dev(bn[3]), 1e-3, wf, biasf, scale)
-    OH, OW = H // 2, W // 2
-    g = hip.geom(B, H, W // 2, 8, OH, OW, N, 7, 4, 2, 1, 3, 2)
-    flags = hip.EPI_RELU if relu else 0
-    y = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
-    p_ref = torch.empty(B, OH // 2, OW // 2, N, dtype=hip.TORCH_DT[dt], device="cuda"); am_ref = torch.empty(B, OH // 2, OW // 2, N, dtype=torch.uint8, device="cuda")
-    hip.conv_igemm(g, dt, flags, molded, wf, biasf, None, None, y)
-    hip.maxpool_fwd(B, OH, OW, N, dt, y, p_ref, am_ref)
-    p = torch.full_like(p_ref, 9.0); am = torch.full_like(am_ref, 99)
-    with hip.options(grid_cap=cap):
-        hip.stem_conv_pool_fwd(g, dt, flags, molded, wf, biasf, p, am)
-    torch.cuda.synchronize()
-    assert float(p_ref.float().abs().max()) > 0
-    assert torch.equal(p.view(torch.int16), p_ref.view(torch.int16)), float((p.float() - p_ref.float()).abs().max())
-    assert torch.equal(am, am_ref), int((am != am_ref).sum())
-    if not relu:
-        assert int((am & 16).sum()) > 0 and int((am & 16).sum()) < am.numel()
-    # without arg-max bytes (inference plans)
-    p2 = torch.full_like(p_ref, 9.0)
-    hip.stem_conv_pool_fwd(g, dt, flags, molded, wf, biasf, p2, None)
-    torch.cuda.synchronize()
-    assert torch.equal(p2.view(torch.int16), p_ref.view(torch.int16))

@@ -201,218 +201,3 @@ int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src,
     else URSO_KLAUNCH((stem_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(stem)");
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The stem with the 3x3 / stride-2 'same' max-pool behind it (net.py:170-176) in ONE kernel: conv1's output (335 MB at cfg2) is read by
-// nothing but the pool, so it never has to reach memory -- the pool's launch (116 us: 335 MB read, 126 MB written) disappears and the
-// stem stops writing its 335 MB.  A pooling window (conv rows 2 py .. 2 py + 2) straddles every 8-row tile boundary, so the tile is
-// 9 conv rows x 32 columns on a stride of 8 rows x 30 columns: 4 x 15 pooled pixels per tile, 1.2x the stem's multiplications.
-//   * 6 waves: wave (cw = w & 1, pw = w >> 1) computes 32 filters x conv rows 3 pw .. 3 pw + 2 exactly as stem_kernel's waves compute their
-//     four rows (23-row input patch, 11 patch rows x 2 halves per wave, 42 MFMAs);
-//   * ReLU -> 16-bit -> LDS tile [9 x 32 pixels][64 filters] -- bit for bit the values stem_kernel would have stored;
-//   * 480 (pooled pixel, 8-channel vector) items over the 384 threads: the nine taps in urso_maxpool3x3s2_fwd's order, strict >, first
-//     maximum wins, bit 4 of the arg-max byte = window maximum <= 0: pooled tensor and arg-max bytes identical to the two-launch path.
-constexpr int SP_ROWS = 9, SP_TY = 8, SP_TX = 30, SP_PR = 4, SP_PC = 15;                 // conv rows per tile; tile strides; pooled rows / columns per tile
-constexpr int SP_PROWS = 2 * SP_ROWS + 5, SP_PIECES = SP_PROWS * (ST_PROW_B / 16);       // 23 patch rows x 36 pieces = 828
-constexpr int SP_ABUF = 13312, SP_OOFF = 2 * SP_ABUF, SP_BOFF = SP_OOFF + SP_ROWS * 32 * 128, SP_LDS = SP_BOFF + 256;
-
-struct StempArgs {
-    const void* src; const void* wgt; const float* bias; void* dst; uint8_t* am;
-    uint32_t src_bytes, dst_bytes, am_bytes;
-    int B, H, W, OH, OW, PH, PW, tiles_x, tiles_y, ntiles;      // H, W input pixels; OH, OW conv output; PH, PW pooled
-    int relu, dbg;
-};
-
-template <typename T>
-__global__ __launch_bounds__(384, 2) void stemp_kernel(const StempArgs a) {
-    static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, pw = wave >> 1;
-    int l31 = lane & 31;
-    const int h = lane >> 5;
-
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int cpx = ceil_div(a.ntiles, 8);
-    const int t_end = min((xcd + 1) * cpx, a.ntiles);
-    int tile = xcd * cpx + lb;
-    if (tile >= t_end) return;
-
-    const i32x4_t rs = st_rsrc(a.src, a.src_bytes);
-    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.dst_bytes);
-    const __amdgpu_buffer_rsrc_t ram = make_rsrc(a.am, a.am ? a.am_bytes : 0);
-
-    int lane_d = lane;
-    auto tile_origin = [&](int t, int& b, int& ty, int& tx) {
-        tx = t % a.tiles_x; const int q = t / a.tiles_x;
-        ty = q % a.tiles_y; b = q / a.tiles_y;
-    };
-    // patch DMA: instruction i of a wave moves pieces 64 (wave + 6 i) + lane of the row-major [23][36] piece grid (3 instructions x 6 waves cover 828)
-    auto dma_tile = [&](int t, int buf) {
-        int b, ty, tx;
-        tile_origin(t, b, ty, tx);
-        const int iy0 = 2 * (ty * SP_TY) - 3, ix0 = 2 * (tx * SP_TX) - 4;
-        asm volatile("" : "+v"(lane_d));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (wave + 6 * i >= SP_ABUF / 1024) continue;               // 13 KiB-slots hold the 828 pieces (wave-uniform)
-            const int p = 64 * (wave + 6 * i) + lane_d;
-            const int r = (p * 1821) >> 16, s = p - 36 * r;             // p / 36 for p < 1152
-            const int iy = iy0 + r, ix = ix0 + 2 * s;
-            const bool ok = p < SP_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            st_dma16(rs, lds0 + buf * SP_ABUF + (wave + 6 * i) * 1024, ok ? (uint32_t)(((b * a.H + iy) * a.W + ix) * 8) : URSO_OOB_SHIFT);
-        }
-    };
-
-    i32x4_t wfr[14];
-    {
-        const int lg = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
-        const char* wrow = (const char*)a.wgt + (size_t)(32 * cw + lg) * (224 * 2);
-#pragma unroll
-        for (int j = 0; j < 14; ++j) wfr[j] = *(const i32x4_t*)(wrow + ((j >> 1) * 32 + (j & 1) * 16 + 8 * h) * 2);
-    }
-    if (tid < 64) *(float*)(smem + SP_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
-
-    constexpr int NSTO = 4;                                // stores per thread and tile: two (pooled pixel, vector) items x (values, arg-max bytes)
-    dma_tile(tile, 0);
-    int buf = 0;
-    bool first = true;
-    while (true) {
-        const bool has_next = tile + bpx < t_end;
-        if (first) st_wait_vm<0>(); else st_wait_vm<NSTO>();
-        first = false;
-        st_barrier();
-        if (has_next) dma_tile(tile + bpx, buf ^ 1);
-        const char* sA = smem + buf * SP_ABUF;
-
-        f32x16_t acc[3];
-        {
-            const f32x4_t* bp = (const f32x4_t*)(smem + SP_BOFF + (32 * cw + 16 * h) * 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4_t b4 = bp[q];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) { acc[r][4 * q] = b4.x; acc[r][4 * q + 1] = b4.y; acc[r][4 * q + 2] = b4.z; acc[r][4 * q + 3] = b4.w; }
-            }
-        }
-        asm volatile("" : "+v"(l31));
-        // step s = (patch row rho of the 11 the wave's 3 conv rows touch, half): used by conv row r as window row ky = rho - 2 r
-        i32x4_t f[4];
-        auto rd = [&](i32x4_t& fs, int s) {
-            const int rho = s >> 1, half = s & 1;
-            fs = *(const i32x4_t*)(sA + (6 * pw + rho) * ST_PROW_B + l31 * 16 + half * 32 + h * 16);
-        };
-        rd(f[0], 0);
-        rd(f[1], 1);
-        rd(f[2], 2);
-#pragma unroll
-        for (int s = 0; s < 22; ++s) {
-            if (s + 3 < 22) rd(f[(s + 3) & 3], s + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            const int rho = s >> 1, half = s & 1;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int ky = rho - 2 * r;
-                if (ky >= 0 && ky <= 6) StMma<T>::run(wfr[2 * ky + half], f[s & 3], acc[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // ---- ReLU -> 16-bit -> LDS tile [288 pixels][64 filters] (16-byte slot ^ ((px >> 1) & 7), as stem_kernel)
-        char* sO = smem + SP_OOFF;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int px = (3 * pw + r) * 32 + l31;
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                T o[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float y = acc[r][8 * v + e]; y = a.relu ? fmaxf(y, 0.f) : y; o[e] = Elem<T>::from_f(y); }
-                i32x4_t ov; __builtin_memcpy(&ov, o, 16);
-                *(i32x4_t*)(sO + px * 128 + (((4 * cw + 2 * h + v) ^ ((px >> 1) & 7)) << 4)) = ov;
-            }
-        }
-        int b, ty, tx;
-        tile_origin(tile, b, ty, tx);
-        st_barrier();
-        // ---- the pool: item = (pooled pixel (pr, pc) of the tile, channel vector cv); taps in urso_maxpool3x3s2_fwd's order
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tid + 384 * it;
-            const int pp = item >> 3, cv = item & 7;
-            const int pr = (pp * 4370) >> 16, pc = pp - SP_PC * pr;                 // pp / 15 for pp < 64
-            const int py = ty * SP_PR + pr, pxg = tx * SP_PC + pc;
-            const bool valid = item < SP_PR * SP_PC * 8 && py < a.PH && pxg < a.PW;
-            float best[8]; int arg[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
-            if (valid && !a.dbg) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (2 * py + ky >= a.OH) continue;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        if (2 * pxg + kx >= a.OW) continue;
-                        const int px = (2 * pr + ky) * 32 + 2 * pc + kx;
-                        const i32x4_t raw = *(const i32x4_t*)(sO + px * 128 + ((cv ^ ((px >> 1) & 7)) << 4));
-                        T e[8]; __builtin_memcpy(e, &raw, 16);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) { const float v = Elem<T>::to_f(e[q]); if (v > best[q]) { best[q] = v; arg[q] = ky * 3 + kx; } }
-                    }
-                }
-            }
-            T o[8]; uint32_t ab0 = 0, ab1 = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                o[q] = Elem<T>::from_f(best[q]);
-                const uint32_t byte = (uint32_t)(arg[q] | (best[q] > 0.f ? 0 : 16));
-                if (q < 4) ab0 |= byte << (8 * q); else ab1 |= byte << (8 * (q - 4));
-            }
-            i32x4_t ov; __builtin_memcpy(&ov, o, 16);
-            const uint32_t pix = (uint32_t)((b * a.PH + py) * a.PW + pxg);
-            buf_store16(rds, valid ? pix * 128u + (uint32_t)cv * 16u : URSO_OOB_SHIFT, ov);
-            __builtin_amdgcn_raw_buffer_store_b64(i32x2_t{(int)ab0, (int)ab1}, ram, (valid && a.am) ? pix * 64u + (uint32_t)cv * 8u : URSO_OOB_SHIFT, 0, 0);
-        }
-        if (!has_next) break;
-        tile += bpx; buf ^= 1;
-    }
-}
-
-// 16-bit packed stem geometry (urso_stem_fits) with an even conv output: the pooled tensor is [B][OH/2][OW/2][64]
-bool urso_stem_pool_fits(const urso_conv_geom* g, int dt) {
-    if (!urso_stem_fits(g, dt, 0, nullptr, nullptr) || (g->OH & 1) || (g->OW & 1)) return false;
-    return (long long)g->B * (g->OH / 2) * (g->OW / 2) * 128 < 0x7FFFFF00ll;
-}
-
-int urso_stem_pool_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, void* dst, uint8_t* am, hipStream_t st) {
-    StempArgs a;
-    a.src = src; a.wgt = wgt; a.bias = bias; a.dst = dst; a.am = am; a.relu = relu; a.dbg = g_urso_opt.pwx_dbg & 8;      // (timing experiment: no pool arithmetic)
-    a.B = g->B; a.H = g->H; a.W = 2 * g->W; a.OH = g->OH; a.OW = g->OW; a.PH = g->OH / 2; a.PW = g->OW / 2;
-    a.src_bytes = (uint32_t)((size_t)a.B * a.H * a.W * 8); a.dst_bytes = (uint32_t)((size_t)a.B * a.PH * a.PW * 128);
-    a.am_bytes = (uint32_t)((size_t)a.B * a.PH * a.PW * 64);
-    a.tiles_x = ceil_div(a.PW, SP_PC); a.tiles_y = ceil_div(a.PH, SP_PR); a.ntiles = a.B * a.tiles_y * a.tiles_x;
-    int bpx = ceil_div(a.ntiles, 8);
-    const int cap = 2 * st_device_cus() / 8;
-    if (bpx > cap) bpx = cap;
-    if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
-    const dim3 grid(8 * bpx), blk(384);
-    if (dt == URSO_BF16) URSO_KLAUNCH((stemp_kernel<__bf16>), grid, blk, 0, st, a);
-    else URSO_KLAUNCH((stemp_kernel<_Float16>), grid, blk, 0, st, a);
-    return urso_check_launch("urso_stem_conv_pool_fwd");
-}
-
-// conv1 + BatchNorm (folded) + ReLU + MaxPooling2D(3, strides 2, 'same') of net.py:170-176 in one launch (stemp_kernel): src the molded
-// input, wgt / bias as urso_conv_igemm takes them for the packed stem geometry g, y_d the POOLED tensor [B][OH/2][OW/2][64], argmax_d
-// its arg-max bytes (may be NULL) -- both identical to urso_conv_igemm followed by urso_maxpool3x3s2_fwd.
-extern "C" int urso_stem_conv_pool_fwd(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
-                                       void* y_d, uint8_t* argmax_d, void* stream) {
-    if (!g || !src_d || !wgt_d || !y_d) { urso_set_error("urso_stem_conv_pool_fwd: null argument"); return URSO_EINVAL; }
-    if (flags & ~URSO_EPI_RELU) { urso_set_error("urso_stem_conv_pool_fwd: only URSO_EPI_RELU"); return URSO_EINVAL; }
-    if (!urso_stem_pool_fits(g, dt)) { urso_set_error("urso_stem_conv_pool_fwd: not the packed 16-bit stem geometry with an even output size"); return URSO_EINVAL; }
-    if ((((uintptr_t)src_d) | ((uintptr_t)wgt_d) | ((uintptr_t)y_d) | ((uintptr_t)argmax_d)) & 15) { urso_set_error("urso_stem_conv_pool_fwd: pointers must be 16-byte aligned"); return URSO_EINVAL; }
-    hipStream_t st = (hipStream_t)stream;
-    const double M = (double)g->B * g->OH * g->OW;
-    ProfScope ps(st, URSO_K_IGEMM, 2.0 * M * 64.0 * 147.0, (double)g->B * g->H * g->W * 16 + M / 4 * (128 + 64) + 224.0 * 64 * 2);
-    return urso_stem_pool_launch(g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src_d, wgt_d, bias_d, y_d, argmax_d, st);
-}

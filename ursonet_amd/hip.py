@@ -90,7 +90,6 @@ _SIGS = {
     "urso_conv_wgrad_partial": (_i, [_gp, _i, _vp, _vp, _vp, _sz, _vp]),
     "urso_param_desc_init": (_i, [_dp, _i, _i, _i, _i, _i, _i, _f, _f]),
     "urso_param_batch_plan": (_i, [_i, _dp, C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _i]),
-    "urso_stem_conv_pool_fwd": (_i, [_gp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "urso_wgrad_group_fits": (_i, [_gp, _i]),
     "urso_conv_wgrad_pair_splits": (_i, [_gp, _gp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "urso_conv_wgrad_partial2": (_i, [_gp, _gp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp]),
@@ -315,12 +314,6 @@ class ParamBatch(object):
         t, nb = self.maps[(phase, key)]
         if nb:
             _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
-
-
-def stem_conv_pool_fwd(g, dt, flags, src, wgt, bias, y, argmax, stream=None):
-    """urso_stem_conv_pool_fwd: the packed 7x7 stem + ReLU + 3x3 / stride-2 max-pool in one launch (pooled tensor + arg-max bytes)."""
-    _chk(_lib.urso_stem_conv_pool_fwd(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(y), ptr(argmax), stream_ptr(stream)),
-         "urso_stem_conv_pool_fwd")
 
 
 def conv_wgrad_pair_splits(g0, g1, dt):
