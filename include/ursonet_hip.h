@@ -219,6 +219,11 @@ int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, cons
  * workspace every block walks whole tiles. */
 int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_add);
 size_t urso_conv_igemm_halo_ws_bytes(void);
+/* The same layers run in conv_halo2.hip where that wins: WHOLE tiles of 128 MI virtual pixels x 64 NJ filters, (MI, NJ) picked per layer so
+ * that the tiles fill the CUs in whole rounds (cfg2: 226 tiles of 384 x 128 in stage 4, 240 of 384 x 64 in stage 5, one per CU) -- no
+ * hand-over between blocks, no residency assumption, bit-identical to conv_halo.hip's whole-tile schedule.  Returns 10 * MI + NJ for the
+ * layer, or 0 when conv_halo.hip keeps it (policy options "hconv2", "hconv2_shape"; has_ws: a hand-over workspace would be passed). */
+int urso_conv_igemm_halo2_shape(const urso_conv_geom* g, int dt, int flags, int has_add, int has_ws);
 
 /*
  * Winograd F(2x2, 3x3) evaluation of a 3x3 / stride-1 / pad-1 forward conv (net.py:106,143: res{2..5}x_branch2b), 16-bit dtypes, epilogue

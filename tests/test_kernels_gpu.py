@@ -212,8 +212,66 @@ def test_halo_conv_kernel_forced(case, dt, cap):
     production size and capped to 8 / 24 blocks so that a block's contiguous run holds several tiles: continuous halo / filter
     stream across tile seams, several filter tiles per pixel tile (N = 256), transposed epilogue, mask-only data gradient."""
     hip = _hip()
-    with hip.options(hconv=2, grid_cap=cap):
+    with hip.options(hconv=2, hconv2=0, grid_cap=cap):
         test_conv_forward_and_gradients(case, dt)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("cap", [0, 8])
+@pytest.mark.parametrize("shape", [32, 31, 22, 21, 12, 11])
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[-1] for c in HALO_CASES])
+def test_halo2_conv_kernel_forced(case, shape, dt, cap):
+    """conv_halo2.hip (whole tiles of 128 MI x 64 NJ, accumulators in AccVGPRs, two-slot filter ring, halo row offsets from an LDS table)
+    on every tile shape that fits the layer, with the grid at its production size and capped to 8 blocks so that a block walks several
+    tiles: the continuous halo / filter stream across tile seams, the next tile's offset table filled while this one runs, the epilogue's
+    stores in flight across the seam; forward with and without ReLU / residual-free, masked data gradient (the forms res{4,5}x_branch2b use)."""
+    hip = _hip()
+    B, H, W, Ci, N = case[:5]
+    with hip.options(hconv=2, hconv2=2, hconv2_shape=shape, grid_cap=cap):
+        g = hip.geom(B, H, W, Ci, H, W, N, 3, 3, 1, 1, 1, 1)
+        if hip.conv_igemm_halo2_shape(g, dt, hip.EPI_RELU) != shape:
+            pytest.skip("tile shape %d does not fit this layer" % shape)
+        test_conv_forward_and_gradients(case, dt)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(32, 32, 40, 256, 256), (32, 16, 20, 512, 512), (16, 32, 40, 256, 256), (3, 19, 23, 128, 384)])
+def test_halo2_conv_equals_whole_tile_halo_kernel_bit_for_bit(shape, dt):
+    """Same MFMA, same k order per output element: conv_halo2.hip on every tile shape that fits (incl. the one its cost model picks for the
+    cfg2 stage-4 / stage-5 layers) equals conv_halo.hip's whole-tile schedule bit for bit -- forward with ReLU and the masked data-gradient
+    form -- and is reproducible from launch to launch."""
+    hip = _hip()
+    B, H, W, Ci, N = shape
+    torch.manual_seed(B + H + Ci)
+    tdt = hip.TORCH_DT[dt]
+    x = torch.randn(B, H, W, Ci, device="cuda").to(tdt)
+    wf = (torch.randn(N, 3, 3, Ci, device="cuda") / np.sqrt(9 * Ci)).to(tdt)
+    bias = torch.randn(N, device="cuda")
+    msk = torch.randn(B, H, W, N, device="cuda").to(tdt)
+    g = hip.geom(B, H, W, Ci, H, W, N, 3, 3, 1, 1, 1, 1)
+
+    def run():
+        y = torch.full((B, H, W, N), 3.0, dtype=tdt, device="cuda"); ym = torch.full((B, H, W, N), 3.0, dtype=tdt, device="cuda")
+        hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, None, y)
+        hip.conv_igemm(g, dt, 0, x, wf, bias, None, msk, ym)
+        torch.cuda.synchronize()
+        return y, ym
+    with hip.options(hconv=2, hconv2=0, c3=0):
+        y0, ym0 = run()
+    taken = 0
+    with hip.options(hconv=2, c3=0):
+        picked = hip.conv_igemm_halo2_shape(g, dt, hip.EPI_RELU)
+    for shp in (32, 31, 22, 21, 12, 11):
+        with hip.options(hconv=2, hconv2=2, hconv2_shape=shp, c3=0):
+            if hip.conv_igemm_halo2_shape(g, dt, hip.EPI_RELU) != shp:
+                continue
+            y, ym = run(); y2, ym2 = run()
+        taken += 1
+        assert torch.equal(y, y0) and torch.equal(ym, ym0), "tile shape %d differs from conv_halo.hip" % shp
+        assert torch.equal(y, y2) and torch.equal(ym, ym2), "tile shape %d is not reproducible" % shp
+    assert taken >= 2
+    if B >= 16:
+        assert picked in (32, 31), "cost model: cfg2 / cfg4 stage-4 and stage-5 layers run on 384-pixel tiles (picked %d)" % picked
 
 
 @pytest.mark.parametrize("dt", [1, 2])

@@ -11,7 +11,8 @@ for (B, H, W, C, N) in ((32, 32, 40, 256, 256), (32, 16, 20, 512, 512)):
     ws = torch.zeros(hip.conv_igemm_halo_ws_bytes() // 4 + 16, device="cuda")
     g = hip.geom(B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 1)
     out = []
-    for name, o in (("full", 0), ("noEpi", 1), ("noLoop", 2), ("neither", 3), ("wholeTiles", 4), ("wholeTiles noEpi", 5)):
+    for name, o in (("full", 0), ("noEpi", 1), ("noLoop", 2), ("neither", 3), ("wholeTiles", 4), ("wholeTiles noEpi", 5),
+                    ("loaders0-3", 16), ("noCopies", 32), ("noBarrier", 64), ("noCopies noBarrier", 96), ("loaders0-3 noBarrier", 80)):
         with hip.options(hconv_dbg=o):
             f = lambda: hip.conv_igemm_ex(g, dt, hip.EPI_RELU, x, wf, b, None, None, y, None, ws)
             for _ in range(3): f()

@@ -33,6 +33,9 @@ struct UrsoOptions {
     int stem = 1;            // conv_stem.hip (im2col on the LDS read side) for the packed 7x7 stem
     int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);
                              // ursonet_amd/dp.py leaves the rest to the collective's resident workgroups.  0 = all of the device's
+    int hconv2 = 1;          // conv_halo2.hip (whole tiles of a per-layer shape, no hand-over): 0 off, 1 where its cost model beats conv_halo.hip's schedule, 2 whenever a shape fits
+    int hconv2_shape = 0;    // 10 * MI + NJ: force its tile shape 128 MI x 64 NJ (tests, probes); 0 = by the cost model
+    int hconv_streamk = 1;   // conv_halo.hip may hand accumulators of cut tiles over between blocks (needs every block resident: ursonet_amd/dp.py switches it off while collectives run beside the step)
     int hconv_dbg = 0;       // kernel-development switches of conv_halo.hip (0 in production)
     int hwgrad = 1;          // conv_hwgrad.hip: halo-run weight gradient of the 3x3 layers with >= 128 channels (gradient groups in registers); 0 off, 1 on; 3 / 5 / 7: timing switches (tools/hwgrad_probe.py)
     int dense = 1;           // conv_dense.hip: skinny GEMM (<= 32 rows) for the Dense heads and their data gradients

@@ -40,7 +40,7 @@ struct HcArgs {
     int krow;                  // bytes per filter row (9 * C * 2)
     float rcp_vw, rcp_vh;
     int relu;
-    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop, bit 2 whole tiles only, bit 3 stream-K whenever a workspace is given
+    int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 skips the epilogue, bit 1 the main loop, bit 2 whole tiles only, bit 3 stream-K whenever a workspace is given, bit 4 copies issued by waves 0-3 only, bit 5 no copies in the loop (timing only), bit 6 no barrier in the loop (timing only)
     // schedule: every block owns a contiguous run of (tile, 64-channel chunk) units, run b = [floor(b units / G), ...).  Without a
     // hand-over workspace (flags == NULL) the units are whole tiles; with one ("stream-K") a tile cut by a run boundary is finished by
     // the block that holds its chunk 0, the other pieces hand their fp32 accumulators over through `part` in run order
@@ -91,7 +91,9 @@ constexpr int HC_NST = 8;                                  // vector-memory stor
 
 __device__ __forceinline__ void hc_sbarrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <typename T>
+// LW = waves that issue the LDS-DMA copies: 8 (every wave its eighth) or 4 (waves 0-3, one per SIMD: their SIMD partners 4-7 go straight
+// from the mid-step barrier to the MFMAs and keep the matrix pipe busy while the copies are issued)
+template <typename T, int LW>
 __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr int BM = HC_BM, BN = HC_BN, BSLOT = HC_BSLOT, ABUF = HC_ABUF, AOFF = HC_AOFF, XOFF = HC_XOFF;
@@ -134,10 +136,11 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     for (int i = 0; i < 2; ++i) rb[i] = 64 * wm + 32 * i + l31;
 
     // ---- filter-tile DMA roles: instruction q covers ring rows 8 (wave + 8 q) + r8
-    uint32_t bsrc0[2];
+    constexpr int NQ = 16 / LW, NJ = 7 * (8 / LW);
+    uint32_t bsrc0[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int Rr = 8 * (wave + 8 * q) + r8;
+    for (int q = 0; q < NQ; ++q) {
+        const int Rr = 8 * (wave + LW * q) + r8;
         const int nl = (Rr & ~31) + hc_perm(Rr & 31);
         bsrc0[q] = (uint32_t)nl * (uint32_t)a.krow + (uint32_t)((c8 ^ ((Rr >> 1) & 7)) << 4);
     }
@@ -160,24 +163,26 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
 
     // halo-tile DMA roles of a tile: instruction j covers halo rows 8 (wave + 8 j) + r8 (JA <= 7 instructions; a wave skips the
     // instructions whose rows lie beyond the halo, so the waits below are all vmcnt(0)-style, never counted per wave)
-    uint32_t arow[7];
+    uint32_t arow[NJ];
     auto set_arow = [&](int tile_) {
         const int p0_ = (tile_ / a.tilesN) * BM;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int r = 8 * (wave + 8 * j) + r8;
+        for (int j = 0; j < NJ; ++j) {
+            const int r = 8 * (wave + LW * j) + r8;
             const int pix = (r < a.R) ? real_pixel(p0_ - (a.Vw + 1) + r) : -1;
             arow[j] = (pix >= 0) ? (uint32_t)pix * (uint32_t)a.C * 2u + (uint32_t)((c8 ^ ((r >> 1) & 7)) << 4) : URSO_OOB_SHIFT;
         }
     };
     auto dma_a = [&](int j, int cc, int buf) {                 // static j
-        if (8 * (wave + 8 * j) < a.R)
-            hc_dma16(rs, lds0 + AOFF + buf * ABUF + (wave + 8 * j) * 1024, arow[j] + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
+        if (wave < LW && 8 * (wave + LW * j) < a.R)
+            hc_dma16(rs, lds0 + AOFF + buf * ABUF + (wave + LW * j) * 1024, arow[j] + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
     };
     auto dma_b = [&](int n0_, int cc, int t, int slot) {       // filter tile (chunk cc, tap t) of the filter block starting at n0_
         const uint32_t koff = (uint32_t)n0_ * (uint32_t)a.krow + (uint32_t)(t * a.C + cc * 64) * 2u;
-        hc_dma16(rw, lds0 + slot * BSLOT + wave * 1024, bsrc0[0] + koff);
-        hc_dma16(rw, lds0 + slot * BSLOT + (wave + 8) * 1024, bsrc0[1] + koff);
+        if (wave < LW) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hc_dma16(rw, lds0 + slot * BSLOT + (wave + LW * q) * 1024, bsrc0[q] + koff);
+        }
     };
 
     int tile = t_begin;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     {   // ---- block prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
         const int n0 = (tile % a.tilesN) * BN;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) dma_a(j, c_begin, 0);
+        for (int j = 0; j < NJ; ++j) dma_a(j, c_begin, 0);
         dma_b(n0, c_begin, 0, 0);
         dma_b(n0, c_begin, 1, 1);
         hc_wait_vm<0>();
@@ -252,13 +257,16 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
                 // ---- mid-step: this wave's copies issued one step ago have landed -> barrier -> every wave's have, and every wave has
                 //      finished reading the previous step's ring slot and (at t = 0) the previous chunk's halo buffer
                 if (t == 0 && first_wait_after_epilogue) hc_wait_vm<HC_NST>(); else hc_wait_vm<0>();
-                hc_sbarrier();
-                {   // filter tile two steps ahead -> ring slot (t + 2) % 3; one piece of the next halo tile -> the other halo buffer
+                if (!(a.dbg & 64)) hc_sbarrier();
+                if (!(a.dbg & 32)) {   // filter tile two steps ahead -> ring slot (t + 2) % 3; one piece of the next halo tile -> the other halo buffer
                     const int t2 = (t + 2) % 9;
                     const bool wrap = t + 2 >= 9;
                     const bool okb = !wrap || more_a;
                     if (okb) dma_b((wrap && last) ? n0n : n0, wrap ? cca : cc, t2, (t + 2) % 3);
-                    if (t < 7 && t < a.JA && more_a) dma_a(t, cca, buf ^ 1);
+                    if (t < 7 && t < a.JA && more_a) {
+#pragma unroll
+                        for (int jj = 0; jj < 8 / LW; ++jj) dma_a((8 / LW) * t + jj, cca, buf ^ 1);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -400,6 +408,9 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HcArgs a) {
     }
 }
 
+int urso_hconv2_try_launch(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* mask,
+                           void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, bool has_ws, hipStream_t st);      // conv_halo2.hip
+
 static int hc_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 128 == 0, N % 128 == 0, halo tile within the LDS
@@ -430,6 +441,11 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
                       hipStream_t st) {
     (void)add;
+    {   // whole tiles of a per-layer shape, one per CU where the layer allows it (conv_halo2.hip)
+        const int r2 = urso_hconv2_try_launch(g, dt, relu, src, wgt, bias, mask, dst, src_bytes, wgt_bytes, dst_bytes, ws,
+                                              ws && ws_bytes >= urso_hconv_ws_bytes(), st);
+        if (r2 != 0) return r2 > 0 ? URSO_OK : r2;
+    }
     HcArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst;
     a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
@@ -453,18 +469,23 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     // fewer tiles than CUs (stage 5 of cfg2: 180; every stage-4/5 layer at batch 16): whole tiles would leave CUs idle for the whole
     // launch -- with the hand-over workspace the (tile, chunk) units are dealt to ALL CUs instead (cfg2 stage 5: 6 units per block
     // instead of 8, measured 62 -> 50 us per layer)
-    if (ws && ws_bytes >= urso_hconv_ws_bytes() && !(a.dbg & 4) && g_urso_opt.grid_cap <= 0 && G < hc_device_cus()) {
+    if (ws && ws_bytes >= urso_hconv_ws_bytes() && !(a.dbg & 4) && g_urso_opt.hconv_streamk && g_urso_opt.grid_cap <= 0 && G < hc_device_cus()) {
         int G2 = hc_device_cus(); const int units = a.ntiles * a.nchunks;
         if (G2 > units) G2 = units;
         G2 = G2 / 8 * 8;
         if (G2 > G && G2 <= 1024 && ceil_div(units, G2) < ceil_div(a.ntiles, G) * a.nchunks) { G = G2; grid = dim3(G2); }
     }
-    const bool can = ws && ws_bytes >= urso_hconv_ws_bytes() && G <= hc_device_cus() && G <= 1024 && !(a.dbg & 4);
+    const bool can = ws && ws_bytes >= urso_hconv_ws_bytes() && G <= hc_device_cus() && G <= 1024 && !(a.dbg & 4) && g_urso_opt.hconv_streamk;
     const bool streamk = can && ((a.dbg & 8) || ceil_div(a.ntiles * a.nchunks, G) < ceil_div(a.ntiles, G) * a.nchunks);      // hconv_dbg bit 3: whenever a workspace is given (tests)
     a.flags = streamk ? (unsigned int*)ws : nullptr;
     a.part = streamk ? (float*)((char*)ws + 4096) : nullptr;
     a.units = streamk ? a.ntiles * a.nchunks : a.ntiles;
-    if (dt == URSO_BF16) URSO_KLAUNCH((hconv_kernel<__bf16>), grid, blk, 0, st, a);
-    else URSO_KLAUNCH((hconv_kernel<_Float16>), grid, blk, 0, st, a);
+    if (a.dbg & 16) {
+        if (dt == URSO_BF16) URSO_KLAUNCH((hconv_kernel<__bf16, 4>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((hconv_kernel<_Float16, 4>), grid, blk, 0, st, a);
+    } else {
+        if (dt == URSO_BF16) URSO_KLAUNCH((hconv_kernel<__bf16, 8>), grid, blk, 0, st, a);
+        else URSO_KLAUNCH((hconv_kernel<_Float16, 8>), grid, blk, 0, st, a);
+    }
     return urso_check_launch("urso_conv_igemm(halo)");
 }

@@ -479,6 +479,12 @@ extern "C" int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flag
 
 extern "C" size_t urso_conv_igemm_halo_ws_bytes(void) { return urso_hconv_ws_bytes(); }
 
+int urso_hconv2_pick(const urso_conv_geom* g, bool has_ws);                                                                          // conv_halo2.hip
+extern "C" int urso_conv_igemm_halo2_shape(const urso_conv_geom* g, int dt, int flags, int has_add, int has_ws) {
+    if (!g || !urso_hconv_fits(g, dt, flags, has_add ? (const void*)g : nullptr)) return 0;
+    return urso_hconv2_pick(g, has_ws != 0);
+}
+
 extern "C" size_t urso_conv_igemm_ws_bytes(const urso_conv_geom* g, int dt) {
     if (!g || g->FH > 0 || (g->N & 3)) return 0;
     const int VE = 16 / (int)dt_size(dt);
@@ -548,9 +554,12 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem: 7x7x3 real taps of the 7x4x8 padded ones
     // a strided pointwise layer reads only the sampled pixels
     const double src_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? (double)a.M * g->C * es : (double)src_bytes;
-    double bytes = src_alg + (double)wgt_bytes + (double)dst_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
-                   (add_d ? dst_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? dst_elems / 8 : dst_elems * es) : 0) +
-                   ((flags & URSO_EPI_EMIT_BITS) ? dst_elems / 8 : 0);
+    // a scattered destination (compact stage-boundary gradient) is written -- and its residual / mask operands are read -- at the B x OH x OW
+    // computed pixels only; the zero fill of the rest is another launch's bytes
+    const double wr_elems = (double)g->B * g->OH * g->OW * g->N;
+    double bytes = src_alg + (double)wgt_bytes + wr_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
+                   (add_d ? wr_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? wr_elems / 8 : wr_elems * es) : 0) +
+                   ((flags & URSO_EPI_EMIT_BITS) ? wr_elems / 8 : 0);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     if (urso_dense_fits(g, dt, flags, a.pointwise, a.M))          // Dense heads: <= 32 rows, weights streamed once (conv_dense.hip)
         return urso_dense_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);

@@ -82,6 +82,7 @@ _SIGS = {
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_igemm_bits_ok": (_i, [_gp, _i, _i, _sz]),
     "urso_conv_igemm_halo_ok": (_i, [_gp, _i, _i, _i]),
+    "urso_conv_igemm_halo2_shape": (_i, [_gp, _i, _i, _i, _i]),
     "urso_conv_igemm_halo_ws_bytes": (_sz, []),
     "urso_conv_igemm_ex": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_wgrad_ws_bytes": (_sz, [_gp, _i]),
@@ -166,7 +167,7 @@ def _chk(rc, what):
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "pair", "c3", "stem", "cus")
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "stem", "cus")
 
 
 def set_option(name, value):
@@ -260,6 +261,11 @@ def conv_igemm_halo_ws_bytes():
 
 def conv_igemm_halo_ok(g, dt, flags, has_add=False):
     return bool(_lib.urso_conv_igemm_halo_ok(C.byref(g), dt, flags, int(bool(has_add))))
+
+
+def conv_igemm_halo2_shape(g, dt, flags, has_add=False, has_ws=False):
+    """10 * MI + NJ of the whole-tile halo kernel (conv_halo2.hip) for this layer, 0 when conv_halo.hip keeps it."""
+    return int(_lib.urso_conv_igemm_halo2_shape(C.byref(g), dt, flags, int(bool(has_add)), int(bool(has_ws))))
 
 
 def conv_igemm_ex(g, dt, flags, src, wgt, bias, add, mask, dst, bits_out=None, ws=None, stream=None):
