@@ -413,6 +413,8 @@ int urso_hconv2_try_launch(const urso_conv_geom* g, int dt, int relu, const void
 
 static int hc_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
+int urso_hconv2_pick(const urso_conv_geom* g, bool has_ws);                                                                          // conv_halo2.hip
+
 // Does (g, dt, flags) qualify?  3x3 / stride 1 / pad 1 / undilated, same-size output, C % 128 == 0, N % 128 == 0, halo tile within the LDS
 // budget -- and a tile count that fills the 256 one-block-per-CU slots evenly: every block walks ceil(tiles / blocks) tiles, so e.g. 340
 // tiles cost as much as 512.  hconv = 1 (default) takes the layer only when that rounding loses < 35 % (measured on cfg2: stage 3 659
@@ -426,6 +428,7 @@ bool urso_hconv_fits(const urso_conv_geom* g, int dt, int flags, const void* add
     if (g->C % 128 || g->N % HC_BN || g->N > HC_MAXN) return false;        // >= 2 channel chunks (the halo double buffer assumes it)
     if (HC_BM + 2 * (g->W + 2) > HC_AROWS || g->W + 1 < 8) return false;
     if ((size_t)g->B * (g->H + 1) * (g->W + 1) >= (1u << 24)) return false;
+    if (urso_hconv2_pick(g, true)) return true;               // conv_halo2.hip has a tile shape that fills the chip in whole rounds
     if (g_urso_opt.hconv == 1) {
         const int ntiles = ceil_div(g->B * (g->H + 1) * (g->W + 1), HC_BM) * (g->N / HC_BN), ncu = hc_device_cus();
         const int blocks = ntiles < ncu ? ntiles : ncu, rounds = ceil_div(ntiles, blocks);

@@ -2,21 +2,32 @@
 // Same layers as conv_halo.hip (3x3 / stride-1 / pad-1 with >= 128 channels: net.py:106,143 res{4,5}x_branch2b forward and, with the
 // flipped filter of urso_conv_weight_prep, their masked data gradient), same virtual pixel grid, same LDS swizzle, same DMA discipline.
 //
-// What is different, and why (tools/hconv_probe.py on the cfg2 stage-4 / stage-5 layers, 60.8 / 58.5 us per launch):
+// What is different, and why (tools/hconv2_probe.py, tools/hconv2_sweep.py; cfg2 stage-4 / stage-5 layers, conv_halo.hip 60.2 / 56.8 us):
 //   * conv_halo.hip walks 256 x 128 tiles; 340 / 180 of them do not divide 256 CUs, so it deals (tile, 64-channel chunk) units to the CUs and
-//     hands fp32 accumulators of cut tiles over through memory ("stream-K").  14 us of a launch remain with the step loop and the epilogue
-//     switched off: launch, first copies and that hand-over; and the hand-over needs every block resident (a hazard beside RCCL's workgroups).
-//   * Here the tile is 128 MI virtual pixels x 64 NJ filters (8 waves as 4 x 2, wave tile 32 MI x 32 NJ on v_mfma_f32_32x32x16) with (MI, NJ)
-//     picked so that the tile count fills the CUs in whole rounds: cfg2 stage 4 (43,296 virtual pixels x 256 filters) = 113 x 2 tiles of
-//     384 x 128 on 256 CUs, stage 5 (11,424 x 512) = 30 x 8 tiles of 384 x 64.  No hand-over, no flags, no residency assumption.
-//   * L2 -> LDS traffic per MAC is what binds these layers next to the matrix pipe (~11 TB/s chip-wide).  A halo tile is
-//     read by nine taps, a filter tile by one: per (chunk, tap) step a block copies 128 NJ * 64 B of filters + (BM + 2 Vw + 2) * 128 / 9 B of
-//     pixels, so tiles want to be TALL (many pixels) and narrow: 384 x 128 moves 22.7 KiB per step and 18.9 M MACs, 256 x 128 moves 21.2 KiB per
-//     12.6 M MACs.
-//   * 3 x 2 MFMA tiles per wave: 5 fragment reads per 6 MFMAs (conv_halo.hip: 4 per 4) -- the LDS read port is 17 % less loaded per MAC.
-//   * the filter ring has TWO slots (the halo double buffer of a 384-pixel tile takes 120 KiB): a slot is refilled behind the barrier that
-//     follows its last fragment read (every wave's reads are waited for with lgkmcnt(0) before it arrives there), one step before it is needed.
+//     hands fp32 accumulators of cut tiles over through memory ("stream-K"): that hand-over is ~6 us of a launch and needs every block
+//     resident (a hazard beside RCCL's workgroups).  Here the tile is 128 MI virtual pixels x 64 NJ filters (8 waves as 4 x 2, wave tile
+//     32 MI x 32 NJ on v_mfma_f32_32x32x16) with (MI, NJ) picked per layer so that the tile count fills the CUs in whole rounds: cfg2
+//     stage 4 (43,296 virtual pixels x 256 filters) = 113 x 2 tiles of 384 x 128 on 256 CUs, stage 5 (11,424 x 512) = 30 x 8 tiles of
+//     384 x 64.  No hand-over, no flags, no residency assumption.
+//   * L2 -> LDS traffic per MAC binds these layers next to the matrix pipe (~11 TB/s chip-wide).  A halo tile is read
+//     by nine taps, a filter tile by one: per (chunk, tap) step a block copies 128 NJ * 64 B of filters + (BM + 2 Vw + 2) * 128 / 9 B of
+//     pixels, so tiles want to be TALL and narrow: 384 x 128 moves 22.7 KiB per 18.9 M MACs, 256 x 128 moves 21.2 KiB per 12.6 M MACs.
+//   * 3 x 2 MFMA tiles per wave: 5 fragment reads per 6 MFMAs (conv_halo.hip: 4 per 4).
+//   * ADDRESS ARITHMETIC WAS THE BOUND.  conv_halo.hip recomputes the swizzled LDS address of every fragment read (shift, and, xor, shifts:
+//     3.9 VALU instructions per MFMA, PMC).  Two waves share a SIMD's issue port; a v_mfma_f32_32x32x16 holds the matrix pipe for 32 clocks =
+//     8 issue slots for BOTH waves, so ~3.5 other instructions per MFMA and wave are free and everything beyond that idles the pipe:
+//     measured MFMA-only loop 26.9 us, LDS-reads-only 9.7 us, both 45 us -- the sum, not the maximum.  Here the swizzle depends on
+//     (row >> 1) & 7 only, so 32 rows further is +4096 bytes: ONE address register per tap (9) + one for the filter operand live for the
+//     whole kernel, MFMA sub-tile / ring slot / halo buffer are immediates of the ds_read, the k sub-step is one v_xor per operand:
+//     0.6 VALU per MFMA, and the loop runs at 84 % of the matrix pipe in CYCLES (what remains is the clock: 1.84 GHz under this load).
+//   * the halo rows' pixel offsets live in an LDS table filled once per tile (one row per thread), not in eight registers per lane that
+//     hipcc spilled and reloaded behind vmcnt(0).
+//   * fixed LDS map (halo buffers at 0 and 60 KiB, two-slot filter ring behind them): the halo double buffer of a 384-pixel tile takes
+//     120 KiB, so a ring slot is refilled behind the barrier that follows its last fragment read (every wave waits lgkmcnt(0) before it
+//     arrives there), one step before it is needed.
 // Results are bit-identical to conv_halo.hip's whole-tile schedule (same MFMA, same k order per output element).
+// Measured (bf16, B = 32, isolated / in the step): stage 4 47.7 / 46-50 us (1.01 PFLOP/s), stage 5 49.0 / 57-59 us (its 4.7 MB filter
+// is cold in the step and a two-slot ring hides one step of latency).
 #include "common.h"
 #include <type_traits>
 
@@ -38,13 +49,6 @@ struct Hx2Args {
     int dbg;                   // experiments (urso_set_option("hconv_dbg")): bit 0 no epilogue, bit 1 no step loop, bit 5 no copies in the loop, bit 6 no barrier in the loop (timing only)
 };
 
-// the same instruction with the accumulator pinned to the AccVGPR half of the register file ("a" constraint)
-__device__ __forceinline__ void hx2_mma_acc(const i32x4_t& a, const i32x4_t& b, f32x16_t& c, __bf16) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void hx2_mma_acc(const i32x4_t& a, const i32x4_t& b, f32x16_t& c, _Float16) {
-    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
 template <typename T> struct Hx2Mma;
 template <> struct Hx2Mma<__bf16> {
     static __device__ __forceinline__ void run(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
@@ -94,10 +98,9 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
     __shared__ __attribute__((aligned(1024))) char smem[HX_LDS];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    // An operand in the AccVGPR half of the register file makes hipcc select the AGPR form of every MFMA in this kernel (accumulators in
-    // a[0..], 128 arch VGPRs left for fragments and addresses).  With the accumulators in arch VGPRs the matrix pipe's accumulator traffic
-    // and the LDS return path meet on the same register-file ports: measured 58.5 -> 54.6 us on the cfg2 stage-4 layer.
-    { int agpr_form; asm volatile("; accumulators in AccVGPRs %0" : "=a"(agpr_form)); (void)agpr_form; }
+    // (Accumulators in AccVGPRs -- an "a"-constrained asm operand flips hipcc to the AGPR form of every MFMA of a kernel -- gave 58.5 ->
+    // 54.6 us while the loop still issued 3.9 VALU per MFMA and nothing once they were gone (47.9 against 48.5 us in the step); it costs
+    // half of the arch VGPRs at two waves per SIMD, so the accumulators stay in arch VGPRs.)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
         };
         // A region = the MI + NJ fragment reads of the next k sub-step, then the MI NJ MFMAs of this one (operands read a region ago).  Spreading
         // the reads between the MFMAs (sched_group_barrier: one read behind each MFMA) was measured and lost: 51.6 against 48.6 us on the cfg2
-        // stage-4 layer -- with the accumulators in AccVGPRs and two v_xor per region the loop runs at 84 % of the matrix pipe in CYCLES; what is
+        // stage-4 layer -- with two v_xor per region the loop runs at 84 % of the matrix pipe in CYCLES; what is
         // left is the clock (1.84 GHz under this load, s_memtime against s_memrealtime: tools/probes/hx2_clk.py).
         auto region_end = [&]() { __builtin_amdgcn_sched_barrier(0); };
         // one 64-channel chunk = nine (chunk, tap) steps; PAR = parity of the chunk = the halo buffer it reads: the ring slot of step
@@ -381,14 +384,15 @@ static bool hx2_shape_fits(const urso_conv_geom* g, int mi, int nj) {
 }
 
 // Estimated time of a layer on shape (mi, nj) in microseconds, fitted to tools/hconv2_sweep.py (profiles/r04_hconv2_sweep.txt: ten layers of
-// cfg2 / cfg4 / cfg5 and batch 8, every shape that fits): rounds of whole tiles x (chunk, tap) steps of 0.037 us per MFMA of a wave + 0.13 us
-// (barrier, copy issue), faster when part of the chip idles (shared L2, power), ~9 us for launch, first copies and the last epilogue, ~3 us
+// cfg2 / cfg4 / cfg5 and batch 8, every shape that fits): rounds of whole tiles x (chunk, tap) steps of 0.037 us per MFMA of a wave + 0.07 us
+// (barrier, copy issue) + 0.003 us per KiB copied, faster when part of the chip idles (shared L2, power), ~9 us for launch, first copies and the last epilogue, ~3 us
 // for every further tile's epilogue.
 static double hx2_cost(const urso_conv_geom* g, int mi, int nj, int ncu) {
     const int Mv = g->B * (g->H + 1) * (g->W + 1);
     const int tiles = ceil_div(Mv, 128 * mi) * (g->N / (64 * nj));
     const int blocks = tiles < ncu ? tiles : ncu, rounds = ceil_div(tiles, blocks);
-    const double step = (0.037 * 4.0 * mi * nj + 0.13) * (0.7 + 0.3 * (double)blocks / ncu);
+    const double kib = (128.0 * nj * 64.0 + (128.0 * mi + 2.0 * (g->W + 2)) * 128.0 / 9.0) / 1024.0;      // L2 -> LDS bytes of a step: tall tiles move less per MAC
+    const double step = (0.037 * 4.0 * mi * nj + 0.07 + 0.003 * kib) * (0.7 + 0.3 * (double)blocks / ncu);
     return 9.0 + rounds * (g->C / 64) * 9.0 * step + (rounds - 1) * 3.0;
 }
 // conv_halo.hip's own schedule on the same scale: 256 x 128 tiles, 0.75 us per step, (tile, chunk) units dealt to all CUs when it has a
