@@ -45,7 +45,7 @@ enum { URSO_F32 = 0, URSO_BF16 = 1, URSO_F16 = 2 };
                                    ever sampled at stride s (net.py:121-126 reads res{2c,3d,4f}_out through stride-2 1x1 layers) */
 
 const char* urso_last_error(void);
-int         urso_abi_version(void);           /* bumped on any signature or data-format change (6: arg-max bytes of the max-pool carry the ReLU decision in bit 4) */
+int         urso_abi_version(void);           /* bumped on any signature or data-format change (6: arg-max bytes of the max-pool carry the ReLU decision in bit 4; 8: urso_prof_record_ex.l2_bytes) */
 
 /*
  * Kernel-policy options (process-wide, explicit; defaults in parentheses).  They select between kernels / tile shapes
@@ -198,6 +198,8 @@ int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_
 /* The inverse: out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere -- the dense form of a compact gradient for a
  * consumer that cannot take the compact operand (stages whose residual hand-over is not a urso_conv_pair launch). */
 int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
+/* Zero fill (16-byte aligned pointer and size): the buffer a scattered data gradient (urso_conv_igemm_ex with FH / FW) lands in. */
+int urso_zero_fill(void* dst_d, size_t bytes, void* stream);
 
 /* urso_conv_igemm_ex for a c -> 4c pointwise layer that closes a stage ('res{2c,3d,4f}_branch2c' + BatchNorm + Add + ReLU, net.py:148-157)
  * with a SECOND output: the pixels at even rows / columns of dst_d, gathered into dst_sampled_d [B][OH/2][OW/2][N] -- what the next
@@ -217,6 +219,9 @@ int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, cons
  * fixed order (deterministic, reproducible from launch to launch).  CONTRACT: the first 4 KiB of that workspace are hand-over flags
  * -- zero on entry, left zero on return; a workspace shared with other entry points must be re-zeroed before the call.  Without a
  * workspace every block walks whole tiles. */
+/* Algorithmic FLOPs and bytes of a urso_conv_igemm_ex launch: the figures the launch profiler records and bench.py prices against the roofline
+ * (each tensor once; a scattered destination and its residual / mask operands at the computed pixels only; host arithmetic, no GPU needed). */
+int urso_conv_igemm_algorithmic(const urso_conv_geom* g, int dt, int flags, int has_add, int has_mask, double* flops_out, double* bytes_out);
 int urso_conv_igemm_halo_ok(const urso_conv_geom* g, int dt, int flags, int has_add);
 size_t urso_conv_igemm_halo_ws_bytes(void);
 /* The same layers run in conv_halo2.hip where that wins: WHOLE tiles of 128 MI virtual pixels x 64 NJ filters, (MI, NJ) picked per layer so
@@ -328,6 +333,8 @@ typedef struct urso_param_desc {
     float *dw_raw, *colsum, *dotpart;                    /* REDUCE outputs; FINALIZE_MAT scratch [ks][N] */
     float *gw, *gb, *ggamma, *gbeta;                     /* gradient slices (gb / ggamma+gbeta may be NULL) */
 } urso_param_desc;
+/* A layer with 2 .. 16 split partials (the grouped weight-gradient launches) has no REDUCE blocks: FINALIZE_MAT / FINALIZE_VEC sum its partials
+ * themselves, in REDUCE's order (bit-identical), so the fp32 sum is neither written nor read back (dw_raw / colsum stay unused for it). */
 enum { URSO_PB_PREP = 0, URSO_PB_REDUCE = 1, URSO_PB_FINALIZE_MAT = 2, URSO_PB_FINALIZE_VEC = 3 };
 int urso_conv_wgrad_splits(const urso_conv_geom* g, int dt);
 int urso_conv_wgrad_partial(const urso_conv_geom* g, int dt, const void* x_d, const void* dz_d,
@@ -545,7 +552,9 @@ typedef struct urso_prof_record_ex {
     double  flops;
     double  bytes;
     int32_t n_launches;
-    char    symbol[236];
+    char    symbol[228];
+    double  l2_bytes;          /* bytes the launch copies out of L2 into LDS / registers, operand re-reads per tile included (0 where the kernel
+                                  does not report it): the roof between HBM and the matrix pipe, ~11 TB/s chip-wide as measured */
 } urso_prof_record_ex;
 int urso_prof_collect_ex(urso_prof_record_ex* out, int max_records);
 

@@ -263,3 +263,46 @@ def test_dp_schedule_launches_every_bucket_after_its_last_producer_and_before_th
                                       ("d", 910, 1500), ("bn_d", 1500, 1520), ("e", 1520, 1800), ("bn_e", 1800, 1830), ("f", 1830, 2000), ("bn_f", 2000, 2010)]}
         for nm, s in s_of.items():
             assert abs(g[s] - 1.5 * (1.0 + s)) < 1e-4 * (1.0 + s), (nm, g[s])
+
+
+def _replan_worker(port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from ursonet_amd.dp import DataParallelEngine, plan_buckets
+    sizes = [("a", 0, 100), ("b", 100, 400), ("c", 400, 1000)]
+
+    class Eng(object):
+        pass
+    eng = Eng()
+    eng.device = torch.device("cpu")
+    eng.flat_w, eng.flat_stats, eng.flat_g = torch.zeros(1000), torch.zeros(8), torch.zeros(1000)
+    eng.rel_exact, eng.loss_pre_ops, eng.plan_version = False, [], 1
+    eng.grad_bucket_bytes, eng.grad_tail_bytes = 600 * 4, 0
+    eng.buckets = plan_buckets(sizes, bucket_bytes=600 * 4)
+    eng.convs = {k: _FakeConv(None) for k in "abc"}
+    eng.prep_ops, eng.fwd_ops, eng.loss_ops, eng.opt_ops = [], [], [], []
+    eng.bwd_ops = [("c", lambda: None), ("b", lambda: None), ("a", lambda: None)]
+    eng._graphs = None
+    eng._build_plan = lambda: None
+    live = [[(0, 1000)]]
+    eng.trainable_ranges = lambda: live[0]
+    dp = DataParallelEngine(eng, bucket_bytes=600 * 4, tail_bytes=0, compress="bf16")
+    dp.reducer.resid.fill_(0.25)                         # rounding remainders of a previous step, every parameter
+    live[0] = [(100, 400)]                               # set_trainable: only layer b still trains
+    eng.plan_version += 1
+    dp._derive_cuts()
+    out.put(dp.reducer.resid.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_error_feedback_remainder_of_frozen_layers_is_dropped_on_replan():
+    """bf16 gradient buckets keep what the rounding dropped for the next step (error feedback).  After a re-plan (set_trainable) the
+    remainder of layers that no longer train must not survive: their gradient slice stays zero, so the old remainder would be added to
+    it, all-reduced and applied to the frozen weights by the optimizer (which runs over the whole flat buffer)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_replan_worker, args=(_free_port(), out))
+    p.start()
+    r = out.get(timeout=120)
+    p.join(60)
+    assert np.all(r[100:400] == 0.25) and np.all(r[:100] == 0.0) and np.all(r[400:] == 0.0)

@@ -360,7 +360,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "symbol %s declared in include/ursonet_hip.h is not exported" % s
     assert set(syms) == set(hip.EXPORTED_SYMBOLS), set(syms) ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip._lib.urso_abi_version() == 7
+    assert hip._lib.urso_abi_version() == 8
 
 
 def test_policy_options_are_explicit_and_never_read_the_environment():
@@ -564,3 +564,36 @@ def test_resize_equals_scipy_ndimage_the_backend_of_skimage_resize():
     ref = ndi.zoom(ndi.gaussian_filter(u8.astype(np.float64), np.maximum(0, (fac - 1) / 2), cval=0, mode="grid-constant"), [1 / x for x in fac], order=1,
                    mode="grid-constant", cval=0, grid_mode=True).astype(np.uint8)
     assert np.array_equal(out[window[0]:window[2], window[1]:window[3]], ref)
+
+
+def test_algorithmic_bytes_charge_compact_and_sampled_tensors_at_their_real_size():
+    """The figures bench.py's roofline prices a launch with (urso_conv_igemm_algorithmic; host arithmetic).  A scattered destination -- the
+    compact stage-boundary data gradient of res{2c,3d,4f}_branch2c -- is written, and its mask read, at the B x OH x OW computed pixels only
+    (that launch was charged the dense 4x tensor and showed 1.26 of the HBM roof); a strided pointwise layer reads only the
+    sampled pixels of its input.  No launch class of the cfg2 step may exceed its roof at ANY duration its bytes allow: the charged bytes
+    never exceed input + filter + output + operands of the tensors as they are stored."""
+    import ursonet_amd.hip as hip
+    B, es = 32, 2
+    # dgrad of res2c_branch2c on the compact gradient: dz [B, 64, 80, 256] -> dX at the even pixels of [B, 128, 160, 64], masked
+    g = hip.geom(B, 64, 80, 256, 64, 80, 64, 1, 1, 1, 1, 0, 0, 1, 1, FH=128, FW=160, OSH=2, OSW=2)
+    fl, by = hip.conv_igemm_algorithmic(g, hip.BF16, 0, has_add=False, has_mask=True)
+    M = B * 64 * 80
+    assert fl == 2.0 * M * 256 * 64
+    assert by == M * 256 * es + 256 * 64 * es + 2 * M * 64 * es                   # dz + filter + (written dX + mask at the written pixels): 126 MB, not 252
+    dense = hip.geom(B, 128, 160, 256, 128, 160, 64, 1, 1)
+    assert hip.conv_igemm_algorithmic(dense, hip.BF16, 0, False, True)[1] == 4 * M * 256 * es + 256 * 64 * es + 2 * 4 * M * 64 * es
+    # stride-2 pointwise entry layer: reads a quarter of its input
+    s2 = hip.geom(B, 128, 160, 256, 64, 80, 128, 1, 1, 2, 2)
+    assert hip.conv_igemm_algorithmic(s2, hip.BF16, 0)[1] == M * 256 * es + 128 * 256 * es + M * 128 * es
+    # bit masks: one byte per 8 outputs, read (MASK_BITS) or written (EMIT_BITS)
+    pw = hip.geom(B, 64, 80, 128, 64, 80, 512, 1, 1)
+    base = hip.conv_igemm_algorithmic(pw, hip.BF16, 0)[1]
+    assert hip.conv_igemm_algorithmic(pw, hip.BF16, hip.EPI_EMIT_BITS, has_add=True)[1] == base + M * 512 * es + M * 512 / 8
+    assert hip.conv_igemm_algorithmic(pw, hip.BF16, hip.EPI_MASK_BITS, has_mask=True)[1] == base + M * 512 / 8
+    # every conv geometry of the cfg2 plan: charged bytes <= the stored tensors it touches (so measured time >= bytes / 8 TB/s keeps frac <= 1)
+    for (h, w, c, n, k, s) in [(256, 320, 8, 64, 7, 2), (128, 160, 64, 64, 3, 1), (128, 160, 64, 256, 1, 1), (64, 80, 128, 128, 3, 1), (64, 80, 512, 128, 1, 1),
+                               (32, 40, 256, 256, 3, 1), (32, 40, 1024, 256, 1, 1), (16, 20, 512, 512, 3, 1), (16, 20, 512, 2048, 1, 1), (16, 20, 2048, 32, 3, 2)]:
+        oh, ow = -(-h // s), -(-w // s)
+        gg = hip.geom(B, h, w, c, oh, ow, n, k, (4 if k == 7 else k), s, s, k // 2, k // 2)
+        stored = B * h * w * c * es + n * k * (4 if k == 7 else k) * c * es + 3 * B * oh * ow * n * es
+        assert hip.conv_igemm_algorithmic(gg, hip.BF16, 0, True, True)[1] <= stored

@@ -1577,3 +1577,15 @@ def test_two_3x3_weight_gradients_in_one_launch(dt, shapes):
         assert float(dw.abs().max()) > 0 and relerr(part, dw.double()) < 5e-5, (i, relerr(part, dw.double()))
         assert relerr(col, cs.double()) < 5e-5
     assert hip.conv_wgrad_pair_splits(gs[0], hip.geom(4, 32, 40, 64, 32, 40, 64, 3, 3, 1, 1, 1, 1), dt) is None      # conv_c3g.hip's layer
+
+
+def test_zero_fill():
+    """urso_zero_fill: the library's own fill for the buffer a scattered data gradient lands in (no torch launch inside the captured step)."""
+    hip = _hip()
+    t = torch.full((3, 37, 16), 5.0, dtype=torch.bfloat16, device="cuda")
+    guard = t[2:]                               # the call covers the first two slabs only
+    hip.zero_fill(t[:2])
+    torch.cuda.synchronize()
+    assert float(t[:2].float().abs().max()) == 0.0 and float(guard.float().min()) == 5.0
+    with pytest.raises(Exception):
+        hip.zero_fill(torch.zeros(3, dtype=torch.bfloat16, device="cuda"))       # 6 bytes: not a multiple of 16

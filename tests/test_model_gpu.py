@@ -24,6 +24,11 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def _rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
 def _cos(a, b):
     a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
@@ -39,6 +44,7 @@ class ReluDecisions(object):
     def __init__(self, eng, tol):
         self.eng, self.tol = eng, tol
         self.flips, self.total = 0, 0
+        self.worst, self.mags = 0.0, []          # largest |pre-activation| / max at a flipped decision; all of them (for the histogram kept in profiles/)
 
     def __call__(self, site, x):
         c = self.eng.convs[site]
@@ -53,7 +59,8 @@ class ReluDecisions(object):
             diff = m != (x.detach() > 0)
             nd = int(diff.sum())
             if nd:
-                worst = float(x.detach().abs()[diff].max() / (x.detach().abs().max() + 1e-30))
+                rel = (x.detach().abs()[diff] / (x.detach().abs().max() + 1e-30)).double()
+                worst = float(rel.max()); self.worst = max(self.worst, worst); self.mags.append(rel.cpu())
                 assert worst < self.tol, "ReLU decision differs at |pre-activation| = %.2e of max in %s" % (worst, site)
             self.flips += nd
             self.total += diff.numel() // 4
@@ -69,11 +76,20 @@ class ReluDecisions(object):
         diff = m != (x.detach() > 0)
         nd = int(diff.sum())
         if nd:
-            worst = float(x.detach().abs()[diff].max() / (x.detach().abs().max() + 1e-30))
+            rel = (x.detach().abs()[diff] / (x.detach().abs().max() + 1e-30)).double()
+            worst = float(rel.max()); self.worst = max(self.worst, worst); self.mags.append(rel.cpu())
             assert worst < self.tol, "ReLU decision differs at |pre-activation| = %.2e of max in %s" % (worst, site)
         self.flips += nd
         self.total += diff.numel()
         return m
+
+    def histogram(self):
+        """Counts of flipped decisions by |pre-activation| / tensor max: [< 1e-3, < 3e-3, < 1e-2, < 3e-2, < 1e-1, >= 1e-1]."""
+        if not self.mags:
+            return [0] * 6
+        v = torch.cat(self.mags)
+        edges = [0.0, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, float("inf")]
+        return [int(((v >= lo) & (v < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
 
 
 def _oracle_step(cfg, weights, img, loc, ori, lr, relu_hook=None, q=None, layer_regex=".*"):
@@ -153,13 +169,15 @@ def test_training_step_parity_fp32_multitile_stream():
         test_training_step_parity_fp32(*CASES[1])
 
 
-def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w):
-    """Outputs, losses, every gradient tensor (relative to its max), global norm, post-step weights; one assertion that reports
-    all the measured errors."""
+def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w, tol_l2=None, tol_norm=None):
+    """Outputs, losses, every gradient tensor (relative to its max; the big ones also in the Euclidean norm), global norm, post-step
+    weights; one assertion that reports all the measured errors."""
+    tol_l2 = tol_g if tol_l2 is None else tol_l2
+    tol_norm = tol_g if tol_norm is None else tol_norm
     gl, go = eng.outputs()
     ls = eng.losses()
     grads = eng.get_grads()
-    worst, worst_big = ("", 0.0), ("", 0.0)
+    worst, worst_big, worst_l2 = ("", 0.0), ("", 0.0), ("", 0.0)
     for ln, ws in ref["grads"].items():
         for wn, gref in ws.items():
             e = _rel(grads[ln][wn], gref.numpy())
@@ -167,17 +185,21 @@ def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w):
                 worst = (ln + "/" + wn, e)
             if gref.numel() >= 4096 and e > worst_big[1]:
                 worst_big = (ln + "/" + wn, e)
+            if gref.numel() >= 4096:          # the same tensors in the Euclidean norm: what a mis-scaled or mis-indexed layer moves, whatever single elements do
+                e2 = _rel_l2(grads[ln][wn], gref.numpy())
+                if e2 > worst_l2[1]:
+                    worst_l2 = (ln + "/" + wn, e2)
     w1 = eng.get_weights()
     worst_w = max((_rel(w1[ln][wn], wref), ln + "/" + wn) for ln, ws in newW.items() for wn, wref in ws.items())
     m = {"loc": _rel(gl.cpu().numpy(), ref["loc"].numpy()), "ori": _rel(go.cpu().numpy(), ref["ori"].numpy()),
          "loc_loss": abs(ls["loc_loss"] - ref["loc_loss"]) / (abs(ref["loc_loss"]) + 1e-6),
          "ori_loss": abs(ls["ori_loss"] - ref["ori_loss"]) / (abs(ref["ori_loss"]) + 1e-6),
-         "grad": worst[1], "grad_big": worst_big[1], "grad_norm": abs(float(eng.normsq.cpu()) ** 0.5 - ref["grad_norm"]) / ref["grad_norm"], "weights": worst_w[0]}
+         "grad": worst[1], "grad_big": worst_big[1], "grad_l2": worst_l2[1], "grad_norm": abs(float(eng.normsq.cpu()) ** 0.5 - ref["grad_norm"]) / ref["grad_norm"], "weights": worst_w[0]}
     print("parity:", {k: "%.2e" % v for k, v in m.items()}, "worst grad", worst[0], "worst big grad", worst_big[0], "worst weight", worst_w[1])
     # tol_g applies to every tensor with >= 4096 elements (filters, dense kernels); the small per-channel tensors (BN gamma/beta, biases:
     # sums with cancellation over 64-2048 channels) get 3 tol_g
     ok = (m["loc"] < tol_out and m["ori"] < tol_out and m["loc_loss"] < tol_out and m["ori_loss"] < tol_out and
-          m["grad_big"] < tol_g and m["grad"] < 3 * tol_g and m["grad_norm"] < tol_g and m["weights"] < tol_w)
+          m["grad_big"] < tol_g and m["grad"] < 3 * tol_g and m["grad_l2"] < tol_l2 and m["grad_norm"] < tol_norm and m["weights"] < tol_w)
     assert ok, "tolerances out %.0e grad %.0e weights %.0e exceeded: %s (worst gradient %s, worst weight %s)" % (
         tol_out, tol_g, tol_w, {k: "%.2e" % v for k, v in m.items()}, worst[0], worst_w[1])
     return worst
@@ -185,23 +207,24 @@ def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w):
 
 @pytest.mark.parametrize("pair", [1, 0], ids=["fused", "apart"])
 @pytest.mark.parametrize("cap", [0, 8], ids=["grid", "capped"])
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 4e-3, 7e-3)])
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2.5e-2, 1.2e-1), ("float16", 4e-3, 1.6e-2)])
 def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, cap, pair):
     """The benchmarked dtype against an oracle that rounds where the device rounds (oracle.graph_ref.StorageRounding: folded
     filters, every stored activation, every activation gradient): outputs, losses, EVERY parameter gradient (relative to the
-    tensor's max), the global norm and the post-step weights -- not a cosine.  'capped' additionally forces the multi-tile
-    stream of the DMA conv kernels (conv_pw.hip) and of the fused pair kernel inside this oracle-compared step; 'fused' / 'apart' run
-    the plan with and without the fused stage-2/3 pointwise pairs (conv_pair.hip).  A mis-scaled or mis-indexed layer
-    cannot pass at these tolerances (a wrong scale of 2 in one tensor is a 50 % error).  Measured on MI355X (r50, 2 x 128 x 192):
-    bf16 outputs 8e-3, losses 3e-3, worst gradient tensor 2.0e-2 (a 64-element BN gamma; filters ~1e-2), global norm 5e-3,
-    post-step weights 3e-5; fp16 outputs 1.2e-3, worst gradient 3.2e-3, norm 7e-4, weights 6e-6.  What remains is the order of the
-    fp32 accumulations (a value within ~1e-6 of a 16-bit rounding boundary rounds differently, ~3e-4 of all elements) and the
-    device's second rounding where two gradient contributions meet in a 16-bit buffer.  That residue is chaotic in bf16: the plan
-    with the fused stage-2 pairs (conv_pair.hip: bit-identical backward, forward equal up to one rounding flip in ~1e-5 of the
-    elements) measures outputs 1.1e-2 / worst filter gradient 2.8e-2 / norm 9e-3 against 7.7e-3 / 1.5e-2 / 5e-3 with the layers
-    launched apart, while fp16 -- 8x finer, so any systematic error would show at the same absolute size -- is unchanged at 3.3e-3;
-    with the single wide layers also on the register-filter kernel fp16 measures outputs 2.1e-3 / worst gradient 3.4e-3.  Every gate is
-    set to about twice the largest value measured over the kernel plans (fused / apart, grid / capped)."""
+    tensor's max, the filters and dense kernels also in the Euclidean norm), the global norm and the post-step weights -- not a cosine.
+    'capped' additionally forces the multi-tile stream of the DMA conv kernels (conv_pw.hip) and of the fused pair kernel inside this
+    oracle-compared step; 'fused' / 'apart' run the plan with and without the fused stage-2/3 pointwise pairs (conv_pair.hip).
+
+    WHERE THE GATES COME FROM (round 4: tools/probes/parity_hist.py, profiles/r04_parity.txt).  What remains between device and oracle is
+    the order of the fp32 accumulations (a value within ~1e-6 of a 16-bit rounding boundary rounds the other way, ~3e-4 of all elements) and
+    the device's second rounding where two gradient contributions meet in a 16-bit buffer.  Through 50 layers at 2 x 128 x 192 that residue
+    is CHAOTIC: the worst of the ~110 filter / dense-kernel gradient tensors, over six data seeds x four kernel plans (fused / apart pairs,
+    conv_halo2.hip on / off), measured in bf16 between 1.6e-2 and 7.8e-2 of the tensor's max (4.8e-2 ... 7.2e-2 on at least one seed of
+    EVERY plan, the round-3 kernels included: the round-3 gate of 4e-2 passed on the one seed it was run on), 1.2e-2 ... 6.7e-2 in the
+    Euclidean norm; outputs <= 1.64e-2, global norm <= 1.44e-2.  The same 24 runs in fp16 -- 8x finer, the same kernels: a mis-scaled or
+    mis-indexed layer shows at the same absolute size in both -- measure 1.9e-3 ... 1.1e-2 (max), <= 8.3e-3 (Euclidean), outputs
+    <= 1.95e-3, norm <= 1.76e-3: the residue scales with the rounding unit, i.e. it IS rounding.  Gates = ~1.5x the largest value of the
+    histogram; fp16's are the ones a systematic error has to get past (a wrong scale of 2 % in one filter tensor fails them)."""
     import ursonet_amd.hip as hip
     from oracle import graph_ref as G
     kw = dict(backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
@@ -214,7 +237,7 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     dec = ReluDecisions(eng, tol=4 * tol_out)
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
-    _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3)
+    _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3, tol_l2=0.85 * tol_g, tol_norm=tol_out)
 
 
 @pytest.mark.parametrize("pwx", [1, 2], ids=["policy", "pwx_everywhere"])
@@ -576,6 +599,7 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                             device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
+        hip.set_option("hconv_streamk", 0)      # what the DP wrapper sets while collectives run beside the step (below): the plain engines it is compared with sum in the same order
         for exact in (False, True):
             cfg = make_config(backbone="resnet50", h=64, w=128, batch=4, regress_ori=False, ori_bins=4, dtype="bfloat16")
             cfg.DP_EXACT_REL_LOSS = exact
@@ -612,8 +636,21 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
         assert torch.equal(eng.flat_w, plain.flat_w) and eng.losses() == plain.losses()
         ex = dp.exposed_comm_ms(2)             # events around the join with the collectives' stream; one rank moves no bytes
         assert 0.0 <= ex < 5.0, ex
+        # no accumulator hand-over between blocks (conv_halo.hip's stream-K needs every block resident) while collectives run beside the step:
+        # the wrapper switches it off for the process and close() gives both options back and re-plans the engine for the whole chip
+        hip.set_option("hconv_streamk", 1)
+        eng2 = Engine(cfg, "training", seed=8, randomize_bn=True, grad_bucket_bytes=8 << 20)
+        with DataParallelEngine(eng2, bucket_bytes=8 << 20, comm_cus=total - 64) as dp2:
+            assert hip.get_option("hconv_streamk") == 0 and hip.get_option("cus") == 64
+            eng2.load_batch(img, loc, ori); dp2.step(); torch.cuda.synchronize()
+            v_dp = eng2.plan_version
+        assert hip.get_option("hconv_streamk") == 1 and hip.get_option("cus") == 0
+        assert eng2.plan_version > v_dp and eng2._graphs is None
+        eng2.load_batch(img, loc, ori); eng2.step_eager(); torch.cuda.synchronize()      # planned for the whole chip again: split counts agree with the launches
+        assert bool(torch.isfinite(eng2.flat_g).all())
     finally:
         hip.set_option("cus", 0)
+        hip.set_option("hconv_streamk", 1)
         dist.destroy_process_group()
 
 
@@ -711,6 +748,23 @@ def test_step_planned_for_fewer_cus():
     assert bool(torch.isfinite(g1).all()) and float(g0.norm()) > 0
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     assert cos >= 0.98 and 0.9 <= float(g1.norm() / g0.norm()) <= 1.1, cos
+
+
+def test_engine_refuses_to_step_under_other_planning_options():
+    """Split counts, partial workspaces and the grouped / paired weight-gradient launches are sized at plan time from kernel-policy options
+    (cus, wgrad_blocks, ...), and the library re-derives some split counts at launch time: a step under other values would sum a different
+    number of partials than it wrote.  The engine says so instead."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    cfg = make_config("resnet50", 64, 128, batch=2, regress_ori=False, ori_bins=4, dtype="bfloat16")
+    img, loc, ori, _ = synthetic_batch(cfg, 2, seed=2)
+    eng = Engine(cfg, "training", seed=7, randomize_bn=True)
+    eng.load_batch(img, loc, ori)
+    eng.step_eager()
+    with hip.options(wgrad_blocks=256):
+        with pytest.raises(RuntimeError, match="wgrad_blocks 512 -> 256"):
+            eng.step_eager()
+    eng.step_eager(); torch.cuda.synchronize()
 
 
 def test_urso_comm_bucket_averaging_one_rank():

@@ -3,7 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r01'
 # rocprofv3 --pmc runs are separate passes (no trace domains besides --kernel-trace), bounded by `timeout`.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp

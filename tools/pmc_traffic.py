@@ -3,8 +3,10 @@
 SYMBOL.  gfx950: FETCH_SIZE reports half the bytes of wide streaming reads -> doubled (MI355X_MICROARCH.md, HBM).  bench.py looks the
 dominant kernels up in `by_symbol` (the symbol is what hipKernelNameRefByPtr / rocprofv3 -M print).
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> backbone batch h w dtype"""
-import collections, csv, json, sys
-IGEMM = ("igemm_kernel", "pw_kernel", "pwx_kernel", "hconv_kernel", "pair_kernel", "pairw_kernel", "pairx_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "stem_kernel")
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ursonet_amd.build import source_hash
+IGEMM = ("igemm_kernel", "pw_kernel", "pwx_kernel", "hconv_kernel", "hconv2_kernel", "pair_kernel", "pairw_kernel", "pairx_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "stem_kernel")
 
 
 def load(path, counter):
@@ -27,6 +29,9 @@ for k in f:
 ig = [k for k in by if any(s in k for s in IGEMM)]
 nig = sum(by[k]["launches_profiled"] for k in ig)
 out = {"workload": [sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]],
+       # SHA-256 of the kernel sources + flags + compiler the counters were collected on (ursonet_amd/build.py): bench.py reports these figures only
+       # for the library they were measured with
+       "source_hash": source_hash(),
        "note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes, kernels keyed by mangled device symbol",
        "igemm_launches_profiled": nig,
        "igemm_hbm_bytes_per_launch": sum(by[k]["hbm_bytes_per_launch"] * by[k]["launches_profiled"] for k in ig) / max(nig, 1),

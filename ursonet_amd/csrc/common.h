@@ -47,6 +47,12 @@ extern UrsoOptions g_urso_opt;
 int urso_device_cus();      // CUs of the current device (runtime.hip)
 int urso_usable_cus();      // the same, or option `cus` when that is smaller: what every grid / split / workspace plan is sized for
 
+// Layers whose weight gradient was cut into at most this many split partials (the grouped launches: 2-8) skip the reduction pass: the batched
+// finalisation sums the partials itself, in the reduction's order (one split-lane up to 48 splits: bit-identical), and the fp32 sum is
+// neither written nor read back
+#define URSO_FUSE_REDUCE_MAX 16
+static __host__ __device__ inline bool urso_fuse_reduce(int splits) { return splits > 1 && splits <= URSO_FUSE_REDUCE_MAX; }
+
 #define URSO_REDUCE_COLS 256   // threads per block of the split-reduction kernels (conv_wgrad.hip): (256 / lanes) float4 columns x lanes; prep.hip plans with it
 // split-lanes of the reduction for a layer with `splits` partials (each lane adds <= ~48 splits in a row)
 static __host__ __device__ inline int urso_reduce_lanes(int splits) { return splits > 384 ? 16 : (splits > 192 ? 8 : (splits > 96 ? 4 : (splits > 48 ? 2 : 1))); }
@@ -55,6 +61,7 @@ static __host__ __device__ inline int urso_reduce_lanes(int splits) { return spl
 void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes);
 void urso_prof_after(hipStream_t s);
 
+void urso_prof_l2(double l2_bytes);                 // runtime.hip: bytes the open record's launch copies out of L2 (into LDS / registers), re-reads included
 void urso_prof_symbol(const void* host_fn);        // runtime.hip: remembers which kernel the open profiler record launched
 // every kernel launch of the library goes through this macro so that the launch profiler can name the kernel by its device symbol
 #define URSO_KLAUNCH(kern, grid, blk, shm, st, ...) do { urso_prof_symbol((const void*)(kern)); hipLaunchKernelGGL(kern, grid, blk, shm, st, ##__VA_ARGS__); } while (0)

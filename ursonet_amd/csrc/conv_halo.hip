@@ -483,6 +483,7 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
     a.flags = streamk ? (unsigned int*)ws : nullptr;
     a.part = streamk ? (float*)((char*)ws + 4096) : nullptr;
     a.units = streamk ? a.ntiles * a.nchunks : a.ntiles;
+    urso_prof_l2((double)a.ntiles * a.nchunks * (9.0 * HC_BSLOT + (double)a.R * 128));
     if (a.dbg & 16) {
         if (dt == URSO_BF16) URSO_KLAUNCH((hconv_kernel<__bf16, 4>), grid, blk, 0, st, a);
         else URSO_KLAUNCH((hconv_kernel<_Float16, 4>), grid, blk, 0, st, a);

@@ -447,6 +447,7 @@ int urso_hconv2_try_launch(const urso_conv_geom* g, int dt, int relu, const void
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);
+    urso_prof_l2((double)a.ntiles * a.nchunks * (9.0 * 64 * nj * 128 + (double)a.R * 128));      // per tile and 64-channel chunk: nine filter tiles + one halo tile
 #define HX2_GO(MI_, NJ_) do { if (dt == URSO_BF16) URSO_KLAUNCH((hconv2_kernel<__bf16, MI_, NJ_>), grid, blk, 0, st, a); \
                               else URSO_KLAUNCH((hconv2_kernel<_Float16, MI_, NJ_>), grid, blk, 0, st, a); } while (0)
     if (10 * mi + nj == 32 && dt == URSO_BF16 && (a.dbg & 384)) {

@@ -514,6 +514,30 @@ extern "C" int urso_conv_igemm_bits_ok(const urso_conv_geom* g, int dt, int flag
     return 1;
 }
 
+// Algorithmic work of a launch -- what the launch profiler and bench.py's roofline price it with.  Host arithmetic only (no GPU).
+//   FLOPs = 2 * pixels * filters * taps * channels (a dilated data gradient multiplies 1 / (DH DW) of its taps; the packed stem 147 of 224);
+//   bytes = input + filter + output, each ONCE, + residual / mask operands + emitted bit mask, where
+//     * a strided pointwise layer reads only the sampled pixels of its input,
+//     * a scattered destination (FH / FW: the compact stage-boundary gradient) is written -- and its residual / mask operands are read -- at the
+//       B x OH x OW computed pixels only; the zero fill of the rest is another launch's bytes.
+extern "C" int urso_conv_igemm_algorithmic(const urso_conv_geom* g, int dt, int flags, int has_add, int has_mask, double* flops_out, double* bytes_out) {
+    if (!g || (dt != URSO_F32 && dt != URSO_BF16 && dt != URSO_F16)) { urso_set_error("urso_conv_igemm_algorithmic: bad argument"); return URSO_EINVAL; }
+    const double es = (double)dt_size(dt);
+    const double M = (double)g->B * g->OH * g->OW;
+    double flops = 2.0 * M * (double)g->N * g->KH * g->KW * g->C;
+    if (g->DH > 1 || g->DW > 1) flops /= (double)(g->DH * g->DW);     // gather-form dgrad: only 1/(DH*DW) taps are real
+    if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem: 7x7x3 real taps of the 7x4x8 padded ones
+    const double src_bytes = (double)g->B * g->H * g->W * g->C * es, wgt_bytes = (double)g->N * g->KH * g->KW * g->C * es;
+    const double src_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? M * g->C * es : src_bytes;
+    const double wr_elems = M * g->N;
+    const double bytes = src_alg + wgt_bytes + wr_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
+                         (has_add ? wr_elems * es : 0) + (has_mask ? ((flags & URSO_EPI_MASK_BITS) ? wr_elems / 8 : wr_elems * es) : 0) +
+                         ((flags & URSO_EPI_EMIT_BITS) ? wr_elems / 8 : 0);
+    if (flops_out) *flops_out = flops;
+    if (bytes_out) *bytes_out = bytes;
+    return URSO_OK;
+}
+
 extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
                                   const void* src_d, const void* wgt_d, const float* bias_d,
                                   const void* add_d, const void* mask_d, void* dst_d, void* bits_out_d,
@@ -548,18 +572,8 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     a.pointwise = (g->KH == 1 && g->KW == 1 && g->SH == 1 && g->SW == 1 && g->PH == 0 && g->PW == 0 && g->DH == 1 && g->DW == 1 &&
                    g->H == g->OH && g->W == g->OW) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    // algorithmic work: 2*M*N*K flops; bytes = src + weights + dst (+ add/mask reads)
-    double flops = 2.0 * a.M * (double)g->N * g->KH * g->KW * g->C;
-    if (g->DH > 1 || g->DW > 1) flops /= (double)(g->DH * g->DW);     // gather-form dgrad: only 1/(DH*DW) taps are real
-    if (g->C == 8 && g->KH == 7 && g->KW == 4 && g->SH == 2) flops *= 147.0 / 224.0;      // the packed stem: 7x7x3 real taps of the 7x4x8 padded ones
-    // a strided pointwise layer reads only the sampled pixels
-    const double src_alg = (g->KH == 1 && g->KW == 1 && (g->SH > 1 || g->SW > 1)) ? (double)a.M * g->C * es : (double)src_bytes;
-    // a scattered destination (compact stage-boundary gradient) is written -- and its residual / mask operands are read -- at the B x OH x OW
-    // computed pixels only; the zero fill of the rest is another launch's bytes
-    const double wr_elems = (double)g->B * g->OH * g->OW * g->N;
-    double bytes = src_alg + (double)wgt_bytes + wr_elems * ((flags & URSO_EPI_OUT_F32) ? 4 : es) +
-                   (add_d ? wr_elems * es : 0) + (mask_d ? ((flags & URSO_EPI_MASK_BITS) ? wr_elems / 8 : wr_elems * es) : 0) +
-                   ((flags & URSO_EPI_EMIT_BITS) ? wr_elems / 8 : 0);
+    double flops, bytes;
+    urso_conv_igemm_algorithmic(g, dt, flags, add_d ? 1 : 0, mask_d ? 1 : 0, &flops, &bytes);
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     if (urso_dense_fits(g, dt, flags, a.pointwise, a.M))          // Dense heads: <= 32 rows, weights streamed once (conv_dense.hip)
         return urso_dense_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);

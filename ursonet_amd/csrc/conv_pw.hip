@@ -399,6 +399,7 @@ int urso_pw_launch(const urso_conv_geom* g, int dt, int conv, int dhs, int dws, 
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
+    urso_prof_l2((double)a.ntiles * a.Kc * 16.0 * (128 + bn));           // every tile copies 128 pixel rows and bn filter rows per K chunk of 16 bytes
     const int sel = (add ? 1 : 0) | (mask ? 2 : 0);
 #define URSO_PW2(TT, BN_, CV_) switch (sel) { case 0: URSO_KLAUNCH((pw_kernel<TT, BN_, false, 0, CV_>), grid, blk, 0, st, a); break; \
                                         case 1: URSO_KLAUNCH((pw_kernel<TT, BN_, true, 0, CV_>), grid, blk, 0, st, a); break; \

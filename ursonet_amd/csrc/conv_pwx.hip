@@ -333,6 +333,7 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
     if (bpx > cus / 8) bpx = cus / 8;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);
+    urso_prof_l2((double)a.ntiles * K * 2.0 * (160 + bn));     // every tile pulls its 160 pixel rows and its bn filter rows of K channels through L2 -> LDS
 #define URSO_PX(TT, BN_, NST_, AD_, MK_, EM_) URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, AD_, MK_, EM_>), grid, blk, 0, st, a)
 #define URSO_PXF(TT, BN_, NST_) switch (form) { case 0: URSO_PX(TT, BN_, NST_, false, 0, false); break; case 1: URSO_PX(TT, BN_, NST_, true, 0, true); break; \
                                                 case 2: URSO_PX(TT, BN_, NST_, false, 1, false); break; case 3: URSO_PX(TT, BN_, NST_, true, 2, false); break; \

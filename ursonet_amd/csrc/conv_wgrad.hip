@@ -1324,7 +1324,7 @@ extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, cons
                                     const int32_t* blockmap_d, int nblocks, void* stream) {
     if (!items_d || !items_h || !blockmap_d || n <= 0 || nblocks <= 0) { urso_set_error("urso_wgrad_group_run: bad argument"); return URSO_EINVAL; }
     if (dt != URSO_BF16 && dt != URSO_F16) { urso_set_error("urso_wgrad_group_run: 16-bit dtypes only"); return URSO_EINVAL; }
-    double flops = 0, bytes = 0; int cnt = 0;
+    double flops = 0, bytes = 0, l2 = 0; int cnt = 0;
     for (int i = 0; i < n; ++i) {
         const urso_wgrad_item& t = items_h[i];
         const urso_conv_geom& g = t.g;
@@ -1337,10 +1337,14 @@ extern "C" int urso_wgrad_group_run(int dt, const urso_wgrad_item* items_d, cons
         const double x_alg = (g.KH == 1 && g.KW == 1 && (g.SH > 1 || g.SW > 1)) ? (double)t.M * g.C * 2 : (double)g.B * g.H * g.W * g.C * 2;
         bytes += x_alg + 2.0 * t.M * g.N + 4.0 * K * g.N;
         cnt += t.ktiles * t.ntiles * t.splits;
+        // every (k tile, n tile) pair pulls its pixel slices of x and dz through L2 -> LDS: x once per n tile, dz once per k tile
+        const double tw = (t.mode & 4) ? 256.0 : 128.0;
+        l2 += (double)t.ktiles * t.ntiles * t.M * 2.0 * 2.0 * tw;
     }
     if (cnt != nblocks) { urso_set_error("urso_wgrad_group_run: block map has %d blocks, the items need %d", nblocks, cnt); return URSO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
+    urso_prof_l2(l2);
     const bool big = (items_h[0].mode & 4) != 0;
     for (int i = 0; i < n; ++i) if (((items_h[i].mode & 4) != 0) != big) { urso_set_error("urso_wgrad_group_run: items planned for different tile shapes"); return URSO_EINVAL; }
     if (big) {

@@ -524,6 +524,23 @@ extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const vo
 
 // out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere: the dense form of a gradient kept on the even pixel grid, for
 // a consumer that cannot take the compact form.
+// Zero fill with 16-byte stores (the scattered data gradient of a stage-closing layer lands on the even pixels of this buffer: everything
+// else is zero).  A library kernel so that the captured step holds no launch the launch profiler does not see.
+__global__ void zero_fill_kernel(size_t nvec, i32x4_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) out[i] = i32x4_t{0, 0, 0, 0};
+}
+
+extern "C" int urso_zero_fill(void* dst_d, size_t bytes, void* stream) {
+    if (!dst_d || (bytes & 15) || (((uintptr_t)dst_d) & 15)) { urso_set_error("urso_zero_fill: bad argument (16-byte aligned pointer and size)"); return URSO_EINVAL; }
+    if (!bytes) return URSO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nvec = bytes / 16;
+    ProfScope ps(st, URSO_K_POOL, 0, (double)bytes);
+    URSO_KLAUNCH(zero_fill_kernel, dim3(pool_blocks(nvec)), dim3(256), 0, st, nvec, (i32x4_t*)dst_d);
+    return urso_check_launch("urso_zero_fill");
+}
+
 extern "C" int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
     if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
         ((((uintptr_t)in_d) | ((uintptr_t)out_d)) & 15)) { urso_set_error("urso_rows_expand2: bad argument (even H, W; 16-byte rows)"); return URSO_EINVAL; }

@@ -195,9 +195,12 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
 
 // ------------------------------------------------------------------ parameter-gradient finalisation
 // pass 1: grid (ceil(N/64), KS): gW = s*dw_raw + c*W, partial column dots of W*dw_raw
+// nsum > 1: dwr is the first of `nsum` split partials, `pstride` floats apart, summed here in split order -- the order (and so the bits) of
+// reduce_partials_body for up to URSO_FUSE_REDUCE_MAX splits (one split-lane) -- instead of by a reduction pass that writes the sum and this
+// pass reading it back
 __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
                                     const float* __restrict__ gamma, const float* __restrict__ var, float eps,
-                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
+                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart, int nsum = 1, size_t pstride = 0) {
     const int kbeg = by * kb, kend = min(K, kbeg + kb);
     if (((N | ldn) & 3) == 0) {
         // 16 column quads (64 columns) x 16 row lanes, 16-byte loads/stores; the 16 row lanes are combined in lane order
@@ -210,7 +213,21 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
             s.x = bn_scale(gamma, var, eps, n); s.y = bn_scale(gamma, var, eps, n + 1);
             s.z = bn_scale(gamma, var, eps, n + 2); s.w = bn_scale(gamma, var, eps, n + 3);
             for (int k = kbeg + tk; k < kend; k += 16) {
-                const f32x4_t d = *(const f32x4_t*)(dwr + (size_t)k * ldn + n), ww = *(const f32x4_t*)(w + (size_t)k * N + n);
+                f32x4_t d = *(const f32x4_t*)(dwr + (size_t)k * ldn + n);
+                const f32x4_t ww = *(const f32x4_t*)(w + (size_t)k * N + n);
+                if (nsum > 1) {
+                    const float* p = dwr + (size_t)k * ldn + n;
+                    f32x4_t t = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    t += d;
+                    int q = 1;
+                    for (; q + 4 <= nsum; q += 4) {             // four loads in flight, added in split order
+                        const f32x4_t v0 = *(const f32x4_t*)(p + (size_t)q * pstride), v1 = *(const f32x4_t*)(p + (size_t)(q + 1) * pstride);
+                        const f32x4_t v2 = *(const f32x4_t*)(p + (size_t)(q + 2) * pstride), v3 = *(const f32x4_t*)(p + (size_t)(q + 3) * pstride);
+                        t += v0; t += v1; t += v2; t += v3;
+                    }
+                    for (; q < nsum; ++q) t += *(const f32x4_t*)(p + (size_t)q * pstride);
+                    d = t;
+                }
                 dot += ww * d;
                 f32x4_t g = s * d + ww * regc;
                 if (!trainable) g = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -234,7 +251,9 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
     if (n < N) {
         const float s = bn_scale(gamma, var, eps, n);
         for (int k = kbeg + tk; k < kend; k += 4) {
-            const float d = dwr[(size_t)k * ldn + n], ww = w[(size_t)k * N + n];
+            float d = 0.f;
+            for (int q = 0; q < nsum; ++q) d += dwr[(size_t)q * pstride + (size_t)k * ldn + n];
+            const float ww = w[(size_t)k * N + n];
             dot += ww * d;
             gw[(size_t)k * N + n] = trainable ? (s * d + regc * ww) : 0.f;
         }
@@ -254,8 +273,9 @@ __global__ void finalize_mat_batch_kernel(const urso_param_desc* __restrict__ de
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     const int gx = ceil_div(d.N, 64);
-    finalize_mat_body(local % gx, local / gx, d.K, d.N, d.npad, d.kb, d.splits == 1 ? d.part : d.dw_raw, d.w, d.gamma, d.var, d.eps,
-                      d.regc, d.trainable, d.gw, d.dotpart);
+    const bool fused = urso_fuse_reduce(d.splits);
+    finalize_mat_body(local % gx, local / gx, d.K, d.N, d.npad, d.kb, (d.splits == 1 || fused) ? d.part : d.dw_raw, d.w, d.gamma, d.var, d.eps,
+                      d.regc, d.trainable, d.gw, d.dotpart, fused ? d.splits : 1, (size_t)d.K * d.npad + URSO_WGRAD_PART_PAD);
 }
 
 // pass 2: one thread per channel
@@ -263,9 +283,10 @@ __device__ __forceinline__ void finalize_vec_body(int n, int N, int ks, const fl
                                     const float* __restrict__ b, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                     float regb, int trainable, int bn_trainable,
-                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta, int nsum = 1, int cstride = 0) {
     if (n >= N) return;
-    const float cs = colsum ? colsum[n] : 0.f;
+    float cs = 0.f;
+    if (colsum) for (int q = 0; q < nsum; ++q) cs += colsum[(size_t)q * cstride + n];        // nsum > 1: the split partials of the column sums, in split order
     const float s = bn_scale(gamma, var, eps, n);
     if (gb) gb[n] = trainable ? (s * cs + regb * (b ? b[n] : 0.f)) : 0.f;
     if (ggamma) {
@@ -293,8 +314,9 @@ __global__ void finalize_vec_batch_kernel(const urso_param_desc* __restrict__ de
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     if (!d.gb && !d.ggamma) return;
-    finalize_vec_body(local * blockDim.x + threadIdx.x, d.N, d.ks, d.dotpart, d.splits == 1 ? d.colpart : d.colsum, d.b, d.gamma, d.mean, d.var, d.eps,
-                      d.regb, d.trainable, d.bn_trainable, d.gb, d.ggamma, d.gbeta);
+    const bool fused = urso_fuse_reduce(d.splits);
+    finalize_vec_body(local * blockDim.x + threadIdx.x, d.N, d.ks, d.dotpart, (d.splits == 1 || fused) ? d.colpart : d.colsum, d.b, d.gamma, d.mean, d.var, d.eps,
+                      d.regb, d.trainable, d.bn_trainable, d.gb, d.ggamma, d.gbeta, fused ? d.splits : 1, d.npad);
 }
 
 static int finalize_ks(int K, int N) {
@@ -335,7 +357,7 @@ static int batch_layer_blocks(int phase, const urso_param_desc& d) {
     switch (phase) {
     case URSO_PB_PREP: return (((d.C | d.N | d.npad) & 3) == 0 ? ceil_div(d.C, 64) * ceil_div(d.npad, 64) : ceil_div(d.C, 32) * ceil_div(d.npad, 32)) * d.KH * d.KW;
     case URSO_PB_REDUCE: {
-        if (d.splits <= 1) return 0;
+        if (d.splits <= 1 || urso_fuse_reduce(d.splits)) return 0;      // few partials: the finalisation sums them itself
         const size_t cnt = (size_t)d.K * d.npad;
         const int rcols = URSO_REDUCE_COLS / urso_reduce_lanes(d.splits);
         return (int)(((cnt + 3) / 4 + rcols - 1) / rcols) + (int)(((size_t)(d.npad + 3) / 4 + rcols - 1) / rcols);

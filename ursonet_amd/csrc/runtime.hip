@@ -19,7 +19,7 @@ int urso_check_launch(const char* what) {
 }
 
 extern "C" const char* urso_last_error(void) { return g_err; }
-extern "C" int urso_abi_version(void) { return 7; }
+extern "C" int urso_abi_version(void) { return 8; }
 
 // ---------------------------------------------------------------- explicit policy options
 UrsoOptions g_urso_opt;
@@ -61,7 +61,7 @@ extern "C" int urso_get_option(const char* name, int* value) {
 }
 
 // ---------------------------------------------------------------- profiler
-struct ProfRec { int id; double flops, bytes; hipEvent_t e0, e1; const void* fn; hipStream_t st; int nl; bool open; };
+struct ProfRec { int id; double flops, bytes, l2; hipEvent_t e0, e1; const void* fn; hipStream_t st; int nl; bool open; };
 static std::mutex g_pmu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
@@ -78,7 +78,7 @@ void urso_prof_before(hipStream_t s, int kernel_id, double flops, double bytes) 
     if (g_prof_depth++ > 0) return;
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
-    ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event(); r.fn = nullptr; r.st = s; r.nl = 0; r.open = true;
+    ProfRec r; r.id = kernel_id; r.flops = flops; r.bytes = bytes; r.l2 = 0.0; r.e0 = get_event(); r.e1 = get_event(); r.fn = nullptr; r.st = s; r.nl = 0; r.open = true;
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
@@ -87,6 +87,13 @@ void urso_prof_after(hipStream_t s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
     if (!g_recs.empty()) { (void)hipEventRecord(g_recs.back().e1, s); g_recs.back().open = false; }
+}
+// bytes the launch copies from L2 into LDS / registers (tile re-reads included): the third roof next to HBM and the matrix pipe
+void urso_prof_l2(double l2_bytes) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pmu);
+    if (g_recs.empty() || !g_recs.back().open) return;
+    g_recs.back().l2 += l2_bytes;
 }
 void urso_prof_symbol(const void* host_fn) {
     if (!g_prof_on) return;
@@ -112,7 +119,7 @@ extern "C" int urso_prof_collect_ex(urso_prof_record_ex* out, int max_records) {
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         if (out && n < max_records) {
             urso_prof_record_ex& o = out[n];
-            o.kernel_id = r.id; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.n_launches = r.nl;
+            o.kernel_id = r.id; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.l2_bytes = r.l2; o.n_launches = r.nl;
             const char* nm = r.fn ? hipKernelNameRefByPtr(r.fn, r.st) : nullptr;
             snprintf(o.symbol, sizeof(o.symbol), "%s", nm ? nm : "");
             ++n;

@@ -173,6 +173,15 @@ class DataParallelEngine(object):
                 self._cus_before = hip.get_option("cus")
                 hip.set_option("cus", usable)           # split counts follow it: the plan below must be rebuilt under the new value (process-wide until close())
                 replan = True
+        # conv_halo.hip's accumulator hand-over between blocks ("stream-K") needs every block of the launch resident: a finishing block spins on
+        # the pieces of the runs behind it.  RCCL's workgroups hold CUs while the backward pass runs, so a producer can sit in the queue behind
+        # them for a collective's duration with a consumer CU spinning on it.  No hand-over while collectives run beside the step (the
+        # whole-tile kernel of conv_halo2.hip takes those layers; option hconv_streamk, restored by close()).
+        self._streamk_before = None
+        if eng.device.type == "cuda" and (self.world > 1 or _force_collectives() or comm is not None) and hip.get_option("hconv_streamk"):
+            self._streamk_before = hip.get_option("hconv_streamk")
+            hip.set_option("hconv_streamk", 0)
+            eng._graphs = None                          # the kernel choice is made at launch time: re-capture under the new policy
         # the last bucket's all-reduce has nothing left to hide behind: cap it (plan_buckets) when ranks really exchange gradients.  On one
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
         if tail_bytes is None:
@@ -187,9 +196,24 @@ class DataParallelEngine(object):
     def close(self):
         """Give the CUs reserved for the collectives back: option `cus` is process-wide, and an Engine planned after this wrapper is gone
         would otherwise size its grids for the smaller chip."""
+        if getattr(self, "_streamk_before", None) is not None:
+            hip.set_option("hconv_streamk", self._streamk_before)
+            self._streamk_before = None
+            self.eng._graphs = None
         if getattr(self, "_cus_before", None) is not None:
             hip.set_option("cus", self._cus_before)
             self._cus_before = None
+            # the wrapped engine planned its split counts, partial workspaces and grouped weight-gradient launches for the reduced CU count:
+            # re-plan it for the whole chip (its captured graph goes with the plan; plan_version moves)
+            self.eng._graphs = None
+            self.eng._build_plan()
+        self._graphs = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _derive_cuts(self):
         """Bucket list, reducer and the backward cut points of the engine's CURRENT plan (set_trainable / a bucket-size change
@@ -201,6 +225,14 @@ class DataParallelEngine(object):
         self.reducer = GradReducer(eng.flat_g, self.buckets, group, compress=self.compress, comm=self.comm)
         if prev is not None and self.compress and prev.flat_g is eng.flat_g:
             self.reducer.resid, self.reducer.cbuf = prev.resid, prev.cbuf      # a re-plan (set_trainable) keeps the error-feedback remainder
+            # ... of the parameters that still train: a frozen layer's gradient slice stays zero, and its old rounding remainder would be
+            # added to it, all-reduced and applied to the frozen weights (the optimizer runs over the whole flat buffer)
+            ranges = getattr(eng, "trainable_ranges", None)
+            if ranges is not None:
+                live = torch.zeros_like(self.reducer.resid, dtype=torch.bool)
+                for (s_, e_) in ranges():
+                    live[s_:e_] = True
+                self.reducer.resid.mul_(live)
         # split the backward op list where each bucket becomes complete
         last_op_of_layer = {}
         for i, (tag, _) in enumerate(eng.bwd_ops):

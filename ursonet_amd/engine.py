@@ -157,6 +157,10 @@ class Engine(object):
             out.setdefault(ln, OrderedDict())[wn] = self.gview(ln, wn).detach().cpu().numpy().copy()
         return out
 
+    def trainable_ranges(self):
+        """[(begin, end)] element ranges of the flat parameter / gradient buffers that belong to trainable layers."""
+        return [(o, o + n) for (ln, _), (o, n, _) in self.slices.items() if self.layer_trainable.get(ln, False)]
+
     def set_trainable(self, layer_regex):
         """net.py:1030-1066: layer.trainable = fullmatch(regex, layer.name).  Rebuilds the plan."""
         self.layer_trainable = {n: bool(re.fullmatch(layer_regex, n)) for n in self.graph.params}
@@ -173,6 +177,9 @@ class Engine(object):
         cfg, g, B, dt, dev = self.config, self.graph, self.B, self.dt, self.device
         training = self.mode == "training"
         self.plan_version = getattr(self, "plan_version", 0) + 1       # ursonet_amd/dp.py re-derives its graph cuts when this moves
+        # split counts, partial workspaces and grouped / paired weight-gradient launches are sized here from these kernel-policy options; the
+        # library re-derives some of them at launch time, so a step under other values would reduce a different number of partials than it wrote
+        self._plan_options = self._planning_options()
         # TRAIN_BN = None ("Train BN layers", net.py:60-76): batch statistics while training -- the BN is not folded, the conv
         # writes its raw output and separate stats / apply / backward kernels run (csrc/bn_train.hip).  Inference and
         # TRAIN_BN = False use the moving statistics folded into the filters.
@@ -704,8 +711,8 @@ class Engine(object):
                 mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
                 if getattr(c, "gd_scatter", False):
                     if add is None:                       # first contribution: everything off the sampled grid is zero
-                        self.bwd_ops.append((None, lambda t=dstg: t.zero_()))       # torch fill: no profiler record
-                        self.labels["bwd"].append(None)
+                        self.bwd_ops.append((None, lambda t=dstg: hip.zero_fill(t)))
+                        self.labels["bwd"].append("zero:" + node.name)
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg, mflag=mflag:
@@ -1063,8 +1070,21 @@ class Engine(object):
         for op in self.opt_ops:
             op()
 
+    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair")
+
+    def _planning_options(self):
+        return tuple(hip.get_option(o) for o in self.PLAN_OPTIONS)
+
+    def _check_plan_options(self):
+        now = self._planning_options()
+        if now != self._plan_options:
+            diff = ", ".join("%s %d -> %d" % (o, a, b) for o, a, b in zip(self.PLAN_OPTIONS, self._plan_options, now) if a != b)
+            raise RuntimeError("kernel-policy options changed since this engine planned its step (%s): the split counts and partial workspaces of the "
+                               "weight-gradient launches are sized at plan time -- build the Engine under the options it runs with" % diff)
+
     def step_eager(self):
         """One training step, launched kernel by kernel (used for capture, profiling and debugging)."""
+        self._check_plan_options()
         self.run_prep(); self.run_forward(); self.run_backward(); self.run_optimizer()
 
     def profile_step(self):

@@ -49,6 +49,14 @@ def load_sample(dataset, config, image_id):
     return Sample(image_id, image, loc, ori, k1, k2)
 
 
+def _hip_section():
+    """The lock that keeps this thread out of HIP while another thread captures a hipGraph (hip.capture_lock; Engine.capture holds it).  Taken
+    around the batched augmentation launches with their device-to-host copies and around pin_memory only: disk loads, the CPU draws and the
+    resize / padding of a batch run unlocked, so a capture waits for a kernel's worth of work, not for a batch's preparation."""
+    from . import hip
+    return hip.capture_lock
+
+
 def augment_samples(samples, dataset, config):
     """The augmentation third (net.py:390-438) for a LIST of samples, in place.  NumPy's GLOBAL generator is consumed exactly as the
     reference consumes it, sample by sample: the sim2real dice (net.py:395), then that sample's rotation dice (net.py:415) and angles
@@ -85,7 +93,8 @@ def augment_samples(samples, dataset, config):
             merged = {"apply": np.concatenate([draws[i]["apply"] for i in g]), "order": np.concatenate([draws[i]["order"] for i in g]),
                       "par": np.concatenate([draws[i]["par"] for i in g]), "seeds": np.concatenate([draws[i]["seeds"] for i in g]),
                       "masks": [draws[i]["masks"][0] for i in g]}
-            out = augment.sim2real_batch(np.stack([samples[i].image for i in g]), draw=merged).cpu().numpy()
+            with _hip_section():
+                out = augment.sim2real_batch(np.stack([samples[i].image for i in g]), draw=merged).cpu().numpy()
             for k, i in enumerate(g):
                 samples[i].image = out[k]
         ids = [i for i in g if i in warp_ids]
@@ -95,12 +104,13 @@ def augment_samples(samples, dataset, config):
                 if not (config.REGRESS_ORI or config.REGRESS_KEYPOINTS):
                     samples[i].ori = dataset.load_quaternion(samples[i].image_id)   # classification targets are re-encoded from the rotated pose
                 quats.append(samples[i].ori)
-            warped, t_new, q_new = augment.rotate_cam_batch(np.stack([samples[i].image for i in ids]), np.stack([samples[i].loc for i in ids]),
-                                                            np.stack(quats), dataset.camera.K, pyr[ids])
-            warped = warped.cpu().numpy()
-            enc = None
-            if not (config.REGRESS_ORI or config.REGRESS_KEYPOINTS):
-                enc = augment.encode_orientations(q_new, dataset.ori_histogram_map, dataset.ori_output_mask, config.BETA).cpu().numpy()
+            with _hip_section():
+                warped, t_new, q_new = augment.rotate_cam_batch(np.stack([samples[i].image for i in ids]), np.stack([samples[i].loc for i in ids]),
+                                                                np.stack(quats), dataset.camera.K, pyr[ids])
+                warped = warped.cpu().numpy()
+                enc = None
+                if not (config.REGRESS_ORI or config.REGRESS_KEYPOINTS):
+                    enc = augment.encode_orientations(q_new, dataset.ori_histogram_map, dataset.ori_output_mask, config.BETA).cpu().numpy()
             for k, i in enumerate(ids):
                 s = samples[i]
                 s.image, s.loc, s.ori = warped[k], t_new[k], q_new[k]
@@ -225,12 +235,12 @@ class DeviceFeeder(object):
             from . import hip
             try:
                 while not self.stop:
-                    # everything here may enter HIP (augmentation kernels and device-to-host copies inside the generator, hipHostMalloc
-                    # in pin_memory): not while the consumer thread captures a hipGraph (hip.capture_lock; Engine.capture holds it)
+                    # the generator takes hip.capture_lock itself around its HIP sections (augment_samples: the batched augmentation kernels and
+                    # their device-to-host copies); here only hipHostMalloc in pin_memory needs it -- not while the consumer thread captures a hipGraph
+                    asm = next(gen)
+                    arrays = [np.ascontiguousarray(a) for a in ([asm.images, asm.loc] + ([asm.k1, asm.k2] if asm.ori is None else [asm.ori]))]
                     with hip.capture_lock:
-                        asm = next(gen)
-                        host = [torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in
-                                ([asm.images, asm.loc] + ([asm.k1, asm.k2] if asm.ori is None else [asm.ori]))]
+                        host = [torch.from_numpy(a).pin_memory() for a in arrays]
                     self.q.put(host)
             except BaseException as e:                         # surfaced by next_into
                 self.err = e

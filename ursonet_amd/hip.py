@@ -45,7 +45,7 @@ capture_lock = threading.RLock()
 
 class ProfRecordEx(C.Structure):
     _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double), ("n_launches", C.c_int32),
-                ("symbol", C.c_char * 236)]
+                ("symbol", C.c_char * 228), ("l2_bytes", C.c_double)]
 
 
 class UrsoHipError(RuntimeError):
@@ -81,6 +81,7 @@ _SIGS = {
     "urso_conv_igemm_ws_bytes": (_sz, [_gp, _i]),
     "urso_conv_igemm_ws": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "urso_conv_igemm_bits_ok": (_i, [_gp, _i, _i, _sz]),
+    "urso_conv_igemm_algorithmic": (_i, [_gp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "urso_conv_igemm_halo_ok": (_i, [_gp, _i, _i, _i]),
     "urso_conv_igemm_halo2_shape": (_i, [_gp, _i, _i, _i, _i]),
     "urso_conv_igemm_halo_ws_bytes": (_sz, []),
@@ -142,6 +143,7 @@ _SIGS = {
     "urso_conv_pointwise_sampled": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rows_expand2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "urso_zero_fill": (_i, [_vp, C.c_size_t, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
     "urso_pad_images_u8": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -261,6 +263,13 @@ def conv_igemm_halo_ws_bytes():
 
 def conv_igemm_halo_ok(g, dt, flags, has_add=False):
     return bool(_lib.urso_conv_igemm_halo_ok(C.byref(g), dt, flags, int(bool(has_add))))
+
+
+def conv_igemm_algorithmic(g, dt, flags, has_add=False, has_mask=False):
+    """(FLOPs, bytes) the launch profiler records for a urso_conv_igemm_ex launch (host arithmetic)."""
+    fl, by = C.c_double(0), C.c_double(0)
+    _chk(_lib.urso_conv_igemm_algorithmic(C.byref(g), dt, flags, int(bool(has_add)), int(bool(has_mask)), C.byref(fl), C.byref(by)), "urso_conv_igemm_algorithmic")
+    return float(fl.value), float(by.value)
 
 
 def conv_igemm_halo2_shape(g, dt, flags, has_add=False, has_ws=False):
@@ -570,6 +579,11 @@ def conv_pointwise_sampled(g, dt, flags, src, wgt, bias, add, dst, bits_out, dst
                                           stream_ptr(stream)), "urso_conv_pointwise_sampled")
 
 
+def zero_fill(t, stream=None):
+    """urso_zero_fill: t[...] = 0 (16-byte aligned tensor whose size is a multiple of 16 bytes)."""
+    _chk(_lib.urso_zero_fill(ptr(t), t.numel() * t.element_size(), stream_ptr(stream)), "urso_zero_fill")
+
+
 def rows_expand2(B, H, W, row_bytes, src, dst, stream=None):
     """urso_rows_expand2: dst[b, y, x, :] = src[b, y/2, x/2, :] at even (y, x), zero elsewhere."""
     _chk(_lib.urso_rows_expand2(B, H, W, row_bytes, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rows_expand2")
@@ -618,6 +632,14 @@ def prof_collect_ex(max_records=65536):
     buf = (ProfRecordEx * max_records)()
     n = _lib.urso_prof_collect_ex(buf, max_records)
     return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes, buf[i].n_launches, buf[i].symbol.decode(errors="replace")) for i in range(n)]
+
+
+def prof_collect_l2(max_records=65536):
+    """prof_collect_ex with the L2 -> LDS / register bytes of each call appended: [(kernel_id, ms, flops, bytes, n_launches, symbol, l2_bytes)]."""
+    buf = (ProfRecordEx * max_records)()
+    n = _lib.urso_prof_collect_ex(buf, max_records)
+    return [(buf[i].kernel_id, buf[i].ms, buf[i].flops, buf[i].bytes, buf[i].n_launches, buf[i].symbol.decode(errors="replace"), buf[i].l2_bytes)
+            for i in range(n)]
 
 
 COMM_ID_BYTES = 128
