@@ -234,7 +234,9 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
         eng, w0 = _run_engine(cfg, img, loc, ori)
     assert len(eng.pair_first) == (5 if pair else 0)          # res2{b,c}, res3{b,c,d}: branch2a fused behind the previous block's branch2c
     q = G.StorageRounding(torch.bfloat16 if dtype == "bfloat16" else torch.float16)
-    dec = ReluDecisions(eng, tol=4 * tol_out)
+    # decisions may differ only where the oracle's own pre-activation is this close to zero (relative to the tensor's max): measured over the 24
+    # runs above, bf16 1.4e4 flips < 1e-3, 1.5e3 < 1e-2, one < 3e-2, none beyond; fp16 all < 1.1e-3 (profiles/r04_parity.txt)
+    dec = ReluDecisions(eng, tol=4e-2 if dtype == "bfloat16" else 4e-3)
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
     _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3, tol_l2=0.85 * tol_g, tol_norm=tol_out)
@@ -253,10 +255,16 @@ def test_training_step_parity_bf16_at_cfg2_width(pwx):
     with hip.options(pwx=pwx, pair=(1 if pwx == 1 else 0)):
         eng, w0 = _run_engine(cfg, img, loc, ori)
     q = G.StorageRounding(torch.bfloat16)
-    dec = ReluDecisions(eng, tol=8e-2)
+    # ReLU decisions of device and oracle may differ only where the oracle's pre-activation is within 2e-2 of the tensor's max of zero.  Measured
+    # at this size (tools/probes/parity_cfg2w.py, profiles/r04_parity.txt; two seeds): 1.2e-3 of the 1.05e8 decisions flip -- 1.0e5 of them below
+    # 1e-3 of the max, 2.0e4 below 3e-3, 1.3e3 below 1e-2, NONE above 9.9e-3 -- so the gate sits at twice the largest flip seen (round 3 allowed
+    # 8e-2).  Errors measured there: outputs 1.3e-2, worst filter gradient 1.4e-2 (max norm) / 9.6e-3 (Euclidean), global norm 3e-4: at the
+    # benchmark's width the gradients average over 25x the pixels of the small case and the 16-bit residue is far from the gates.
+    dec = ReluDecisions(eng, tol=2e-2)
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
-    _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3)
+    print("relu flips:", dec.flips, "of", dec.total, "worst %.2e" % dec.worst, dec.histogram())
+    _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3, tol_l2=2.5e-2, tol_norm=1e-2)
 
 
 @pytest.mark.parametrize("dtype,tol_out,tol_g", [("bfloat16", 2e-2, 4e-2), ("float16", 4e-3, 7e-3)])

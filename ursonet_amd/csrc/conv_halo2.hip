@@ -22,14 +22,18 @@
 //     0.6 VALU per MFMA, and the loop runs at 84 % of the matrix pipe in CYCLES (what remains is the clock: 1.84 GHz under this load).
 //   * the halo rows' pixel offsets live in an LDS table filled once per tile (one row per thread), not in eight registers per lane that
 //     hipcc spilled and reloaded behind vmcnt(0).
-//   * fixed LDS map (halo buffers at 0 and 60 KiB, two-slot filter ring behind them): the halo double buffer of a 384-pixel tile takes
-//     120 KiB, so a ring slot is refilled behind the barrier that follows its last fragment read (every wave waits lgkmcnt(0) before it
-//     arrives there), one step before it is needed.
+//   * fixed LDS map (halo buffers at 0 and 60 KiB, the filter ring behind them): the halo double buffer of a 384-pixel tile takes 120 KiB, so
+//     the ring has 32 KiB: two slots of 16 KiB (NJ = 2) -- a slot is refilled behind the barrier that follows its last fragment read (every wave
+//     waits lgkmcnt(0) before it arrives there), one step before it is needed -- or four of 8 KiB (NJ = 1) refilled three steps ahead, two
+//     copies kept in flight across the barriers with a counted vmcnt: cfg2's stage 5, whose 4.7 MB filter is cold in the step.
 // Results are bit-identical to conv_halo.hip's whole-tile schedule (same MFMA, same k order per output element).
 // Measured (bf16, B = 32, isolated / in the step): stage 4 47.7 / 46-50 us (1.01 PFLOP/s), stage 5 49.0 / 57-59 us (its 4.7 MB filter
 // is cold in the step and a two-slot ring hides one step of latency).
 #include "common.h"
 #include <type_traits>
+#ifndef URSO_HX2_NS1
+#define URSO_HX2_NS1 4          // filter-ring slots of the NJ = 1 shapes (2: the two-slot protocol of NJ = 2; A/B through URSO_VARIANT_FLAGS)
+#endif
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -91,7 +95,14 @@ constexpr int HX_ABUF1 = 61440, HX_FOFF = 2 * HX_ABUF1;
 template <typename T, int MI, int NJ, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    constexpr int BM = 128 * MI, BN = 64 * NJ, BSLOT = BN * 128, XOFF = HX_FOFF + 2 * BSLOT;
+    // NS ring slots: a filter tile is copied NS - 1 steps before its first read.  Two where the 64-filter-per-MFMA-column tile is 16 KiB (the halo
+    // double buffer leaves no more); four for the 8 KiB tiles of NJ = 1 -- the shape of cfg2's stage 5, whose 4.7 MB filter is cold in the step:
+    // with one step of lead (0.5 us) every step waited for HBM (57-59 us in the step against 47-49 us on a warm filter)
+#ifndef URSO_HX2_NS1
+#define URSO_HX2_NS1 4
+#endif
+    constexpr int NS = (NJ == 1) ? URSO_HX2_NS1 : 2;
+    constexpr int BM = 128 * MI, BN = 64 * NJ, BSLOT = BN * 128, XOFF = HX_FOFF + NS * BSLOT;
     constexpr int NQ = NJ;                                     // filter-tile DMA instructions per wave and tap (BSLOT / 8 KiB)
     constexpr int LPR = 4 * NJ, RPI = 64 / LPR, NSI = 32 / RPI; // epilogue: lanes per output row (32 NJ filters * 2 B / 16), rows per store instruction, instructions per 32-pixel sub-tile
     constexpr int NST = MI * NSI;                              // vector-memory stores per lane of one epilogue
@@ -168,10 +179,10 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
         *(uint32_t*)(smem + TOFF + which * 2048 + tid * 4) = (pix >= 0) ? (uint32_t)pix * (uint32_t)(a.C * 2) : URSO_OOB_SHIFT;
     };
     const uint32_t aswz = (uint32_t)((c8 ^ ((4 * wave + (r8 >> 1)) & 7)) << 4);      // (row >> 1) & 7 of row 8 (wave + 8 j) + r8 does not depend on j
-    auto table_entry = [&](int which, int j) -> uint32_t {    // static j
+    auto table_entry = [&](int which, int j) -> uint32_t {
         return *(const uint32_t*)(smem + TOFF + which * 2048 + (8 * (wave + 8 * j) + r8) * 4);
     };
-    auto dma_a = [&](int j, int cc, int buf, uint32_t rowoff) {                 // static j
+    auto dma_a = [&](int j, int cc, int buf, uint32_t rowoff) {
         if (8 * (wave + 8 * j) < a.R)
             hx_dma16(rs, lds0 + buf * HX_ABUF1 + (wave + 8 * j) * 1024, rowoff + aswz + (uint32_t)cc * 128u);      // OOB_SHIFT + small stays out of range
     };
@@ -184,20 +195,29 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     int tile = t_begin;
     int tw = 0;                                                // the table of the tile whose halo rows are being copied
-    {   // ---- block prologue: chunk 0's halo tile, filter tiles of steps 0 and 1
+    {   // ---- block prologue: chunk 0's halo tile, filter tiles of the first NS steps
         const int n0 = (tile % a.tilesN) * BN;
         fill_table(tile, 0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (j < a.JA) dma_a(j, 0, 0, table_entry(0, j));
-        dma_b(n0, 0, 0, 0);
-        dma_b(n0, 0, 1, 1);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) dma_b(n0, 0, t, t);
         hx_wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // also publishes the bias written above
     }
     i32x4_t fwA[NJ], fpA[MI], fwB[NJ], fpB[MI];               // fragment sets of two consecutive 16-deep k sub-steps
-    // fragments of (tap t, k sub-step k) out of ring slot `slot` and halo buffer `hb` (both static: immediates)
+    // ring slot x of a step = its index in the chunk pair mod NS (static), turned by `sb` (18 steps per pair: with four slots the phase moves by
+    // two from pair to pair): one base register per slot, re-derived once per chunk pair
+    int sb = 0;
+    uint32_t fbs[NS];
+    auto set_fbs = [&]() {
+#pragma unroll
+        for (int x = 0; x < NS; ++x) fbs[x] = fb + (uint32_t)(((x + sb) & (NS - 1)) * BSLOT);
+    };
+    set_fbs();
+    // fragments of (tap t, k sub-step k) out of ring slot `slot` (static index) and halo buffer `hb` (static: an immediate)
     auto rd = [&](i32x4_t (&fw)[NJ], i32x4_t (&fp)[MI], const int slot, const int hb, const int t, const int k) {
         if constexpr (PROBE == 1) {
 #pragma unroll
@@ -206,13 +226,13 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
             for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fp[i]));
             return;
         }
-        const uint32_t ub = fb ^ (uint32_t)(k << 5), ua = (pb[t] ^ (uint32_t)(k << 5)) + (uint32_t)(hb * HX_ABUF1);
+        const uint32_t ub = fbs[slot] ^ (uint32_t)(k << 5), ua = (pb[t] ^ (uint32_t)(k << 5)) + (uint32_t)(hb * HX_ABUF1);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fw[j] = *(const i32x4_t*)(smem + slot * BSLOT + j * 4096 + ub);
+        for (int j = 0; j < NJ; ++j) fw[j] = *(const i32x4_t*)(smem + j * 4096 + ub);
 #pragma unroll
         for (int i = 0; i < MI; ++i) fp[i] = *(const i32x4_t*)(smem + i * 4096 + ua);
     };
-    rd(fwA, fpA, 0, 0, 0, 0);                                  // step 0, k = 0
+    rd(fwA, fpA, 0, 0, 0, 0);                                  // step 0, k = 0 (ring slot 0)
 
     bool stores_pending = false;                               // the previous tile's epilogue left NST stores in flight
     while (true) {
@@ -252,40 +272,69 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
             const bool last = cc + 1 == a.nchunks;
             if (par == 0 && cc + 2 == a.nchunks && has_next) fill_table(tile + 1, tw ^ 1);     // visible behind this chunk's barriers
             if (last && has_next) tw ^= 1;                     // from here on the halo copies target the next tile's chunk 0
-            uint32_t acur = table_entry(tw, 0);
             const bool more_a = !last || has_next;
             const int cca = last ? 0 : cc + 1;
             const bool first_wait_after_epilogue = cc == 0 && stores_pending && !(a.dbg & 1);
+            // halo pieces of the next chunk ride along in this chunk's first steps.  Two slots (copies waited for a step later): piece t at step t.
+            // Four slots (a copy is only known to have landed three barriers later, and the next chunk's halo is first read behind barrier 8):
+            // all pieces by step 5 -- two per step in the first JA - 6 steps, one per step after
+            const int e2 = NS == 4 ? max(0, a.JA - 6) : 0;
+            auto piece = [&](int t, int q) -> int { return t < e2 ? 2 * t + q : (q == 0 ? t + e2 : 64); };      // 64: none
+            uint32_t acur0 = table_entry(tw, 0), acur1 = table_entry(tw, 1);
             // the read addresses of a k sub-step are one v_xor away from these: keep the compiler from computing all 4 x (9 MI + NJ) of them
             // ahead of the loop (it then spills)
-            asm volatile("" : "+v"(fb));
+#pragma unroll
+            for (int x = 0; x < NS; ++x) asm volatile("" : "+v"(fbs[x]));
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 asm volatile("" : "+v"(pb[t]));
-                const int S = (par + t) & 1;                   // this step's ring slot; S ^ 1 holds the next step's filter tile
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int u = 9 * par + t, S = u % NS, S1 = (u + 1) % NS;      // this step's ring slot index; S1 holds the next step's filter tile
                 // k = 0 fragments are in fwA / fpA (read during the previous step)
                 rd(fwB, fpB, S, par, t, 1); region_end(); mma(fwA, fpA); region_end();
                 rd(fwA, fpA, S, par, t, 2); region_end(); mma(fwB, fpB); region_end();
                 rd(fwB, fpB, S, par, t, 3); region_end(); mma(fwA, fpA); region_end();
-                // ---- this wave's copies issued one step ago have landed and its reads of slot S have returned -> barrier -> every wave's
-                //      have: slot S and (at t = 0) the previous chunk's halo buffer are free, slot S ^ 1 and the pieces of the next halo tile
+                // ---- this wave's copies issued NS - 1 steps ago have landed and its reads of slot S have returned -> barrier -> every wave's
+                //      have: slot S and (at t = 0) the previous chunk's halo buffer are free, slot S1 and the pieces of the next halo tile
                 //      copied so far are visible
-                if (t == 0 && first_wait_after_epilogue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (NS == 2) {
+                    if (t == 0 && first_wait_after_epilogue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NST) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                } else {
+                    // Four slots: the filter tile of step u + 1 was copied at step u - 3.  Every step issues its halo pieces FIRST and its one
+                    // filter copy LAST, so "at most two copies in flight" means: the filter copy of step u - 1, and either a halo piece of step
+                    // u - 1 (then the filter copy of step u - 2 has landed too: two steps of lead while halo pieces ride along) or the filter
+                    // copy of step u - 2 (three steps of lead).  A static count -- no per-wave bookkeeping.  In a tile's first three steps
+                    // the previous epilogue's stores, issued behind those copies, may stay in flight as well; at the end of the block's
+                    // last tile no further copies are issued and the count runs down.
+                    static_assert(NQ == 1, "the four-slot ring is the NJ = 1 form");
+                    if (t < 3 && first_wait_after_epilogue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NST + 2) : "memory");
+                    else if (t >= 6 && !more_a) { if (t == 6) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                }
                 if (!(a.dbg & 64)) asm volatile("s_barrier" ::: "memory");
-                if (!(a.dbg & 32)) {   // filter tile two steps ahead -> slot S; one piece of the next halo tile -> the other halo buffer
-                    const int t2 = (t + 2) % 9;
-                    const bool wrap = t + 2 >= 9;
+                if (!(a.dbg & 32)) {   // pieces of the next halo tile -> the other halo buffer; filter tile NS steps ahead -> slot S
+                    if constexpr (NS == 2) {
+                        if (t < 8 && t < a.JA && more_a) dma_a(t, cca, par ^ 1, acur0);
+                        if (t < 7) acur0 = table_entry(tw, t + 1);
+                    } else {
+                        if (t < 6 && more_a) {
+                            const int j0 = piece(t, 0), j1 = piece(t, 1);
+                            if (j0 < a.JA) dma_a(j0, cca, par ^ 1, acur0);
+                            if (j1 < a.JA) dma_a(j1, cca, par ^ 1, acur1);
+                        }
+                        if (t < 5) { acur0 = table_entry(tw, min(piece(t + 1, 0), 7)); acur1 = table_entry(tw, min(piece(t + 1, 1), 7)); }
+                    }
+                    const int t2 = (t + NS) % 9;
+                    const bool wrap = t + NS >= 9;
                     const bool okb = !wrap || more_a;
-                    if (okb) dma_b((wrap && last) ? n0n : n0, wrap ? cca : cc, t2, S);
-                    if (t < 8 && t < a.JA && more_a) dma_a(t, cca, par ^ 1, acur);
-                    if (t < 7) acur = table_entry(tw, t + 1);
+                    if (okb) dma_b((wrap && last) ? n0n : n0, wrap ? cca : cc, t2, (S + sb) & (NS - 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // next step's k = 0 fragments (its filter tile and -- across a chunk seam -- its halo tile became visible at this or an
                 // earlier barrier)
-                if (t < 8) rd(fwA, fpA, S ^ 1, par, t + 1, 0);
-                else rd(fwA, fpA, S ^ 1, par ^ 1, 0, 0);
+                if (t < 8) rd(fwA, fpA, S1, par, t + 1, 0);
+                else rd(fwA, fpA, S1, par ^ 1, 0, 0);
                 region_end(); mma(fwB, fpB); region_end();
             }
         };
@@ -293,6 +342,7 @@ __global__ __launch_bounds__(512, 2) void hconv2_kernel(const Hx2Args a) {
             for (int cc = 0; cc < a.nchunks; cc += 2) {
                 chunk(std::integral_constant<int, 0>{}, cc);
                 chunk(std::integral_constant<int, 1>{}, cc + 1);
+                if constexpr (NS == 4) { sb ^= 2; set_fbs(); }
             }
 
         // ---- epilogue: + bias -> ReLU -> 16-bit, transposed through LDS (this wave's 2 NJ KiB of halo buffer 1, retired by the tile's last
@@ -380,7 +430,7 @@ static bool hx2_shape_fits(const urso_conv_geom* g, int mi, int nj) {
     if (Vw < 64 / (4 * nj)) return false;                     // the epilogue's row walk advances 16 / NJ virtual pixels per store instruction
     if (hx2_abuf(R, nj) > (size_t)HX_ABUF1) return false;      // the fixed LDS map: two halo buffers of at most HX_ABUF1 bytes, ring, bias
     if (R > 512) return false;                                // one halo row per thread in the offset tables
-    return (size_t)HX_FOFF + (size_t)2 * BN * 128 + (size_t)g->N * 4 + 2 * 2048 <= (size_t)HX_LDS;
+    return (size_t)HX_FOFF + (size_t)(nj == 1 ? URSO_HX2_NS1 : 2) * BN * 128 + (size_t)g->N * 4 + 2 * 2048 <= (size_t)HX_LDS;      // ring (4 slots of 8 KiB or 2 of 16), bias, offset tables
 }
 
 // Estimated time of a layer on shape (mi, nj) in microseconds, fitted to tools/hconv2_sweep.py (profiles/r04_hconv2_sweep.txt: ten layers of
