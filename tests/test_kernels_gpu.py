@@ -679,7 +679,10 @@ def test_batched_param_phases_equal_per_layer_entry_points(dt):
     pb = hip.ParamBatch(descs, torch.device("cuda"))
     ids = list(range(len(descs)))
     for ph in (hip.PB_PREP, hip.PB_REDUCE, hip.PB_FINALIZE_MAT, hip.PB_FINALIZE_VEC):
-        assert pb.plan(ph, "t", ids) > 0
+        nb = pb.plan(ph, "t", ids)
+        # a layer with 2 .. 16 split partials has no reduction blocks: the finalisation sums its partials itself, in the reduction's order
+        # (the bit-equality with urso_conv_wgrad + urso_param_grad_finalize below is that claim's test)
+        assert (nb > 0) if (ph != hip.PB_REDUCE or any(d.splits > 16 for d in descs)) else (nb == 0), (ph, nb, [d.splits for d in descs])
     pb.run(hip.PB_PREP, "t", dt)
     for t in keep:
         hip.conv_wgrad_partial(t["g"], dt, t["x"], t["dz"], t["ws"])

@@ -646,6 +646,8 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
         assert 0.0 <= ex < 5.0, ex
         # no accumulator hand-over between blocks (conv_halo.hip's stream-K needs every block resident) while collectives run beside the step:
         # the wrapper switches it off for the process and close() gives both options back and re-plans the engine for the whole chip
+        dp.close()                              # gives the CUs back (the engine it wrapped is re-planned for the whole chip)
+        assert hip.get_option("cus") == 0
         hip.set_option("hconv_streamk", 1)
         eng2 = Engine(cfg, "training", seed=8, randomize_bn=True, grad_bucket_bytes=8 << 20)
         with DataParallelEngine(eng2, bucket_bytes=8 << 20, comm_cus=total - 64) as dp2:

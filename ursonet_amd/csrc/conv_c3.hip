@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
             const int hy = (hr * 241) >> 13, hx = hr - hy * C3_HW;         // hr / 34 for hr < 224
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool ok = hr < C3_HROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 128 + (((lane_d & 7) ^ ((hr >> 1) & 7)) << 4));
+            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 128 + (((lane_d & 7) ^ ((hx >> 1) & 7)) << 4));      // slot swizzle: see rd below
             c3_dma16(rs, lds0 + buf * C3_ABUF + (wave + 4 * i) * 1024, ok ? off : URSO_OOB_SHIFT);
         }
     };
@@ -115,6 +115,9 @@ __global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
 
     // store roles: instruction i covers output-tile rows 8 (wave + 4 i) + (lane >> 3) (pixel ty = row / 32, tx = row % 32), LDS slot lane & 7
     constexpr int NST = 4;
+    uint32_t ea[3];                                            // fragment read addresses: lane part of tap column kx (see rd)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) ea[kx] = (uint32_t)(l31 * 128 + ((h ^ (((l31 + kx) >> 1) & 7)) << 4));
 
     dma_tile(tile, 0);
     int buf = 0;
@@ -125,7 +128,6 @@ __global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
         first = false;
         c3_barrier();
         if (has_next) dma_tile(tile + bpx, buf ^ 1);
-        const char* sA = smem + buf * C3_ABUF;
 
         f32x16_t acc[2];
         {
@@ -137,15 +139,21 @@ __global__ __launch_bounds__(256, 2) void c3_kernel(const C3Args a) {
                 for (int r = 0; r < 2; ++r) { acc[r][4 * q] = b4.x; acc[r][4 * q + 1] = b4.y; acc[r][4 * q + 2] = b4.z; acc[r][4 * q + 3] = b4.w; }
             }
         }
-        // the fragment addresses are functions of (lane, tap) only: keep them from being hoisted out of the tile loop into registers
-        asm volatile("" : "+v"(l31));
         // step s = (halo row hr of the wave's 4, column shift kx, 16-channel slice j): ONE fragment, used by output row 0 as tap (hr, kx)
-        // and by output row 1 as tap (hr - 1, kx) -- 48 LDS reads feed the 72 MFMAs; fragments are requested three steps ahead
+        // and by output row 1 as tap (hr - 1, kx) -- 48 LDS reads feed the 72 MFMAs; fragments are requested three steps ahead.
+        // Address of a fragment: the slot swizzle is taken on the pixel's position INSIDE its halo row, (hx >> 1) & 7 with hx = l31 + kx (the
+        // halo pitch is even, so the bank-row parity of a pixel is that of hx and any 32 consecutive pixels of a row read conflict-free as
+        // before), which makes it a function of (lane, kx) alone: three lane registers ea[kx], the halo row and kx as an immediate, the
+        // channel slice one v_xor.  Recomputing (row >> 1) & 7 on the whole row index cost ~5 VALU instructions per read -- two waves share a
+        // SIMD's issue port, a 32x32x16 MFMA leaves ~3.5 other instructions per MFMA and wave free (conv_halo2.hip).
         i32x4_t f[4];
+        uint32_t eb[3];                                        // this tile's read bases: patch buffer and the wave's row pair folded in (multiples of 128)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) eb[kx] = ea[kx] + (uint32_t)(buf * C3_ABUF + 2 * pw * C3_HW * 128);
         auto rd = [&](i32x4_t& fs, int s) {
             const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
-            const int row = (2 * pw + hr) * C3_HW + l31 + kx;
-            fs = *(const i32x4_t*)(sA + c3_rd(row, h, j));
+            if (j == 0) asm volatile("" : "+v"(eb[kx]));      // (opaque per (row, kx): no twelve pre-formed addresses next to the 144 filter registers)
+            fs = *(const i32x4_t*)(smem + (hr * C3_HW + kx) * 128 + (eb[kx] ^ (uint32_t)(j << 5)));
         };
         rd(f[0], 0);
         rd(f[1], 1);
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
             // slot swizzle: the halo row index for the 34-pixel pitch; for the 18-pixel pitch the index on a VIRTUAL pitch of 16 -- ds_read_b128
             // services lanes {0-3, 12-15, 20-27} (and {4-11, 16-19, 28-31}) of a half wave together (tools/probes/lds_group_probe.hip), and only
             // with 16 virtual rows between the two half rows of the 8 x 16 tile do those 16 lanes see 16 different (parity, swizzle) pairs
-            const int sw = TW == 32 ? ((hr >> 1) & 7) : (((hy * 16 + hx) >> 1) & 7);
+            const int sw = (hx >> 1) & 7;                      // on the position inside the halo row (= the virtual-pitch-16 index of the 18-pixel pitch, mod 8)
             const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + half * 128 + (((lane_d & 7) ^ sw) << 4));
             if (ii < 54) c3_dma16(rs, lds0 + buf * C3W_PATCH + half * C3_ABUF + rb * 1024, ok ? off : URSO_OOB_SHIFT);
         }
@@ -280,6 +288,14 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
     if (tid < 128) *(float*)(smem + C3W_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
 
     constexpr int NST = 4;                                     // 128 pixels x 16 slots = 2048 vectors / 512 threads
+    // fragment read addresses: the lane part of tap column kx (c3_kernel's rd has the derivation); 8 x 16 geometry: lane & 15 is the column,
+    // lane >> 4 the row of the halo row pair
+    uint32_t ea[3];
+    {
+        const int prow = TW == 32 ? l31 : (l31 >> 4) * HW + (l31 & 15);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) ea[kx] = (uint32_t)(prow * 128 + ((h ^ ((((l31 & (TW - 1)) + kx) >> 1) & 7)) << 4));
+    }
     dma_tile(tile, 0);
     int buf = 0;
     bool first = true;
@@ -289,20 +305,25 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
         first = false;
         c3_barrier();                                          // (1)
         if (has_next) dma_tile(tile + bpx, buf ^ 1);
-        const char* sA = smem + buf * C3W_PATCH + ch * C3_ABUF;
-
         f32x16_t acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-        asm volatile("" : "+v"(l31));
         i32x4_t f[4];
+        // this tile's read bases (patch buffer and channel half folded in: multiples of 128, the xor below touches bits 5-6 only)
+        uint32_t eb[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) eb[kx] = ea[kx] + (uint32_t)(buf * C3W_PATCH + ch * C3_ABUF);
+        // (opaque at every new (row, kx): hipcc would otherwise form all twelve xor-ed addresses ahead of the loop and spill next to the
+        // 144 filter registers)
+        auto fresh = [&](int s) { if ((s & 3) == 0) asm volatile("" : "+v"(eb[(s / 4) % 3])); };
         if constexpr (TW == 32) {
             // step s = (halo row hr of 6, column shift kx, 16-channel slice j): one fragment for the output rows r = hr - ky, ky = 0..2
             auto rd = [&](i32x4_t& fs, int s) {
                 const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
-                fs = *(const i32x4_t*)(sA + c3_rd(hr * HW + l31 + kx, h, j));
+                fresh(s);
+                fs = *(const i32x4_t*)(smem + (hr * HW + kx) * 128 + (eb[kx] ^ (uint32_t)(j << 5)));
             };
             rd(f[0], 0);
             rd(f[1], 1);
@@ -322,11 +343,10 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
         } else {
             // pixel tile m = output rows 2 m, 2 m + 1.  Step s = (first halo row rp of a row pair, 0..8; kx; j): the fragment of halo rows
             // (rp, rp + 1) serves tile m with ky = rp - 2 m wherever 0 <= ky <= 2 (even rp: two tiles, odd rp: one): 108 reads per 144 MFMAs
-            const int prow = (l31 >> 4) * HW + (l31 & 15), vrow = (l31 >> 4) * 16 + (l31 & 15);
             auto rd = [&](i32x4_t& fs, int s) {
                 const int rp = s / 12, kx = (s / 4) % 3, j = s & 3;
-                const int row = rp * HW + prow + kx, sw = ((rp * 16 + vrow + kx) >> 1) & 7;       // swizzle on the virtual 16-pixel pitch (dma_tile)
-                fs = *(const i32x4_t*)(sA + row * 128 + (((2 * j + h) ^ sw) << 4));
+                fresh(s);
+                fs = *(const i32x4_t*)(smem + (rp * HW + kx) * 128 + (eb[kx] ^ (uint32_t)(j << 5)));
             };
             rd(f[0], 0);
             rd(f[1], 1);

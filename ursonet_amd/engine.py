@@ -1070,7 +1070,7 @@ class Engine(object):
         for op in self.opt_ops:
             op()
 
-    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair")
+    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap")
 
     def _planning_options(self):
         return tuple(hip.get_option(o) for o in self.PLAN_OPTIONS)
