@@ -14,6 +14,7 @@ PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 FAMILIES = [
     ("pwx_kernel", "conv_pwx.hip", "160 px x {256,128} filters, 8 waves (80x64 wave tiles), 3-4 stage LDS-DMA ring 156/148 KiB, 1 block/CU", "reduction-heavy pointwise layers (K >= 512) of stages 4-5"),
     ("pw_kernel", "conv_pw.hip", "128 px x {128,64}, 4 waves, 2 LDS-DMA stages 64/48 KiB, 2-3 blocks/CU", "general 16-bit DMA implicit GEMM: pointwise, strided / sampled layers, 3x3 on small grids"),
+    ("hconv2_kernel", "conv_halo2.hip", "128 MI virtual px x 64 NJ filters per tile, (MI, NJ) per layer (cfg2: 384 x 128 in stage 4, 384 x 64 in stage 5: one WHOLE tile per CU), 8 waves (32 MI x 32 NJ, 32x32x16 MFMA), halo double buffer + 2- / 4-slot filter ring 160 KiB, one LDS address register per tap", "3x3 / stride-1 layers with >= 128 channels (stages 4-5)"),
     ("hconv_kernel", "conv_halo.hip", "256 virtual px x 128 filters, 8 waves (64x64, 32x32x16 MFMA), halo tile + 3-slot filter ring 160 KiB, 1 block/CU, (tile, chunk) stream-K", "3x3 / stride-1 layers with >= 128 channels (stages 4-5)"),
     ("c3w_kernel", "conv_c3.hip", "8x16 px x 128 filters, filters in registers, 2 blocks/CU", "3x3 layers with 128 channels (stage 3)"),
     ("c3_kernel", "conv_c3.hip", "4x32 px x 64 filters, 4 waves, filter (72 KiB) in registers, 72 KiB LDS, 2 blocks/CU", "3x3 layers with 64 channels (stage 2)"),
