@@ -65,6 +65,7 @@ int         urso_abi_version(void);           /* bumped on any signature or data
  *   c3 (1)            register-resident-filter kernels (conv_c3.hip) for 3x3 stride-1 layers: 64 channels / filters always, 128 / 128
  *                     where the 4 x 32 tiles cover the image to >= 88 % (else the halo kernel); 2: only the 64-channel form, 3: both always
  *   stem (1)          conv_stem.hip for the packed 7x7 / stride-2 stem (0: the DMA kernel's one-copy-per-tap form)
+ *   stem_pool (1)     urso_stem_conv_pool available (0: callers run urso_conv_igemm + urso_maxpool3x3s2_fwd)
  *   cus (0)           > 0: the CUs the persistent conv grids, the weight-gradient split and their workspaces are planned for (whole XCD
  *                     rows of 8; 0 = all of the device's).  A data-parallel host sets it to (CUs - what the collective's resident
  *                     workgroups hold) BEFORE it plans a step, so that a CU held by RCCL never gives a statically partitioned tile
@@ -417,6 +418,15 @@ int urso_mold_images(int B, int H, int W, int src_is_u8, const void* src_d, cons
  * written or read.  16-bit dtypes; workspace: urso_conv_wgrad_ws_bytes(g, dt). */
 int urso_stem_wgrad_pooled(const urso_conv_geom* g, int dt, const void* x_d, const void* dpool_d, const uint8_t* argmax_d,
                            void* ws_d, size_t ws_bytes, float* dw_raw_d, float* colsum_d, void* stream);
+/* conv1 + bn_conv1 (folded) + ReLU + MaxPooling2D((3,3), strides 2, "same") in one kernel (net.py:170-176; conv_stem.hip
+ * stem_pool_kernel): g is the packed stem geometry of urso_conv_igemm (x_d = urso_mold_images output, wgt_d / bias_d =
+ * urso_stem_weight_pack output), y_d the POOLED tensor [B][OH/2][OW/2][64] and argmax_d its bytes in the urso_maxpool3x3s2_fwd
+ * format.  Same values and arg-max bytes as urso_conv_igemm(URSO_EPI_RELU) followed by urso_maxpool3x3s2_fwd, but conv1's output --
+ * the largest tensor of the net -- is never written or read.  16-bit dtypes, OH and OW even; urso_stem_conv_pool_ok says whether
+ * the geometry qualifies (options stem, stem_pool). */
+int urso_stem_conv_pool_ok(const urso_conv_geom* g, int dt);
+int urso_stem_conv_pool(const urso_conv_geom* g, int dt, const void* x_d, const void* wgt_d, const float* bias_d, void* y_d,
+                        uint8_t* argmax_d, void* stream);
 /* MaxPooling2D((3,3), strides=(2,2), padding="same") (net.py:176,258), H,W even.
  * fwd also stores one byte per output element: the arg-max tap (first maximum in row-major window order, 0..8) in bits 0-3 and,
  * in bit 4, whether the window maximum is <= 0.

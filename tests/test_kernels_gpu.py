@@ -413,6 +413,15 @@ def _stem_case(hip, dt, B, H, W, N):
         pooled = torch.empty(B, PH, PW, N, dtype=hip.TORCH_DT[dt], device="cuda")
         am = torch.empty(B, PH, PW, N, dtype=torch.uint8, device="cuda")
         hip.maxpool_fwd(B, OH, OW, N, dt, y, pooled, am)
+        if hip.stem_conv_pool_ok(g, dt):
+            # conv1 + ReLU + max-pool in one kernel (urso_stem_conv_pool): the pooled tensor and its arg-max bytes, bit for bit
+            pooled2 = torch.full_like(pooled, float("nan")); am2 = torch.full_like(am, 255)
+            hip.stem_conv_pool(g, dt, molded, wf, biasf, pooled2, am2)
+            torch.cuda.synchronize()
+            assert torch.equal(pooled2.float(), pooled.float()), "fused stem + pool: %d values differ" % int((pooled2.float() != pooled.float()).sum())
+            assert torch.equal(am2, am), "fused stem + pool: %d arg-max bytes differ" % int((am2 != am).sum())
+        else:
+            assert (OH | OW) & 1, "urso_stem_conv_pool_ok refused an even conv grid"
         dpool = dev(rnd(torch.randn(B, PH, PW, N), dt), dt)
         dzp = torch.empty(B, OH, OW, N, dtype=hip.TORCH_DT[dt], device="cuda")
         hip.maxpool_bwd(B, OH, OW, N, dt, pooled, dpool, am, 1, dzp)

@@ -65,6 +65,10 @@ class ReluDecisions(object):
             self.flips += nd
             self.total += diff.numel() // 4
             return m
+        if getattr(c.dst, "fused_pool", False):
+            # conv1 inside urso_stem_conv_pool: its output exists only pooled.  The oracle keeps its own decisions here; a decision that differs
+            # concerns a value within rounding of zero, which the max-pool behind it forwards only if the whole window is that small
+            return x.detach() > 0
         dev_act = c.dst.data.float().cpu().view(B, -1)[:, :n.dst.h * n.dst.w * c.npad]
         if x.dim() == 4:
             m = (dev_act.view(B, n.dst.h, n.dst.w, c.npad)[..., :n.cout] > 0).permute(0, 3, 1, 2)

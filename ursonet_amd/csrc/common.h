@@ -31,6 +31,7 @@ struct UrsoOptions {
     int pair = 1;            // conv_pair.hip: fused pointwise pairs of stages 2-3 (read by the host plan, ursonet_amd/engine.py)
     int c3 = 1;              // conv_c3.hip (register-resident 3x3 filter) for 64-channel / 64-filter 3x3 layers
     int stem = 1;            // conv_stem.hip (im2col on the LDS read side) for the packed 7x7 stem
+    int stem_pool = 1;       // conv1 + ReLU + max-pool in one kernel (urso_stem_conv_pool); 0: the engine runs the two kernels
     int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);
                              // ursonet_amd/dp.py leaves the rest to the collective's resident workgroups.  0 = all of the device's
     int hconv2 = 1;          // conv_halo2.hip (whole tiles of a per-layer shape, no hand-over): 0 off, 1 where its cost model beats conv_halo.hip's schedule, 2 whenever a shape fits

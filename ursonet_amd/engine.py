@@ -217,8 +217,11 @@ class Engine(object):
         max_igemm_ws = 0
         max_bn_ws = 0
         descs = []                                 # hip.ParamDesc of every non-stem weight layer
+        self._fused_pools = {}                     # id(pool node) -> the stem conv whose kernel also pools
         for node in g.nodes:
             if node.op == "pool":
+                if id(node) in self._fused_pools:      # computed by the stem's own kernel (urso_stem_conv_pool): no launch, no conv1 output
+                    continue
                 src, dst = act(node.src), act(node.dst)
                 am = torch.empty(dst.numel, dtype=torch.uint8, device=dev)
                 h, w, c = node.src.h, node.src.w, node.src.c
@@ -365,6 +368,18 @@ class Engine(object):
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_winograd_fwd(c.gf, dt, f, c.xin, c.wf, c.biasf, c.dst.data, self.wino_ws))
                 self.labels["fwd"].append("fwd:" + node.name)
                 c.winograd = True
+            elif self._stem_pool_node(g, node, c, dt) is not None:
+                # conv1 + ReLU + the max-pool behind it in one kernel: conv1's output (the largest tensor of the net, read by the pool
+                # alone) is neither written nor read; its _Act keeps no storage
+                pool = self._stem_pool_node(g, node, c, dt)
+                self._fused_pools[id(pool)] = c
+                pdst = act(pool.dst)
+                pool._am = torch.empty(pdst.numel, dtype=torch.uint8, device=dev)
+                c.dst.data = torch.empty(0, dtype=self.tdt, device=dev)
+                c.dst.fused_pool = True
+                c.fwd_index = len(self.fwd_ops)
+                self.fwd_ops.append(lambda c=c, d=pdst, am=pool._am: hip.stem_conv_pool(c.gf, dt, c.xin, c.wf, c.biasf, d.data, am))
+                self.labels["fwd"].append("fwd:%s+maxpool" % node.name)
             else:
                 c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, f=flags: hip.conv_igemm_ex(
@@ -998,6 +1013,18 @@ class Engine(object):
         self.fwd_ops[idx[0]] = (lambda P=P, gs=gs: hip.conv_igemm_ex(gs, self.dt, P.fwd_flags, P.xin, P.wf, P.biasf, None, None, P.dst.data, None, None))
         self.labels["fwd"][idx[0]] = "fwd:%s@sampled" % P.name
         Y.fwd_scattered = True
+
+    def _stem_pool_node(self, g, node, c, dt):
+        """The pool node the stem's kernel can compute as well (urso_stem_conv_pool), or None: the stem with its ReLU and a folded BN,
+        read by nothing but ONE max-pool, in a 16-bit dtype on a geometry the kernel takes."""
+        if not node.stem or not node.relu or c.batch_bn or c.res is not None or node.out_f32 or dt == hip.F32:
+            return None
+        if any(t.id == node.dst.id for t in g.outputs.values()) or (g.feat is not None and getattr(g.feat, "id", None) == node.dst.id):
+            return None
+        users = [n for n in g.nodes if n is not node and (n.src.id == node.dst.id or (n.op == "conv" and n.residual is not None and n.residual.id == node.dst.id))]
+        if len(users) != 1 or users[0].op != "pool" or not hip.stem_conv_pool_ok(c.gf, dt):
+            return None
+        return users[0]
 
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly

@@ -137,6 +137,8 @@ _SIGS = {
     "urso_conv_dgrad_wgrad_pw": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _i, _vp, _fp, _fp, _sz, _vp]),
     "urso_conv_pair_wgrad_entry": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _fp, _fp, _fp, _fp, _sz, _vp]),
     "urso_stem_wgrad_pooled": (_i, [_gp, _i, _vp, _vp, _vp, _vp, _sz, _fp, _fp, _vp]),
+    "urso_stem_conv_pool_ok": (_i, [_gp, _i]),
+    "urso_stem_conv_pool": (_i, [_gp, _i, _vp, _vp, _fp, _vp, _vp, _vp]),
     "urso_conv_pair_wgrad_splits": (_i, [C.c_longlong, _i]),
     "urso_conv_pair_wgrad": (_i, [C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _sz, _vp]),
     "urso_conv_pointwise_sampled_ok": (_i, [_gp, _i, _i, _i]),
@@ -169,7 +171,7 @@ def _chk(rc, what):
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "stem", "cus")
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "stem", "stem_pool", "cus")
 
 
 def set_option(name, value):
@@ -549,6 +551,16 @@ def conv_pair_wgrad_entry(M, dt, src, w1, add, bits, w2, u, dst, ws, xin, mask_b
     _chk(_lib.urso_conv_pair_wgrad_entry(int(M), dt, ptr(src), ptr(w1), ptr(add), ptr(bits), ptr(w2), ptr(u), ptr(dst), ptr(ws), ptr(xin), int(bool(mask_by_xin)), ptr(dxin),
                                          ptr(part), ptr(colpart), ptr(part_s), ptr(colpart_s), int(part_stride), stream_ptr(stream)),
          "urso_conv_pair_wgrad_entry")
+
+
+def stem_conv_pool_ok(g, dt):
+    """urso_stem_conv_pool_ok: does the packed stem geometry qualify for the fused conv1 + ReLU + max-pool kernel?"""
+    return bool(_lib.urso_stem_conv_pool_ok(C.byref(g), dt))
+
+
+def stem_conv_pool(g, dt, x, wf, bias, y_pooled, argmax, stream=None):
+    """urso_stem_conv_pool: conv1 + ReLU + 3x3/s2 max-pool in one kernel; y_pooled [B][OH/2][OW/2][64], argmax its bytes."""
+    _chk(_lib.urso_stem_conv_pool(C.byref(g), dt, ptr(x), ptr(wf), ptr(bias), ptr(y_pooled), ptr(argmax), stream_ptr(stream)), "urso_stem_conv_pool")
 
 
 def stem_wgrad_pooled(g, dt, x, dpool, argmax, ws, dw_raw, colsum, stream=None):
