@@ -1,6 +1,6 @@
 """A/B: conv1 (stem_kernel) + maxpool_fwd_kernel vs the fused stem_pool_kernel at a bench geometry; HIP-event times, cold-ish (other tensors touched between)."""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ursonet_amd import hip
 B, H, W = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 512, 640)))
 dt = hip.BF16; N = 64

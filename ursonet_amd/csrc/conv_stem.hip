@@ -208,17 +208,23 @@ int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src,
 // (335 MB at cfg2) is the largest tensor of the net and its only reader is the pool -- written by stem_kernel (87 us, HBM write-bound) and
 // read back 1.45x by maxpool_fwd_kernel (117 us).  Here it never leaves the registers:
 //   * tile = 17 x 32 conv outputs -> 8 x 15 pooled outputs; tiles advance by 16 conv rows / 30 conv columns, i.e. the row and the two
-//     columns a window shares with the next tile are recomputed (MFMA work x 1.13 x 1.07; the kernel is VALU-bound, not MFMA-bound);
+//     columns a window shares with the next tile are recomputed (MFMA work x 1.13 x 1.07);
 //   * wave (cw, pw) = filters 32 cw .. + 32 x conv rows 8 pw .. 8 pw + 8 of the tile (nine rows: pooled rows 4 pw .. 4 pw + 3), computed
 //     as three register groups of three rows with the patch-row fragment reuse of stem_kernel;
 //   * pooling works on integer KEYS: key = (16-bit value << 16) | priority, priority = 8 - (3 ky + kx) of the window tap the element
 //     would be.  For values >= 0 the 16-bit float patterns order like integers, so a signed max over the nine keys of a window is the
 //     window maximum AND its FIRST arg-max (the strict `>` scan of maxpool_fwd_kernel) in one v_max; negative values give negative keys
-//     and the ReLU is the final clamp max(key, 8).  The column neighbours come over DPP wave_shl:1 fused into v_max_i32 (lane = conv
-//     column), the row neighbours are other registers of the same lane: T(odd l) = max(A(l), B(l+1)), key(even l) = max(A(l), T(l+1)),
-//     window = max3(row 2p + 6, row 2p+1 (its +3 folded into A), row 2p+2);
+//     and the ReLU is the final clamp max(key, 8).  Rows first: the three conv rows of a pooled row are other registers of the same lane
+//     (max3 of row 2p + 6, row 2p+1 with its +3 built in, row 2p+2); then the column neighbours over DPP wave_shl:1 fused into v_max_i32
+//     (lane = conv column): T(odd l) = max(P(l), P(l+1)), window(even l) = max(P(l) + 2, T(l+1)); filters 8..15 then move into the idle odd
+//     lanes so that the packing runs on 8 registers with every lane at work;
 //   * columns past the image start from a bias of -3e38 (never the maximum: the window's top-left tap is always inside), rows past it
 //     get negative keys; the 8 x 15 pooled tile and its arg-max bytes go through LDS to row-contiguous 16-byte stores.
+// Measured (cfg2, profiles/r04_stem_pool.txt): 99-105 us against 222 us for the two kernels.  Per SIMD the 126 MFMAs (x 32 clk) and the ~1070 other
+// VALU instructions (x 3.5-4 clk) of a wave-tile ADD UP to the kernel time (SQ_VALU_MFMA_BUSY 49 % + VALU issue 58 % of the SIMD cycles): on this
+// part an MFMA in flight does not hide another wave's VALU work, so issuing the pooling between the MFMAs of the next row group (tried:
+// same time at two blocks per CU) buys nothing and what counts is the instruction count -- rows before columns (the column maximum runs on 4
+// pooled rows instead of 9 conv rows) and the odd-lane merge took it from 1660 to 1070.
 // Output bit-identical to urso_conv_igemm(stem) + urso_maxpool3x3s2_fwd (value and arg-max byte; a -0 the two-kernel path can store is +0).
 struct StempArgs {
     const void* src; const void* wgt; const float* bias; void* dst; uint8_t* am;
@@ -311,9 +317,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StempArgs a) {
     }
     if (tid < 64) *(float*)(smem + SP_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
 
-    // key priorities: even conv rows carry 2 - kx (this lane's own tap: kx = lane & 1), odd rows 3 more (ky = 1); the kx = 2 role of an even lane is A - 2
-    const int cA = 2 - (l31 & 1), cA3 = cA + 3;
-    const bool emit_lane = !(l31 & 1) && l31 < 2 * SP_PC;
+    // key priorities: 6 - 3 ky (added when the row takes its role) + 2 - kx; built with the lane's kx = 2 / kx = 1 role (even lanes 0, odd 1),
+    // an even lane's own kx = 0 role is + 2
+    const int cL = l31 & 1;
+    const bool odd_lane = l31 & 1, emit_lane = l31 < 2 * SP_PC;
 
     constexpr int NST = 6;
     dma_tile(tile, 0);
@@ -344,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StempArgs a) {
         }
         asm volatile("" : "+v"(l31));
 
-        // conv rows base .. base + NR - 1 of the wave -> keys hk[r][e] (horizontal maximum of the window starting at this lane's column)
-        auto conv_rows = [&](auto nr_c, int base, int (&hk)[decltype(nr_c)::value][16]) {
+        // conv rows base .. base + NR - 1 of the wave -> keys K[r][e] = (16-bit value << 16) | row priority | lane parity
+        auto conv_rows = [&](auto nr_c, int base, int (&K)[decltype(nr_c)::value][16]) {
             constexpr int NR = decltype(nr_c)::value, NS = 2 * (2 * NR + 5);
             f32x16_t acc[NR];
             const char* sW = sA + (2 * (8 * pw + base)) * ST_PROW_B + l31 * 16 + h * 16;
@@ -369,71 +376,77 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StempArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                // a conv row below the image (wave-uniform) gets the sign bit: negative keys are never the maximum
-                const int c = (((base + r) & 1) ? cA3 : cA) | (cy0 + base + r >= a.OH ? (int)0x80000000 : 0);
+                // odd rows are window row ky = 1 (+3); a conv row below the image (wave-uniform) gets the sign bit: negative keys never win
+                const int c = (((base + r) & 1) ? cL + 3 : cL) | (cy0 + base + r >= a.OH ? (int)0x80000000 : 0);
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const uint32_t p = sp_pack2<T>(acc[r][e], acc[r][e + 1]);
-                    const int A0 = (int)((p << 16) | (uint32_t)c), A1 = (int)((p & 0xFFFF0000u) | (uint32_t)c);
-                    const int T0 = sp_max(A0, sp_next_lane(A0 - 2)), T1 = sp_max(A1, sp_next_lane(A1 - 2));
-                    hk[r][e] = sp_max(A0, sp_next_lane(T0));
-                    hk[r][e + 1] = sp_max(A1, sp_next_lane(T1));
+                    K[r][e] = (int)((p << 16) | (uint32_t)c);
+                    K[r][e + 1] = (int)((p & 0xFFFF0000u) | (uint32_t)c);
                 }
             }
         };
-        // pooled row p of the wave: the keys of its 16 filters -> values + arg-max bytes in the LDS tile
-        auto emit = [&](int p, const int (&k)[16]) {
-            const int prow = 4 * pw + p, pcol = l31 >> 1;
-            char* sO = smem + SP_OOFF + (prow * 16 + pcol) * 128;
-            char* sM = smem + SP_MOFF + (prow * 16 + pcol) * 64 + 32 * cw + 16 * h;
+        // pooled row p of the wave from the column maxima P[e] (per lane = conv column; priorities 6 - 3 ky + (odd lane: 1)): the window
+        // maximum over kx at the even lanes, filters 8..15 moved into the odd lanes beside filters 0..7, then values + arg-max bytes
+        auto pool_out = [&](int p, const int (&P)[16]) {
+            int w[16];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                int kk[8];
+            for (int e = 0; e < 16; ++e) {
+                const int Tn = sp_max(P[e], sp_next_lane(P[e]));                              // odd lanes: max(kx = 1 (own), kx = 2 (next lane))
+                w[e] = sp_max(P[e] + 2, sp_next_lane(Tn));                                    // even lanes: max(kx = 0 (own, +2), the odd lane's)
+            }
+            int kk[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) kk[e] = sp_max(k[8 * v + e], 8);                 // the ReLU: all-negative windows -> value 0, first tap
-                i32x4_t ov;
+            for (int j = 0; j < 8; ++j) {
+                const int up = __builtin_amdgcn_update_dpp(0, w[8 + j], 0xA0 /* quad_perm:[0,0,2,2] */, 0xf, 0xf, true);
+                kk[j] = sp_max(odd_lane ? up : w[j], 8);                                      // the ReLU: all-negative windows -> value 0, first tap
+            }
+            const int prow = 4 * pw + p, pcol = l31 >> 1, v = l31 & 1;
+            i32x4_t ov;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (int)__builtin_amdgcn_perm((uint32_t)kk[2 * j + 1], (uint32_t)kk[2 * j], 0x07060302u);
-                uint32_t ab[2] = {0u, 0u};
+            for (int j = 0; j < 4; ++j) ov[j] = (int)__builtin_amdgcn_perm((uint32_t)kk[2 * j + 1], (uint32_t)kk[2 * j], 0x07060302u);
+            uint32_t ab[2] = {0u, 0u};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t byte = (uint32_t)((kk[e] > 0xFFFF ? 8 : 24) - (kk[e] & 15));  // tap 8 - priority; bit 4: window maximum <= 0
-                    ab[e >> 2] |= byte << (8 * (e & 3));
-                }
-                if (emit_lane) {
-                    *(i32x4_t*)(sO + (((4 * cw + 2 * h + v) ^ (pcol & 7)) << 4)) = ov;
-                    *(uint2*)(sM + 8 * v) = make_uint2(ab[0], ab[1]);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t byte = (uint32_t)((kk[e] > 0xFFFF ? 8 : 24) - (kk[e] & 15));      // tap 8 - priority; bit 4: window maximum <= 0
+                ab[e >> 2] |= byte << (8 * (e & 3));
+            }
+            if (emit_lane) {
+                *(i32x4_t*)(smem + SP_OOFF + (prow * 16 + pcol) * 128 + (((4 * cw + 2 * h + v) ^ (pcol & 7)) << 4)) = ov;
+                *(uint2*)(smem + SP_MOFF + (prow * 16 + pcol) * 64 + 32 * cw + 16 * h + 8 * v) = make_uint2(ab[0], ab[1]);
             }
         };
 
-        // three groups of three conv rows: pooled row 0 = rows 0-2, 1 = rows 2-4, 2 = rows 4-6, 3 = rows 6-8; one 16-register carry between groups
-        int carry[16], k[16];
         {
-            int hk[3][16];
-            conv_rows(std::integral_constant<int, 3>{}, 0, hk);
+        // three groups of three conv rows: pooled row 0 = rows 0-2, 1 = rows 2-4, 2 = rows 4-6, 3 = rows 6-8; the row maximum first (same
+        // lane, other registers), one 16-register carry between groups
+        int carry[16], P[16];
+        {
+            int K[3][16];
+            conv_rows(std::integral_constant<int, 3>{}, 0, K);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { k[e] = sp_max(sp_max(hk[0][e] + 6, hk[1][e]), hk[2][e]); carry[e] = hk[2][e] + 6; }
-            emit(0, k);
+            for (int e = 0; e < 16; ++e) { P[e] = sp_max(sp_max(K[0][e] + 6, K[1][e]), K[2][e]); carry[e] = K[2][e] + 6; }
+            pool_out(0, P);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            int hk[3][16];
-            conv_rows(std::integral_constant<int, 3>{}, 3, hk);
+            int K[3][16];
+            conv_rows(std::integral_constant<int, 3>{}, 3, K);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { k[e] = sp_max(sp_max(carry[e], hk[0][e]), hk[1][e]); carry[e] = sp_max(hk[1][e] + 6, hk[2][e]); }
-            emit(1, k);
+            for (int e = 0; e < 16; ++e) { P[e] = sp_max(sp_max(carry[e], K[0][e]), K[1][e]); carry[e] = sp_max(K[1][e] + 6, K[2][e]); }
+            pool_out(1, P);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            int hk[3][16];
-            conv_rows(std::integral_constant<int, 3>{}, 6, hk);
+            int K[3][16];
+            conv_rows(std::integral_constant<int, 3>{}, 6, K);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) k[e] = sp_max(carry[e], hk[0][e]);
-            emit(2, k);
+            for (int e = 0; e < 16; ++e) P[e] = sp_max(carry[e], K[0][e]);
+            pool_out(2, P);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) k[e] = sp_max(sp_max(hk[0][e] + 6, hk[1][e]), hk[2][e]);
-            emit(3, k);
+            for (int e = 0; e < 16; ++e) P[e] = sp_max(sp_max(K[0][e] + 6, K[1][e]), K[2][e]);
+            pool_out(3, P);
+        }
         }
         st_barrier();
         // ---- the pooled tile -> row-contiguous 16-byte stores: values [8][16 (15 used)][8 chunks], arg-max bytes [8][16][4 chunks]
