@@ -13,6 +13,10 @@
 // Same operand layouts and k order conventions as urso_conv_igemm (weights [N][K] as urso_conv_weight_prep writes them).
 #include "common.h"
 
+#ifndef URSO_DENSE_UN
+#define URSO_DENSE_UN 4
+#endif
+
 struct DnArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst;
     uint32_t src_bytes, wgt_bytes, dst_bytes;
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(512) void dense_kernel(const DnArgs a) {
     // lane (fr, fg): weight row n0 + fr, activation rows fr and 16 + fr, the 8 k starting at 32 slab + 8 fg
     const bool wok = n0 + fr < a.N, a0ok = fr < a.M, a1ok = 16 + fr < a.M;
     const uint32_t wrow = (uint32_t)(n0 + fr) * (uint32_t)a.K * 2u, arow0 = (uint32_t)fr * (uint32_t)a.K * 2u, arow1 = (uint32_t)(16 + fr) * (uint32_t)a.K * 2u;
-    constexpr int UN = 4;
+    constexpr int UN = URSO_DENSE_UN;                         // slabs of loads in flight per wave (3 x 16 B per lane each)
     for (int s0 = wave; s0 < nslabs; s0 += 8 * UN) {
         i32x4_t fw[UN], fa0[UN], fa1[UN];
 #pragma unroll
