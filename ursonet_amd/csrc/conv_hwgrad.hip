@@ -18,6 +18,7 @@
 //     fastest, so the blocks that share a pixel range (all groups of a split) sit behind one L2.
 // Copies per layer: groups x pixels x 256 B x (1 + halo) -- 3.5x fewer than before at stage 4.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef short hw_s16x4_t __attribute__((ext_vector_type(4)));
@@ -202,20 +203,24 @@ __device__ __forceinline__ void hwgrad_body(const HwgArgs& a, const int bid, con
     const int tap0 = tg == 0 ? 0 : 5;
     const bool csum = tg == 1 && ct == 0 && cg == 0;
 
-    int tile = t0;
-    if (tile < t1) { tile_offs(0); dma_tile(0); tile_offs(1); }
-    int buf = 0;
-    for (; tile < t1; ++tile, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's copies (requested one tile ago); nothing younger is in flight
-        __syncthreads();                                       // ... every wave's have landed, and every wave is done with the other stage
-        if (tile + 1 < t1 && !(a.dbg & 2)) dma_tile(buf ^ 1);
-        const char* st = smem + buf * HW_STAGE;
-        if (!(a.dbg & 1)) {
-            if (tg == 0) hw_tile<T, 0>(st, acc, zoff, abase, false);
-            else hw_tile<T, 1>(st, acc, zoff, abase, csum);
+    if (t0 < t1) { tile_offs(0); dma_tile(0); tile_offs(1); }
+    // ONE tile loop per tap group.  With a single loop that branches to hw_tile<0> / hw_tile<1> inside, hipcc gives the two bodies different
+    // registers for the 80 loop-carried accumulators and copies them back after every tile (80 v_mov behind the tile's last MFMA, i.e. behind
+    // its whole pipeline latency: 4.9 VALU instructions per MFMA in the PMC counts, all of them these copies)
+    auto run_tiles = [&](auto tg_c) {
+        constexpr int TG = decltype(tg_c)::value;
+        int buf = 0;
+        for (int tile = t0; tile < t1; ++tile, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's copies (requested one tile ago); nothing younger is in flight
+            __syncthreads();                                   // ... every wave's have landed, and every wave is done with the other stage
+            if (tile + 1 < t1 && !(a.dbg & 2)) dma_tile(buf ^ 1);
+            const char* st = smem + buf * HW_STAGE;
+            if (!(a.dbg & 1)) hw_tile<T, TG>(st, acc, zoff, abase, TG == 1 && csum);
+            tile_offs(tile - t0 + 2);                          // (past the block's range: clamped, never issued)
         }
-        tile_offs(tile - t0 + 2);                              // (past the block's range: clamped, never issued)
-    }
+    };
+    if (tg == 0) run_tiles(std::integral_constant<int, 0>{});
+    else run_tiles(std::integral_constant<int, 1>{});
 
     // this block's part of split sp's partial: rows k = C tap + 64 cg + 32 ct + (r & 3) + 8 (r >> 2) + 4 h, columns 64 ng + 32 nt + l31
     float* part = a.part + (size_t)sp * a.part_stride;

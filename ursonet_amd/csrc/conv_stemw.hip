@@ -23,6 +23,7 @@
 // tile in LDS is bit for bit what that kernel would have written -- and the weight gradient proceeds as above.  The gradient of conv1's
 // output (335 MB at cfg2) is then neither written by the pool's backward pass nor read here, and that launch disappears.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef short sw_s16x4_t __attribute__((ext_vector_type(4)));
@@ -103,6 +104,11 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     const i32x4_t ones = {SwMma<T>::ONES, SwMma<T>::ONES, SwMma<T>::ONES, SwMma<T>::ONES};
 
+    // ONE tile loop per window-row group ks (the waves of a group never meet the other group's code): with `ks` tested inside the reduction
+    // loop hipcc kept acc[3] of the two arms in different registers and copied it back behind EVERY step -- 16 register moves behind an
+    // `s_nop 11` that waits out the whole MFMA pipeline (tools/loop_movs.py)
+    auto run_tiles = [&](auto ks_c) {
+    constexpr int KS = decltype(ks_c)::value;
     for (int tile = xcd * cpx + lb; tile < t_end; tile += bpx) {
         const int tx = tile % a.tiles_x, tq = tile / a.tiles_x;
         const int ty = tq % a.tiles_y, b = tq / a.tiles_y;
@@ -206,17 +212,20 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void stemw_kernel(const StemwA
             const uint32_t zb = (uint32_t)((32 * ry + 16 * hs) * 128);
             const i32x2_t zl = sw_tr16(smem + zoff[0] + zb), zh = sw_tr16(smem + zoff[1] + zb);
             const i32x4_t fz = i32x4_t{zl.x, zl.y, zh.x, zh.y};
-            const uint32_t ab = (uint32_t)((2 * ry + ks) * SW_PROW_B + 16 * hs * 16) + aoff;
+            const uint32_t ab = (uint32_t)((2 * ry + KS) * SW_PROW_B + 16 * hs * 16) + aoff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i == 3 && ks == 1) { SwMma<T>::run(ones, fz, acc[3]); continue; }          // ky = 7 does not exist: the column sums
-                const uint32_t ap = ab + (uint32_t)(2 * i * SW_PROW_B);                      // window row ky = ks + 2 i
+                if (i == 3 && KS == 1) { SwMma<T>::run(ones, fz, acc[3]); continue; }          // ky = 7 does not exist: the column sums
+                const uint32_t ap = ab + (uint32_t)(2 * i * SW_PROW_B);                      // window row ky = KS + 2 i
                 const i32x2_t al = sw_tr16(smem + ap), ah = sw_tr16(smem + ap + 64);
                 SwMma<T>::run(i32x4_t{al.x, al.y, ah.x, ah.y}, fz, acc[i]);
             }
         }
         __syncthreads();                                       // every wave is done with the tiles before the next copies land
     }
+    };
+    if (ks == 0) run_tiles(std::integral_constant<int, 0>{});
+    else run_tiles(std::integral_constant<int, 1>{});
 
     // ---- this block's partial (zero for a block without tiles): rows k = 32 ky + (r & 3) + 8 (r >> 2) + 4 h, columns 32 nh + l31
     float* part = a.part + (size_t)blockIdx.x * a.part_stride;
