@@ -371,6 +371,23 @@ def test_stem_pixel_pair_conv(dt, size):
             _stem_case(hip, dt, B, H, W, N)
 
 
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 5, 7), (3, 36, 44)], ids=["quads", "ragged", "quads2"])
+def test_mold_images_float_source(dt, shape):
+    """urso_mold_images on a float32 source (what Engine.load_batch hands over), with and without a mean: [B,H,W,3] -> [B,H,W,4] in dt with a
+    zero fourth channel.  Pixel counts that are multiples of 4 take the four-pixels-per-thread kernel, the others the scalar one."""
+    hip = _hip()
+    B, H, W = shape
+    torch.manual_seed(5)
+    src = (torch.rand(B, H, W, 3) * 255 - 120).cuda()
+    for mean in (None, torch.tensor([123.7, 116.8, 103.9]).cuda()):
+        out = torch.full((B, H, W, 4), 7.0, dtype=hip.TORCH_DT[dt], device="cuda")
+        hip.mold_images(B, H, W, src, mean, dt, out)
+        torch.cuda.synchronize()
+        ref = src if mean is None else src - mean
+        assert torch.equal(out[..., :3].float(), ref.to(hip.TORCH_DT[dt]).float()) and float(out[..., 3].float().abs().max()) == 0.0
+
+
 def _stem_case(hip, dt, B, H, W, N):
     torch.manual_seed(7)
     img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
