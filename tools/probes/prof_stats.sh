@@ -1,8 +1,8 @@
-# rocprofv3 kernel stats of a short bench run: per-kernel average durations (us) of the families named in $1 (regex)
+# rocprofv3 kernel stats of a short bench run: per-kernel average durations (us) of the families named in $1 (regex); $2 = URSO_LIB_VARIANT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/ps
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 > /tmp/ps_bench.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- env URSO_LIB_VARIANT=${2:-} python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-steps 0 > /tmp/ps_bench.txt 2>&1
 tail -1 /tmp/ps_bench.txt | python -c "
 import sys,json
 try:
