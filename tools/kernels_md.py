@@ -24,7 +24,7 @@ FAMILIES = [
     ("pairx_kernel", "conv_pairx.hip", "all 160 KiB of LDS in two rings", "backward launch behind stage 2's first block (pair + 2 weight gradients + shortcut)"),
     ("pair_kernel", "conv_pair.hip", "64 / 32-px tiles, 4 / 8 waves, both filter matrices in registers, 80-144 KiB LDS", "fused pointwise pairs of stages 2-3; single c -> 4c layers of stages 2-5"),
     ("stemw_kernel", "conv_stemw.hip", "8x32 output px, 4 waves, un-pool in LDS", "7x7 stem weight gradient (+ max-pool backward)"),
-    ("stem_pool_kernel", "conv_stem.hip", "17x32 conv px -> 8x15 pooled px x 64 filters per tile (stride 16x30), 4 waves, filters in registers, pooling on integer keys (value | tap priority): row max in registers, column max over DPP wave_shl", "7x7 / stride-2 stem + ReLU + 3x3/s2 max-pool (conv1 output never written)"),
+    ("stem_pool_kernel", "conv_stem.hip", "17x32 conv px -> 8x15 pooled px x 64 filters per tile (stride 16x30), 4 waves, filters in registers, pooling on integer keys (value over tap priority): row max in registers, column max over DPP wave_shl", "7x7 / stride-2 stem + ReLU + 3x3/s2 max-pool (conv1 output never written)"),
     ("stem_kernel", "conv_stem.hip", "8x32 output px x 64 filters, 4 waves, filters in registers", "7x7 / stride-2 stem"),
     ("wgrad_group_big_kernel", "conv_wgrad.hip", "256 (k) x 256 (n) tile, 8 waves (128 x 64 wave tiles), 4-stage ring of 32-pixel steps 128 KiB, 1 block/CU, over a device table of layers: up to 8 layers per launch, 1/n of the splits each", "weight gradients of consecutive wide layers (>= 256 channels and filters) of a bucket, grouped"),
     ("wgrad_group_kernel", "conv_wgrad.hip", "the 128 x 128 body of wgrad_tr_kernel over a device table of layers: up to 8 layers per launch, 512 blocks shared, 1/n of the splits each", "weight gradients of consecutive 1x1 / strided layers of a bucket, grouped"),
