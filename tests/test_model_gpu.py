@@ -66,9 +66,32 @@ class ReluDecisions(object):
             self.total += diff.numel() // 4
             return m
         if getattr(c.dst, "fused_pool", False):
-            # conv1 inside urso_stem_conv_pool: its output exists only pooled.  The oracle keeps its own decisions here; a decision that differs
-            # concerns a value within rounding of zero, which the max-pool behind it forwards only if the whole window is that small
-            return x.detach() > 0
+            # conv1 inside urso_stem_conv_pool: its output exists only pooled, but every decision anything depends on is in the pool's arg-max
+            # bytes -- byte = 3 ky + kx of the window's first maximum, + 16 when that maximum is <= 0 (conv_stem.hip) -- i.e. per pooled
+            # pixel WHICH conv output the device forwarded and what its ReLU decided.  Those decisions are compared and forced like any
+            # other layer's; a conv output that wins no window feeds nothing, forward or backward, and keeps the oracle's own decision.
+            pool = [nn for nn in self.eng.graph.nodes if nn.op == "pool" and nn.src.id == n.dst.id][0]
+            am = pool._am.cpu().view(B, pool.dst.h, pool.dst.w, pool.dst.c).permute(0, 3, 1, 2).long()
+            pos = am < 16
+            k = am & 15
+            assert int(k.max()) <= 8
+            ii = torch.arange(pool.dst.h).view(1, 1, -1, 1) * 2 + k // 3          # 'same' on an even grid pads below / right only: window rows 2i .. 2i+2
+            jj = torch.arange(pool.dst.w).view(1, 1, 1, -1) * 2 + k % 3
+            assert int(ii.max()) < n.dst.h and int(jj.max()) < n.dst.w, "an arg-max points into the padding"
+            xd = x.detach()
+            m = (xd > 0).clone()
+            bb = torch.arange(B).view(-1, 1, 1, 1).expand_as(am)
+            cc = torch.arange(pool.dst.c).view(1, -1, 1, 1).expand_as(am)
+            m[bb, cc, ii, jj] = pos
+            diff = m != (xd > 0)
+            nd = int(diff.sum())
+            if nd:
+                rel = (xd.abs()[diff] / (xd.abs().max() + 1e-30)).double()
+                worst = float(rel.max()); self.worst = max(self.worst, worst); self.mags.append(rel.cpu())
+                assert worst < self.tol, "ReLU decision differs at |pre-activation| = %.2e of max in %s (from the pool's arg-max bytes)" % (worst, site)
+            self.flips += nd
+            self.total += am.numel()
+            return m
         dev_act = c.dst.data.float().cpu().view(B, -1)[:, :n.dst.h * n.dst.w * c.npad]
         if x.dim() == 4:
             m = (dev_act.view(B, n.dst.h, n.dst.w, c.npad)[..., :n.cout] > 0).permute(0, 3, 1, 2)
@@ -173,7 +196,7 @@ def test_training_step_parity_fp32_multitile_stream():
         test_training_step_parity_fp32(*CASES[1])
 
 
-def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w, tol_l2=None, tol_norm=None):
+def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w, tol_l2=None, tol_norm=None, check=True):
     """Outputs, losses, every gradient tensor (relative to its max; the big ones also in the Euclidean norm), global norm, post-step
     weights; one assertion that reports all the measured errors."""
     tol_l2 = tol_g if tol_l2 is None else tol_l2
@@ -202,6 +225,8 @@ def _compare_step(eng, ref, newW, tol_out, tol_g, tol_w, tol_l2=None, tol_norm=N
     print("parity:", {k: "%.2e" % v for k, v in m.items()}, "worst grad", worst[0], "worst big grad", worst_big[0], "worst weight", worst_w[1])
     # tol_g applies to every tensor with >= 4096 elements (filters, dense kernels); the small per-channel tensors (BN gamma/beta, biases:
     # sums with cancellation over 64-2048 channels) get 3 tol_g
+    if not check:
+        return m
     ok = (m["loc"] < tol_out and m["ori"] < tol_out and m["loc_loss"] < tol_out and m["ori_loss"] < tol_out and
           m["grad_big"] < tol_g and m["grad"] < 3 * tol_g and m["grad_l2"] < tol_l2 and m["grad_norm"] < tol_norm and m["weights"] < tol_w)
     assert ok, "tolerances out %.0e grad %.0e weights %.0e exceeded: %s (worst gradient %s, worst weight %s)" % (
@@ -244,6 +269,58 @@ def test_training_step_parity_16bit_same_rounding_points(dtype, tol_out, tol_g, 
     ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
     assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
     _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3, tol_l2=0.85 * tol_g, tol_norm=tol_out)
+
+
+def test_training_step_parity_bf16_five_seeds_two_sided_gate():
+    """The bf16 whole-step comparison on FIVE data seeds with a two-sided gate.  The single-seed gate above has to
+    sit above the chaotic residue's maximum (1.2e-1 of the worst tensor's max), which a uniform 2 % scale error would pass.  Over seeds the
+    residue's MEDIAN is small -- profiles/r04_parity.txt: worst filter-gradient tensor 1.6e-2 ... 7.8e-2, median ~3e-2 -- while a systematic
+    error moves every seed: median of the worst-tensor error <= 4e-2 (max norm) and <= 3e-2 (Euclidean), median output error <= 1.2e-2,
+    and the single-seed maxima as before."""
+    from oracle import graph_ref as G
+    kw = dict(backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
+    cfg = make_config(dtype="bfloat16", **kw)
+    ms = []
+    for seed in (1, 2, 3, 4, 5):
+        img, loc, ori, _ = synthetic_batch(cfg, 2, seed=seed)
+        eng, w0 = _run_engine(cfg, img, loc, ori)
+        q = G.StorageRounding(torch.bfloat16)
+        dec = ReluDecisions(eng, tol=4e-2)
+        ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+        assert dec.flips <= 2e-3 * dec.total
+        ms.append(_compare_step(eng, ref, newW, 2.5e-2, 1.2e-1, 1e-3, tol_l2=0.85 * 1.2e-1, tol_norm=2.5e-2))
+        del eng
+    med = {k: float(np.median([m[k] for m in ms])) for k in ms[0]}
+    print("median over seeds:", {k: "%.2e" % v for k, v in med.items()})
+    log = __import__("os").environ.get("URSO_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("bf16 2x128x192 five seeds: median %s  max %s\n" % ({k: "%.2e" % v for k, v in med.items()},
+                                                                         {k: "%.2e" % max(m[k] for m in ms) for k in ms[0]}))
+    assert med["grad_big"] <= 4e-2 and med["grad_l2"] <= 3e-2 and med["loc"] <= 1.2e-2 and med["ori"] <= 1.2e-2 and med["grad_norm"] <= 1e-2, med
+
+
+def test_training_step_parity_bf16_full_benchmark_batch():
+    """ONE oracle-compared training step of the benchmark workload itself: cfg2 at batch 32 x 512 x 640, bf16 (the
+    other oracle comparisons at this width run batch 2).  About a minute of oracle time on the GPU box's host cores."""
+    from oracle import graph_ref as G
+    import os
+    torch.set_num_threads(min(os.cpu_count() or 8, 128))
+    cfg = make_config(dtype="bfloat16", backbone="resnet50", h=512, w=640, batch=32, regress_ori=False, ori_bins=16)
+    img, loc, ori, _ = synthetic_batch(cfg, 32, seed=1)
+    eng, w0 = _run_engine(cfg, img, loc, ori)
+    q = G.StorageRounding(torch.bfloat16)
+    dec = ReluDecisions(eng, tol=2e-2)
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+    assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
+    print("relu flips:", dec.flips, "of", dec.total, "worst %.2e" % dec.worst, dec.histogram())
+    m = _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3, tol_l2=2.5e-2, tol_norm=1e-2, check=False)
+    log = os.environ.get("URSO_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("bf16 cfg2 FULL batch 32x512x640: %s; relu flips %d of %d, worst %.2e %s\n"
+                    % ({k: "%.2e" % v for k, v in m.items()}, dec.flips, dec.total, dec.worst, dec.histogram()))
+    _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3, tol_l2=2.5e-2, tol_norm=1e-2)
 
 
 @pytest.mark.parametrize("pwx", [1, 2], ids=["policy", "pwx_everywhere"])
@@ -679,9 +756,9 @@ def test_fused_pointwise_pairs_change_nothing_but_the_launch_count(dtype):
     img, loc, ori, _ = synthetic_batch(cfg, 4, seed=21)
     res = []
     for pair in (1, 0):
-        with hip.options(pair=pair):
+        with hip.options(pair=pair):               # (planned AND run under the option: the engine refuses to step under another pair policy)
             eng = Engine(cfg, "training", seed=5, randomize_bn=True)
-        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+            eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((len(eng.fwd_ops), len(eng.bwd_ops), [t.float().clone() for t in eng.outputs()], eng.losses(), None,
                     sorted(eng.pair_first), sum(1 for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+" in l), list(eng.shortcut_folded),
                     sum(1 for l in eng.labels["fwd"] if l and l.endswith("@sampled")), sum(1 for l in eng.labels["fwd"] if l and l.startswith("subsample:"))))
@@ -718,7 +795,7 @@ def test_weight_gradient_folded_into_the_stage2_backward_pair(dtype):
     for pair in (1, 2):
         with hip.options(pair=pair):
             eng = Engine(cfg, "training", seed=6, randomize_bn=True)
-        eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
+            eng.load_batch(img, loc, ori); eng.step(); torch.cuda.synchronize()
         res.append((eng.flat_g.clone(), dict(eng.slices), eng.losses(), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad:") and "+wgrad:" in l],
                     sum(1 for l in eng.labels["bwd"] if l and l.startswith("wgrad:")), [l for l in eng.labels["bwd"] if l and l.startswith("dgrad+wgrad:")]))
     assert res[0][3] == ["dgrad:res2c_branch2a+res2b_branch2c+wgrad:res2b_branch2c",

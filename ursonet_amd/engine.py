@@ -701,6 +701,7 @@ class Engine(object):
                             dxin = Sc.src.grad_buf()
                             Sc.src.grad_written = True
                             dstg.zero_()                   # dL/dX never reaches memory in this form: the buffer stays what it is (zeros, not whatever the allocator left)
+                            X.grad_on_chip = True          # (tests/test_layerwise_gpu.py skips what it cannot read)
                             self.bwd_ops.append((None, lambda c=c, A=A, Sc=Sc, G=G, add=add, X=X, dst2=dst2, dxin=dxin:
                                                  hip.conv_pair_wgrad_entry(A.Mpix, dt, G, c.wd, add, X.bits, A.wd, A.src.data, dst2, Sc.wd, Sc.src.data, Sc.src.spec.relu, dxin,
                                                                            A.wg_ws, A.wg_ws[A.wg_npart:], Sc.wg_ws, Sc.wg_ws[Sc.wg_npart:],
@@ -776,6 +777,59 @@ class Engine(object):
             self.opt_ops.append(lambda: hip.sgd_momentum_clip(n, self.flat_w, self.flat_g, self.flat_v, self.hyper, self.normsq))
         self.labels["opt"] += ["sqnorm", "adam" if self.adam else "sgd"]
         self.flat_g.zero_()
+        self._fork_weight_gradients()
+
+    def _fork_weight_gradients(self):
+        """Weight-gradient launches are leaves of the backward pass: nothing reads their partials before the bucket's reduction.  On one
+        chain each of them is a full-chip persistent grid with a cold prologue and a synchronised store tail, and the data-gradient launch
+        behind it waits for its last block.  Here they go to a second stream instead (captured into the same hipGraph as a fork off the
+        chain): fork = the point of the chain where the launch stood (its dz is final there, every tensor has a gradient buffer of its own
+        and nothing later overwrites what it reads), join = the next reduction / finalisation / unpack launch (and the optimizer).  The
+        blocks of the two launches share the chip: a data-gradient grid fills the CUs the weight-gradient launch's tail has left and vice
+        versa.  Every kernel keeps its fixed-order arithmetic, so the step stays bit-identical to the single chain.  The wrapped closures
+        are what ursonet_amd/dp.py cuts into segments: every segment ends behind a finalisation, i.e. joined.
+        MEASURED (round 5, cfg2, alternating in one gpurun call): 7.07 / 7.06 ms on the single chain, 7.24 / 7.23 ms forked -- it LOSES 2.4 %.
+        Every grid here is a static partition of its tile stream over all 256 CUs; a block that finds its CU held by the other launch
+        runs as a second wave behind it, which costs more than the idle tails it fills (the same arithmetic as CUs held by a collective,
+        profiles/r02_dp_cu_contention.json).  So the fork is OFF by default (URSO_WGRAD_STREAM=1 switches it on); what the tails want is
+        both gradients of a layer inside ONE grid that partitions the CUs itself (conv_dwg.hip)."""
+        self.wgrad_stream = None
+        if os.environ.get("URSO_WGRAD_STREAM", "0") != "1" or self.mode != "training":
+            return
+        self.wgrad_stream = torch.cuda.Stream(device=self.device)
+        self._side_open = False
+        self._single_chain = False
+
+        def on_side(op):
+            def run():
+                if self._single_chain:
+                    return op()
+                main = torch.cuda.current_stream(self.device)
+                self.wgrad_stream.wait_stream(main)
+                with torch.cuda.stream(self.wgrad_stream):
+                    op()
+                self._side_open = True
+            return run
+
+        def joined(op):
+            def run():
+                self._join_weight_gradients()
+                return op()
+            return run
+        ops = []
+        for (tag, op), lab in zip(self.bwd_ops, self.labels["bwd"]):
+            if lab.startswith("wgrad:"):
+                op = on_side(op)
+            elif lab.split(":")[0] in ("reduce", "finalize_mat", "finalize_vec", "finalize", "unpack"):
+                op = joined(op)
+            ops.append((tag, op))
+        self.bwd_ops = ops
+        self.opt_ops[0] = joined(self.opt_ops[0])
+
+    def _join_weight_gradients(self):
+        if self.wgrad_stream is not None and self._side_open:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            self._side_open = False
 
     def _plan_relu_bitmasks(self):
         """A post-ReLU tensor gets a bit mask (1/16 of its bytes) for the backward pass when the conv that produces it can
@@ -1097,7 +1151,7 @@ class Engine(object):
         for op in self.opt_ops:
             op()
 
-    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap")
+    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair", "stem", "stem_pool", "c3")
 
     def _planning_options(self):
         return tuple(hip.get_option(o) for o in self.PLAN_OPTIONS)
@@ -1122,11 +1176,13 @@ class Engine(object):
         torch.cuda.synchronize(self.device)
         hip.prof_collect()
         hip.prof_enable(True)
+        self._single_chain = True               # every launch timed alone: the weight gradients stay on the chain (_fork_weight_gradients)
         try:
             self.step_eager()
             torch.cuda.synchronize(self.device)
             recs = hip.prof_collect_ex()
         finally:
+            self._single_chain = False
             hip.prof_enable(False)
         assert len(recs) == len(labels), (len(recs), len(labels))
         return [(l,) + r for l, r in zip(labels, recs)]
