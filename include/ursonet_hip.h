@@ -587,6 +587,16 @@ int urso_comm_allreduce_bucket(urso_comm* comm, void* buf_d, size_t count, int d
 int urso_comm_wait(urso_comm* comm, void* compute_stream);
 int urso_comm_destroy(urso_comm* comm);
 
+/*
+ * 16-bit gradient buckets with error feedback (ursonet_amd/dp.py GradReducer, compress = "bf16": half the bytes over xGMI).  The reference has
+ * no gradient exchange (config.py:20 GPU_COUNT = 1); these two replace three torch elementwise passes per bucket of the Python form.
+ *   urso_bucket_round_ef     t = g + resid;  c = bf16(t) (round to nearest even);  resid = t - float(c).   g is only read.
+ *   urso_bucket_expand_bf16  g = float(c): the averaged bucket back over the fp32 gradient slice the optimizer reads.
+ * n elements; g / resid 16-byte aligned, c 8-byte aligned (bucket boundaries are multiples of 4 elements).
+ */
+int urso_bucket_round_ef(size_t n, const float* g_d, float* resid_d, void* c_bf16_d, void* stream);
+int urso_bucket_expand_bf16(size_t n, const void* c_bf16_d, float* g_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

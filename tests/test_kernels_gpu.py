@@ -1618,3 +1618,25 @@ def test_zero_fill():
     assert float(t[:2].float().abs().max()) == 0.0 and float(guard.float().min()) == 5.0
     with pytest.raises(Exception):
         hip.zero_fill(torch.zeros(3, dtype=torch.bfloat16, device="cuda"))       # 6 bytes: not a multiple of 16
+
+
+def test_bucket_round_error_feedback_kernel_equals_the_torch_form():
+    """urso_bucket_round_ef / urso_bucket_expand_bf16 (ursonet_amd/dp.py GradReducer, compress='bf16') against the three torch passes they
+    replace -- t = g + r; c = bf16(t); r = t - float(c) -- bit for bit, on sizes with and without a whole number of 4-element vectors."""
+    import ursonet_amd.hip as hip
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for n in (4, 1000, 4096 + 3, (1 << 20) + 4):
+        g = torch.randn(n + 4, device="cuda", generator=gen)[:n] * 1e-2
+        r = torch.randn(n + 4, device="cuda", generator=gen)[:n] * 1e-5
+        c = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        g0, r0 = g.clone(), r.clone()
+        t = g0 + r0
+        c_ref = t.to(torch.bfloat16)
+        r_ref = t - c_ref.float()
+        hip.bucket_round_ef(g, r, c)
+        torch.cuda.synchronize()
+        assert torch.equal(g, g0), "the gradient slice is only read"
+        assert torch.equal(c.view(torch.int16), c_ref.view(torch.int16)) and torch.equal(r, r_ref)
+        back = torch.empty(n, device="cuda")
+        hip.bucket_expand_bf16(c, back)
+        assert torch.equal(back, c_ref.float())

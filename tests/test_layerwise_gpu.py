@@ -45,6 +45,9 @@ class DeviceTensors(object):
         self.npad = {}
         for c in eng.convs.values():
             self.npad[c.dst.spec.id] = c.npad
+        # a projection shortcut computed inside the fused forward pair (conv_pairs.hip) has no output tensor
+        self.never_stored = {eng.convs[nm].dst.spec.id for nm in getattr(eng, "shortcut_folded", [])}
+        self.producer = {c.dst.spec.id: c for c in eng.convs.values()}
         self.pool_of_stem = {}
         for n in eng.graph.nodes:
             if n.op == "pool":
@@ -63,7 +66,7 @@ class DeviceTensors(object):
     def values(self, X):
         """(values [B, C, H, W] with zeros where the device computes nothing, valid-pixel mask or None = all) -- None when the tensor is never stored."""
         s = X.spec
-        if getattr(X, "fused_pool", False):
+        if getattr(X, "fused_pool", False) or X.spec.id in self.never_stored:
             return None
         if getattr(X, "fwd_sampled", False):                     # computed at the even pixels only, stored compact
             v = torch.zeros(self.B, s.c, s.h, s.w)
@@ -77,7 +80,7 @@ class DeviceTensors(object):
 
     def grad(self, X):
         """dL/d(pre-activation of X's producer) as the device stored it, dense; None when it never reaches memory in full."""
-        if X.grad is None or not X.grad_written or getattr(X, "grad_on_chip", False):
+        if X.grad is None or not X.grad_written or getattr(X.grad, "_urso_on_chip", False):
             return None
         s = X.spec
         if X.compact is not None:                                # [B, H/2, W/2, C]: zero off the even grid
@@ -134,9 +137,18 @@ def layerwise_errors(eng, w0, img, cfg, dtype):
         res = None
         if c.res is not None:
             rv = dev.values(c.res)
-            if rv is None:
+            if rv is None and c.res.spec.id in dev.never_stored:
+                # the shortcut lives inside this layer's fused launch as 64 more columns of its GEMM, added in fp32 and never rounded to
+                # storage: the oracle's shortcut layer on ITS device input, unrounded
+                Sc = dev.producer[c.res.spec.id]
+                sx = dev.values(Sc.src)[0]
+                with torch.no_grad():
+                    res = G.conv_bn(_pad_for(Sc.node, sx), P[Sc.node.name], P[Sc.node.bn] if Sc.node.bn else None, False,
+                                    stride=Sc.node.stride, padding="valid", q=q)
+            elif rv is None:
                 skipped["fwd"].append(n.name); continue
-            res = rv[0]
+            else:
+                res = rv[0]
         xt = x.clone().requires_grad_(True)
         # ---- the oracle's single layer on them
         if n.dense:
@@ -151,12 +163,17 @@ def layerwise_errors(eng, w0, img, cfg, dtype):
         y = y if n.out_f32 else rnd(y.detach())
         # ---- forward: the layer's stored output
         dv = dev.values(c.dst)
-        if dv is None:                                           # conv1 inside urso_stem_conv_pool: only the pooled tensor exists
+        if dv is None and c.dst.spec.id in dev.never_stored:     # the folded shortcut: checked through the layer that adds it (above); its dz is that layer's
+            dzs = dev.grad(c.dst)
+            if dzs is None:
+                skipped["bwd"].append(n.name); add_contrib(c.src, None, False); continue
+            dv = (None, None)
+        elif dv is None:                                         # conv1 inside urso_stem_conv_pool: only the pooled tensor exists
             pool = dev.pool_of_stem[c.dst.spec.id]
             pd = dev.values(acts_by_id[pool.dst.id])[0]
             yp = G.maxpool_3x3_s2_same(y.detach())
             out["fwd"][n.name + "+maxpool"] = (_max_rel(yp, pd), _l2_rel(yp, pd))
-        else:
+        elif dv[0] is not None:
             out["fwd"][n.name] = (_max_rel(y.detach(), dv[0], dv[1]), _l2_rel(y.detach(), dv[0], dv[1]))
         # ---- backward: the device's dz through the layer
         if dv is None:
@@ -221,9 +238,12 @@ def _worst(d):
 # sides can land on neighbouring 16-bit values where their fp32 sums differ: one unit); an activation gradient that two consumers
 # accumulate into is rounded twice on the device; parameter gradients are fp32 sums over the pixels of operands that are IDENTICAL on
 # both sides, so they agree to fp32 summation order.
+# Measured (profiles/r05_parity.txt; cfg2 width, three seeds x two plans, and fp16 ResNet-101): bf16 outputs <= 6.4e-3 of the tensor's max
+# (2.5e-4 Euclidean), activation gradients <= 7.0e-3 (3.0e-3), kernels <= 1.0e-3 (9.2e-4), vectors <= 1.1e-3 (9.0e-4); fp16 8.6e-4 (6.6e-5),
+# 8.2e-4 (3.2e-4), 1.0e-4, 4.5e-5.  Gates = ~1.5x those.
 GATES = {
-    "bfloat16": {"fwd": (1.5e-2, 4e-3), "dx": (1.5e-2, 4e-3), "dkernel": (2e-3, 1e-3), "dvec": (5e-3, 2e-3)},
-    "float16": {"fwd": (2e-3, 5e-4), "dx": (2e-3, 5e-4), "dkernel": (2e-3, 1e-3), "dvec": (5e-3, 2e-3)},
+    "bfloat16": {"fwd": (1.0e-2, 5e-4), "dx": (1.1e-2, 4.5e-3), "dkernel": (1.6e-3, 1.4e-3), "dvec": (2e-3, 1.4e-3)},
+    "float16": {"fwd": (1.3e-3, 1e-4), "dx": (1.3e-3, 5e-4), "dkernel": (2e-4, 1e-4), "dvec": (2e-4, 1e-4)},
 }
 
 
@@ -275,7 +295,7 @@ def test_teacher_forced_layer_parity_bf16_at_cfg2_width(plan, seed):
     (errs, skipped), eng = _run("bfloat16", kw, seed, {} if plan == "policy" else {"pair": 0})
     _report("bf16 cfg2-width %s seed %d" % (plan, seed), errs, skipped)
     nconv = len(eng.convs)
-    assert len(errs["fwd"]) == nconv and not skipped["fwd"]
+    assert len(errs["fwd"]) == nconv - len(eng.shortcut_folded) and not skipped["fwd"]
     if plan == "apart":
         assert len(errs["dkernel"]) == nconv and not skipped["bwd"], skipped
         assert len(errs["dx"]) >= 40, (len(errs["dx"]), skipped["dx"])
@@ -289,5 +309,5 @@ def test_teacher_forced_layer_parity_fp16_resnet101():
     kw = dict(backbone="resnet101", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
     (errs, skipped), eng = _run("float16", kw, 1, {})
     _report("fp16 r101 128x192", errs, skipped)
-    assert len(errs["fwd"]) == len(eng.convs)
+    assert len(errs["fwd"]) == len(eng.convs) - len(eng.shortcut_folded)
     _check("float16", errs)

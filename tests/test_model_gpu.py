@@ -275,8 +275,9 @@ def test_training_step_parity_bf16_five_seeds_two_sided_gate():
     """The bf16 whole-step comparison on FIVE data seeds with a two-sided gate.  The single-seed gate above has to
     sit above the chaotic residue's maximum (1.2e-1 of the worst tensor's max), which a uniform 2 % scale error would pass.  Over seeds the
     residue's MEDIAN is small -- profiles/r04_parity.txt: worst filter-gradient tensor 1.6e-2 ... 7.8e-2, median ~3e-2 -- while a systematic
-    error moves every seed: median of the worst-tensor error <= 4e-2 (max norm) and <= 3e-2 (Euclidean), median output error <= 1.2e-2,
-    and the single-seed maxima as before."""
+    error moves every seed: median of the worst-tensor error <= 4e-2 (max norm) and <= 3e-2 (Euclidean), median output error <= 1.5e-2,
+    and the single-seed maxima as before.  Measured (profiles/r05_parity.txt): worst-tensor 1.6e-2, 2.2e-2, 7.8e-2, 1.6e-2, 2.6e-2 -> median
+    2.2e-2; Euclidean median 1.7e-2; outputs median 1.0e-2."""
     from oracle import graph_ref as G
     kw = dict(backbone="resnet50", h=128, w=192, batch=2, regress_ori=False, ori_bins=8)
     cfg = make_config(dtype="bfloat16", **kw)
@@ -288,7 +289,8 @@ def test_training_step_parity_bf16_five_seeds_two_sided_gate():
         dec = ReluDecisions(eng, tol=4e-2)
         ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
         assert dec.flips <= 2e-3 * dec.total
-        ms.append(_compare_step(eng, ref, newW, 2.5e-2, 1.2e-1, 1e-3, tol_l2=0.85 * 1.2e-1, tol_norm=2.5e-2))
+        _compare_step(eng, ref, newW, 2.5e-2, 1.2e-1, 1e-3, tol_l2=0.85 * 1.2e-1, tol_norm=2.5e-2)          # every seed: the single-seed maxima
+        ms.append(_compare_step(eng, ref, newW, 0, 0, 0, check=False))
         del eng
     med = {k: float(np.median([m[k] for m in ms])) for k in ms[0]}
     print("median over seeds:", {k: "%.2e" % v for k, v in med.items()})
@@ -297,7 +299,7 @@ def test_training_step_parity_bf16_five_seeds_two_sided_gate():
         with open(log, "a") as f:
             f.write("bf16 2x128x192 five seeds: median %s  max %s\n" % ({k: "%.2e" % v for k, v in med.items()},
                                                                          {k: "%.2e" % max(m[k] for m in ms) for k in ms[0]}))
-    assert med["grad_big"] <= 4e-2 and med["grad_l2"] <= 3e-2 and med["loc"] <= 1.2e-2 and med["ori"] <= 1.2e-2 and med["grad_norm"] <= 1e-2, med
+    assert med["grad_big"] <= 4e-2 and med["grad_l2"] <= 3e-2 and med["loc"] <= 1.5e-2 and med["ori"] <= 1.5e-2 and med["grad_norm"] <= 1e-2, med
 
 
 def test_training_step_parity_bf16_full_benchmark_batch():

@@ -63,6 +63,50 @@ __global__ __launch_bounds__(1024) void probe(const char* __restrict__ base, uin
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) sink[0] = 1;
 }
 
+// The activation stream of a pointwise layer as conv_pwx.hip reads it: a tile of R pixel rows of `pitch` bytes, consumed in K-steps of `seg` bytes
+// per row (seg = 128: 64 channels) -- one LDS-DMA instruction covers 1024 / seg rows x seg bytes, a row's bytes are requested pitch / seg times,
+// one K-step apart.  seg = pitch is the same tile read row by row (what a kernel with the whole reduction per step would do).
+template <int D>
+__global__ __launch_bounds__(512) void rowseg(const char* __restrict__ base, uint64_t bytes, int R, uint32_t pitch, uint32_t seg, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const uint32_t lps = seg >> 4, rpi = 1024u / seg;               // lanes per row segment, rows per instruction
+    const uint32_t lrow = lane / lps, lcol = (lane % lps) * 16u;
+    const int groups = (int)((uint32_t)R / rpi);
+    char* my = lds + wave * (D * 1024);
+    int slot = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const char* tb = base + (uint64_t)t * R * pitch;
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb), 0, (uint32_t)R * pitch, 0x00020000);
+        for (uint32_t k = 0; k < pitch; k += seg)
+            for (int g = wave; g < groups; g += W) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(my + slot * 1024), 16,
+                                                         ((uint32_t)g * rpi + lrow) * pitch + k + lcol, 0, 0, 0);
+                slot = (slot + 1 == D) ? 0 : slot + 1;
+                wait_vm<D - 1>();
+            }
+    }
+    wait_vm<0>();
+}
+
+static double run_rowseg(const char* buf, uint64_t bytes, int ncu, int R, uint32_t pitch, uint32_t seg, int reps) {
+    const int ntiles = (int)(bytes / ((uint64_t)R * pitch));
+    const size_t lds_bytes = 96 * 1024;
+    CK(hipFuncSetAttribute((const void*)rowseg<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int k = 0; k < reps + 1; ++k) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((rowseg<12>), dim3(ncu), dim3(512), lds_bytes, 0, buf, bytes, R, pitch, seg, ntiles);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (k > 0 && ms < best) best = ms;
+    }
+    return (double)ntiles * R * pitch / (best * 1e-3);
+}
+
 template <int MODE, int D>
 static double run(const char* buf, uint64_t ws, int ncu, int W, uint64_t per_cu_bytes, int* sink, int reps) {
     const uint64_t per_iter = (uint64_t)W * D * 1024 * (MODE == 2 ? 2 : 1);
@@ -106,7 +150,9 @@ int main(int argc, char** argv) {
         {"HBM window 512 MiB/XCD", 512ull << 20, 16ull << 20},
     };
     printf("%-26s %-8s %2s %2s %10s %12s\n", "source", "path", "W", "D", "TB/s chip", "GB/s per CU");
+    const bool only_rowseg = argc > 1 && argv[1][0] == 'r';
     for (const Case& c : cases) {
+        if (only_rowseg) break;
         for (int W : {4, 8, 16}) {
             double r;
             r = run<0, 8>(buf, c.ws, ncu, W, c.per_cu, sink, 3); printf("%-26s %-8s %2d %2d %10.2f %12.1f\n", c.name, "lds-dma", W, 8, r / 1e12, r / 1e9 / ncu);
@@ -116,5 +162,16 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    // ---- the activation stream of the stage-4 / stage-5 pointwise layers (160-row tiles, rows of 2 KiB / 4 KiB / 512 B), by K-step width
+    printf("\n%-44s %8s %10s\n", "row-segment stream (LDS-DMA, 8 waves, 12 in flight)", "seg B", "TB/s chip");
+    struct RS { const char* name; uint64_t bytes; int R; uint32_t pitch; };
+    const RS rs[] = {{"HBM 4 GiB, 160 rows x 2048 B (K = 1024)", 4ull << 30, 160, 2048}, {"HBM 4 GiB, 160 rows x 4096 B (K = 2048)", 4ull << 30, 160, 4096},
+                     {"HBM 4 GiB, 160 rows x 512 B (K = 256)", 4ull << 30, 160, 512},
+                     {"84 MB (one layer's tensor, re-read), 160 x 2048", 84ull << 20, 160, 2048}};
+    for (const RS& c : rs)
+        for (uint32_t seg = 128; seg <= c.pitch && seg <= 1024; seg *= 2) {
+            const double r = run_rowseg(buf, c.bytes, ncu, c.R, c.pitch, seg, 3);
+            printf("%-44s %8u %10.2f\n", c.name, seg, r / 1e12); fflush(stdout);
+        }
     return 0;
 }

@@ -112,3 +112,53 @@ extern "C" int urso_comm_destroy(urso_comm* c) {
     delete c;
     return URSO_OK;
 }
+
+// ---------------------------------------------------------------- 16-bit gradient buckets with error feedback (ursonet_amd/dp.py GradReducer, compress = 'bf16')
+// One pass instead of three torch elementwise launches per bucket:  t = g + resid;  c = bf16(t);  resid = t - float(c).  g itself is left
+// alone: the averaged bucket is expanded over it by urso_bucket_expand_bf16 once the collective is done.  Round-to-nearest-even, the
+// conversion torch's copy_ uses, so that the two forms agree bit for bit (tests/test_kernels_gpu.py).
+__global__ void bucket_round_ef_kernel(size_t n, const float* __restrict__ g, float* __restrict__ resid, __bf16* __restrict__ c) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4_t gv = ((const f32x4_t*)g)[i], rv = ((const f32x4_t*)resid)[i];
+        float t[4] = {gv.x + rv.x, gv.y + rv.y, gv.z + rv.z, gv.w + rv.w};
+        __bf16 cb[4]; f32x4_t rn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cb[k] = Elem<__bf16>::from_f(t[k]); rn[k] = t[k] - Elem<__bf16>::to_f(cb[k]); }
+        uint64_t pk; __builtin_memcpy(&pk, cb, 8);
+        ((uint64_t*)c)[i] = pk;
+        ((f32x4_t*)resid)[i] = rn;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) { const float t = g[i] + resid[i]; const __bf16 cb = Elem<__bf16>::from_f(t); c[i] = cb; resid[i] = t - Elem<__bf16>::to_f(cb); }
+}
+extern "C" int urso_bucket_round_ef(size_t n, const float* g_d, float* resid_d, void* c_bf16_d, void* stream) {
+    if (!g_d || !resid_d || !c_bf16_d) { urso_set_error("urso_bucket_round_ef: null argument"); return URSO_EINVAL; }
+    if (((((uintptr_t)g_d) | ((uintptr_t)resid_d)) & 15) || (((uintptr_t)c_bf16_d) & 7)) { urso_set_error("urso_bucket_round_ef: g / resid must be 16-byte, c 8-byte aligned"); return URSO_EINVAL; }
+    if (n == 0) return URSO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 14);
+    size_t blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    URSO_KLAUNCH(bucket_round_ef_kernel, dim3((int)blocks), dim3(256), 0, st, n, g_d, resid_d, (__bf16*)c_bf16_d);
+    return urso_check_launch("urso_bucket_round_ef");
+}
+
+__global__ void bucket_expand_kernel(size_t n, const __bf16* __restrict__ c, float* __restrict__ g) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t pk = ((const uint64_t*)c)[i];
+        __bf16 cb[4]; __builtin_memcpy(cb, &pk, 8);
+        ((f32x4_t*)g)[i] = f32x4_t{Elem<__bf16>::to_f(cb[0]), Elem<__bf16>::to_f(cb[1]), Elem<__bf16>::to_f(cb[2]), Elem<__bf16>::to_f(cb[3])};
+    }
+    if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) g[i] = Elem<__bf16>::to_f(c[i]);
+}
+extern "C" int urso_bucket_expand_bf16(size_t n, const void* c_bf16_d, float* g_d, void* stream) {
+    if (!g_d || !c_bf16_d) { urso_set_error("urso_bucket_expand_bf16: null argument"); return URSO_EINVAL; }
+    if ((((uintptr_t)g_d) & 15) || (((uintptr_t)c_bf16_d) & 7)) { urso_set_error("urso_bucket_expand_bf16: g must be 16-byte, c 8-byte aligned"); return URSO_EINVAL; }
+    if (n == 0) return URSO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)n * 6);
+    size_t blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    URSO_KLAUNCH(bucket_expand_kernel, dim3((int)blocks), dim3(256), 0, st, n, (const __bf16*)c_bf16_d, g_d);
+    return urso_check_launch("urso_bucket_expand_bf16");
+}

@@ -493,7 +493,7 @@ int urso_hconv2_try_launch(const urso_conv_geom* g, int dt, int relu, const void
     a.relu = relu; a.dbg = g_urso_opt.hconv_dbg;
     a.clk = (ws && has_ws && (a.dbg & 2048)) ? (unsigned long long*)((char*)ws + 8192) : nullptr;
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = ncu / 8;                                  // all of a CU's LDS: one block per CU, each walks a contiguous run of whole tiles
+    const int cap = ncu / 8 > 0 ? ncu / 8 : 1;                // all of a CU's LDS: one block per CU, each walks a contiguous run of whole tiles (>= 1 block per XCD whatever option `cus` says)
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(512);

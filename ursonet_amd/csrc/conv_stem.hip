@@ -194,7 +194,7 @@ int urso_stem_launch(const urso_conv_geom* g, int dt, int relu, const void* src,
     a.src_bytes = (uint32_t)((size_t)a.B * a.H * a.W * 8); a.dst_bytes = (uint32_t)((size_t)a.B * a.OH * a.OW * 128);
     a.tiles_x = ceil_div(a.OW, ST_TW); a.tiles_y = ceil_div(a.OH, ST_TH); a.ntiles = a.B * a.tiles_y * a.tiles_x;
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = 2 * st_device_cus() / 8;
+    const int cap = 2 * st_device_cus() / 8 > 0 ? 2 * st_device_cus() / 8 : 1;      // (>= 1 block per XCD whatever option `cus` says)
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);
@@ -484,7 +484,7 @@ int urso_stem_pool_launch(const urso_conv_geom* g, int dt, const void* src, cons
     a.src_bytes = (uint32_t)((size_t)a.B * a.H * a.W * 8); a.dst_bytes = (uint32_t)((size_t)a.B * a.PH * a.PW * 128); a.am_bytes = a.dst_bytes / 2;
     a.tiles_x = ceil_div(a.PW, SP_PC); a.tiles_y = ceil_div(a.PH, SP_PR); a.ntiles = a.B * a.tiles_y * a.tiles_x;
     int bpx = ceil_div(a.ntiles, 8);
-    const int cap = 2 * st_device_cus() / 8;
+    const int cap = 2 * st_device_cus() / 8 > 0 ? 2 * st_device_cus() / 8 : 1;      // (>= 1 block per XCD whatever option `cus` says)
     if (bpx > cap) bpx = cap;
     if (g_urso_opt.grid_cap > 0 && bpx > ceil_div(g_urso_opt.grid_cap, 8)) bpx = ceil_div(g_urso_opt.grid_cap, 8);
     const dim3 grid(8 * bpx), blk(256);

@@ -111,9 +111,12 @@ class GradReducer(object):
         back = None
         if self.compress:
             r, c = self.resid[s:e], self.cbuf[s:e]
-            t.add_(r)                       # error feedback: last step's rounding remainder
-            c.copy_(t)                      # round to bf16
-            torch.sub(t, c.float(), out=r)  # what this rounding dropped, kept for the next step
+            if t.is_cuda:                   # one library pass (urso_bucket_round_ef): c = bf16(g + r), r = (g + r) - float(c); g is only read
+                hip.bucket_round_ef(t, r, c)
+            else:                           # CPU tensors (the gloo tests of the schedule): the same arithmetic in torch
+                t.add_(r)                   # error feedback: last step's rounding remainder
+                c.copy_(t)                  # round to bf16
+                torch.sub(t, c.float(), out=r)  # what this rounding dropped, kept for the next step
             back, t = t, c
         if self.comm is not None:           # urso_comm_allreduce_bucket: RCCL average on the communicator's own stream
             self.comm.allreduce_bucket(t)
@@ -131,9 +134,43 @@ class GradReducer(object):
                 w.wait()
             if scale is not None:
                 scale.div_(self.world)
-            if back is not None:
-                back.copy_(t)               # averaged bf16 gradient -> the fp32 buffer the optimizer reads
+            if back is not None:            # averaged bf16 gradient -> the fp32 buffer the optimizer reads
+                if back.is_cuda:
+                    hip.bucket_expand_bf16(t, back)
+                else:
+                    back.copy_(t)
         self.works = []
+
+
+class _OptionOverride(object):
+    """Process-wide kernel-policy options that DataParallelEngine overrides while collectives run beside the step (`cus`, `hconv_streamk`),
+    reference-counted: wrappers nest, the value from before the FIRST override comes back when the LAST wrapper that asked for it closes,
+    and a second wrapper asking for another value of a held option is an error instead of a silent split-count mismatch."""
+    held = {}                               # option -> [value before the first override, override value, count]
+
+    @classmethod
+    def acquire(cls, name, value):
+        h = cls.held.get(name)
+        if h is None:
+            cls.held[name] = [hip.get_option(name), int(value), 1]
+            hip.set_option(name, int(value))
+        elif h[1] != int(value):
+            raise RuntimeError("option %r is held at %d by another DataParallelEngine; this one needs %d -- close() the other first" % (name, h[1], value))
+        else:
+            h[2] += 1
+
+    @classmethod
+    def release(cls, name):
+        """True when this release restored the option (the last holder is gone)."""
+        h = cls.held.get(name)
+        if h is None:
+            return False
+        h[2] -= 1
+        if h[2] > 0:
+            return False
+        hip.set_option(name, h[0])
+        del cls.held[name]
+        return True
 
 
 class DataParallelEngine(object):
@@ -166,21 +203,30 @@ class DataParallelEngine(object):
         dist.broadcast(eng.flat_stats, src=0, group=group)
         # gradient buckets are planned by the engine (it batches the gradient finalisation per bucket)
         replan = False
+        self._holds = []                                # options this wrapper holds (_OptionOverride), given back by close()
+        try:
+            self._init_policy(eng, explicit, comm, bucket_bytes, tail_bytes, replan)
+        except BaseException:
+            self.close()                                # an exception here must not leave the process on the reduced chip / without stream-K
+            raise
+
+    def _init_policy(self, eng, explicit, comm, bucket_bytes, tail_bytes, replan):
         if self.comm_cus and eng.device.type == "cuda" and (self.world > 1 or (explicit and _force_collectives())):
             total = torch.cuda.get_device_properties(eng.device).multi_processor_count
             usable = max(8, total - self.comm_cus)
-            if hip.get_option("cus") != usable:
-                self._cus_before = hip.get_option("cus")
-                hip.set_option("cus", usable)           # split counts follow it: the plan below must be rebuilt under the new value (process-wide until close())
-                replan = True
+            if hip.get_option("cus") != usable or "cus" in _OptionOverride.held:
+                before = hip.get_option("cus")
+                _OptionOverride.acquire("cus", usable)  # split counts follow it: the plan below must be rebuilt under the new value (process-wide until close())
+                self._holds.append("cus")
+                replan = before != usable
         # conv_halo.hip's accumulator hand-over between blocks ("stream-K") needs every block of the launch resident: a finishing block spins on
         # the pieces of the runs behind it.  RCCL's workgroups hold CUs while the backward pass runs, so a producer can sit in the queue behind
         # them for a collective's duration with a consumer CU spinning on it.  No hand-over while collectives run beside the step (the
         # whole-tile kernel of conv_halo2.hip takes those layers; option hconv_streamk, restored by close()).
-        self._streamk_before = None
-        if eng.device.type == "cuda" and (self.world > 1 or _force_collectives() or comm is not None) and hip.get_option("hconv_streamk"):
-            self._streamk_before = hip.get_option("hconv_streamk")
-            hip.set_option("hconv_streamk", 0)
+        if eng.device.type == "cuda" and (self.world > 1 or _force_collectives() or comm is not None) and (
+                hip.get_option("hconv_streamk") or "hconv_streamk" in _OptionOverride.held):
+            _OptionOverride.acquire("hconv_streamk", 0)
+            self._holds.append("hconv_streamk")
             eng._graphs = None                          # the kernel choice is made at launch time: re-capture under the new policy
         # the last bucket's all-reduce has nothing left to hide behind: cap it (plan_buckets) when ranks really exchange gradients.  On one
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
@@ -196,17 +242,18 @@ class DataParallelEngine(object):
     def close(self):
         """Give the CUs reserved for the collectives back: option `cus` is process-wide, and an Engine planned after this wrapper is gone
         would otherwise size its grids for the smaller chip."""
-        if getattr(self, "_streamk_before", None) is not None:
-            hip.set_option("hconv_streamk", self._streamk_before)
-            self._streamk_before = None
+        holds, self._holds = list(getattr(self, "_holds", [])), []
+        if "hconv_streamk" in holds:
+            _OptionOverride.release("hconv_streamk")
             self.eng._graphs = None
-        if getattr(self, "_cus_before", None) is not None:
-            hip.set_option("cus", self._cus_before)
-            self._cus_before = None
+        if "cus" in holds:
+            restored = _OptionOverride.release("cus")
             # the wrapped engine planned its split counts, partial workspaces and grouped weight-gradient launches for the reduced CU count:
-            # re-plan it for the whole chip (its captured graph goes with the plan; plan_version moves)
+            # once the option is back (the last wrapper holding it is gone) re-plan it for the whole chip (its captured graph goes with the
+            # plan; plan_version moves); while another wrapper still holds the reduced chip this engine's plan already matches the option
             self.eng._graphs = None
-            self.eng._build_plan()
+            if restored:
+                self.eng._build_plan()
         self._graphs = None
 
     def __enter__(self):
@@ -326,6 +373,8 @@ class DataParallelEngine(object):
         the optimizer."""
         if self.plan_version != self.eng.plan_version:
             self._derive_cuts()
+        if hasattr(self.eng, "_check_plan_options"):
+            self.eng._check_plan_options()
         segs, last = self._segments()
         if self.rel_exact:
             for op in self.eng.prep_ops + self.eng.fwd_ops + self.eng.loss_pre_ops:

@@ -38,6 +38,7 @@ class _Act(object):
 
     def __init__(self, eng, spec, numel, dtype):
         self.spec, self.numel = spec, numel
+        self.fused_pool = False      # conv1's output when urso_stem_conv_pool computes the max-pool as well: never stored
         self.data = torch.empty(numel, dtype=dtype, device=eng.device)
         self.grad = None
         self.grad_written = False
@@ -46,6 +47,16 @@ class _Act(object):
         self.compact = None          # (H, W): the gradient buffer holds only the even rows / columns of the pixel grid ([B, H/2, W/2, C])
         self.pending_hw = None       # same, for a pending residual gradient
         self.eng = eng
+
+    @property
+    def data(self):
+        if self.fused_pool:
+            raise RuntimeError("T%d is conv1's output inside the fused conv1 + ReLU + max-pool kernel: it is never stored (option stem_pool = 0 keeps it)" % self.spec.id)
+        return self._data
+
+    @data.setter
+    def data(self, t):
+        self._data = t
 
     def grad_buf(self):
         if self.grad is None:
@@ -375,7 +386,7 @@ class Engine(object):
                 self._fused_pools[id(pool)] = c
                 pdst = act(pool.dst)
                 pool._am = torch.empty(pdst.numel, dtype=torch.uint8, device=dev)
-                c.dst.data = torch.empty(0, dtype=self.tdt, device=dev)
+                c.dst.data = torch.empty(0, dtype=self.tdt, device=dev)      # (frees the 335 MB; any later read raises: _Act.data)
                 c.dst.fused_pool = True
                 c.fwd_index = len(self.fwd_ops)
                 self.fwd_ops.append(lambda c=c, d=pdst, am=pool._am: hip.stem_conv_pool(c.gf, dt, c.xin, c.wf, c.biasf, d.data, am))
@@ -701,7 +712,7 @@ class Engine(object):
                             dxin = Sc.src.grad_buf()
                             Sc.src.grad_written = True
                             dstg.zero_()                   # dL/dX never reaches memory in this form: the buffer stays what it is (zeros, not whatever the allocator left)
-                            X.grad_on_chip = True          # (tests/test_layerwise_gpu.py skips what it cannot read)
+                            dstg._urso_on_chip = True      # (tests/test_layerwise_gpu.py skips what it cannot read; the shortcut's gradient aliases this buffer)
                             self.bwd_ops.append((None, lambda c=c, A=A, Sc=Sc, G=G, add=add, X=X, dst2=dst2, dxin=dxin:
                                                  hip.conv_pair_wgrad_entry(A.Mpix, dt, G, c.wd, add, X.bits, A.wd, A.src.data, dst2, Sc.wd, Sc.src.data, Sc.src.spec.relu, dxin,
                                                                            A.wg_ws, A.wg_ws[A.wg_npart:], Sc.wg_ws, Sc.wg_ws[Sc.wg_npart:],

@@ -131,6 +131,8 @@ _SIGS = {
     "urso_comm_allreduce_bucket": (_i, [_vp, _vp, _sz, _i, _vp]),
     "urso_comm_wait": (_i, [_vp, _vp]),
     "urso_comm_destroy": (_i, [_vp]),
+    "urso_bucket_round_ef": (_i, [_sz, _fp, _fp, _vp, _vp]),
+    "urso_bucket_expand_bf16": (_i, [_sz, _vp, _fp, _vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
     "urso_conv_pair_shortcut": (_i, [C.c_longlong, _i, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _vp, _vp]),
@@ -232,6 +234,18 @@ def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1, FH
 def conv_igemm(g, dt, flags, src, wgt, bias, add, mask, dst, stream=None):
     _chk(_lib.urso_conv_igemm(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
                               stream_ptr(stream)), "urso_conv_igemm")
+
+
+def bucket_round_ef(g, resid, c, stream=None):
+    """urso_bucket_round_ef: c = bf16(g + resid), resid = (g + resid) - float(c), one pass (g is only read)."""
+    assert g.dtype == torch.float32 and resid.dtype == torch.float32 and c.dtype == torch.bfloat16 and g.numel() == resid.numel() == c.numel()
+    _chk(_lib.urso_bucket_round_ef(g.numel(), ptr(g), ptr(resid), ptr(c), stream_ptr(stream)), "urso_bucket_round_ef")
+
+
+def bucket_expand_bf16(c, g, stream=None):
+    """urso_bucket_expand_bf16: g = float(c)."""
+    assert g.dtype == torch.float32 and c.dtype == torch.bfloat16 and g.numel() == c.numel()
+    _chk(_lib.urso_bucket_expand_bf16(g.numel(), ptr(c), ptr(g), stream_ptr(stream)), "urso_bucket_expand_bf16")
 
 
 def conv_winograd_ws_bytes(g, dt):
