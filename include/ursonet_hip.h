@@ -199,6 +199,8 @@ int urso_conv_pair_wgrad(long long M, int dt, const void* src_d, const void* w1_
 /* The inverse: out[b][y][x][:] = in[b][y/2][x/2][:] at even (y, x), zero elsewhere -- the dense form of a compact gradient for a
  * consumer that cannot take the compact operand (stages whose residual hand-over is not a urso_conv_pair launch). */
 int urso_rows_expand2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
+/* The same, writing ONLY the even pixels of out (a quarter of the bytes): for a dense buffer the caller cleared once and nothing else writes. */
+int urso_rows_scatter2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream);
 /* Zero fill (16-byte aligned pointer and size): the buffer a scattered data gradient (urso_conv_igemm_ex with FH / FW) lands in. */
 int urso_zero_fill(void* dst_d, size_t bytes, void* stream);
 
@@ -564,7 +566,7 @@ typedef struct urso_prof_record_ex {
     int32_t n_launches;
     char    symbol[228];
     double  l2_bytes;          /* bytes the launch copies out of L2 into LDS / registers, operand re-reads per tile included (0 where the kernel
-                                  does not report it): the roof between HBM and the matrix pipe, ~11 TB/s chip-wide as measured */
+                                  does not report it): the roof between HBM and the matrix pipe, ~35 TB/s chip-wide (tools/probes/l2_bw_probe.hip, profiles/r05_l2_probe.txt) */
 } urso_prof_record_ex;
 int urso_prof_collect_ex(urso_prof_record_ex* out, int max_records);
 

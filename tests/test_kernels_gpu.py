@@ -1000,18 +1000,22 @@ C3W_CASES = [
     (3, 17, 45, 128, 128, 3, 1, (1, 1), "c3w_ragged"),
     (2, 64, 96, 128, 128, 3, 1, (1, 1), "c3w_multi_tile"),
     (8, 64, 80, 128, 128, 3, 1, (1, 1), "c3w_stage3_rows"),
+    (2, 21, 50, 128, 128, 3, 1, (1, 1), "c3w_ragged_16"),          # 8 x 16 tiles with partial rows and columns on both borders
 ]
 
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("cap", [0, 8])
+@pytest.mark.parametrize("c3v", [1, 0], ids=["wave16", "halves"])
 @pytest.mark.parametrize("case", C3W_CASES, ids=[c[-1] for c in C3W_CASES])
-def test_3x3_128_channel_layers_register_filter_kernel(case, dt, cap):
-    """The 128-channel form of conv_c3.hip (8 waves, each 32 filters x one 64-channel half of the filter in registers; the reduction over
-    the two halves finished through LDS), forced on every shape (option c3 = 3: the default policy takes it only where its tiles fit the
-    image width): forward, data gradient with mask and weight gradient against the CPU fp32 reference; ragged sizes, capped grid."""
+def test_3x3_128_channel_layers_register_filter_kernel(case, dt, cap, c3v):
+    """The 128-channel forms of conv_c3.hip, forced on every shape (option c3 = 3: the default policy takes them only where their tiles fit
+    the image width): forward, data gradient with mask and weight gradient against the CPU fp32 reference; ragged sizes, capped grid.
+    'halves' = c3w_kernel (8 waves, each 32 filters x one 64-channel half of the filter in registers, the two halves' sums exchanged through
+    LDS; the only form on 4 x 32 tiles); 'wave16' (option c3v, default) = c3v_kernel on the 8 x 16 tiles (c3w_ragged, c3w_stage3_rows:
+    every wave 16 filters over the whole reduction, no exchange)."""
     hip = _hip()
-    with hip.options(c3=3, grid_cap=cap):
+    with hip.options(c3=3, c3v=c3v, grid_cap=cap):
         test_conv_forward_and_gradients(case, dt)
 
 

@@ -958,6 +958,10 @@ def test_bench_under_torchrun_with_forced_collectives_one_rank():
     assert p["dp"] is None and d["dp"] is not None
     assert d["n_gpus"] == 1 and d["metric"] == p["metric"]
     assert d["dp"]["exposed_comm_ms"] >= 0.0 and len(d["dp"]["bucket_bytes"]) >= 2
+    # the self-diagnosis of a scaling run: per-rank exposed exchange time and step time, the bucket schedule, RCCL's own account of itself
+    assert len(d["dp"]["exposed_comm_ms_per_rank"]) == 1 and len(d["dp"]["ms_per_step_per_rank"]) == 1
+    assert abs(d["dp"]["ms_per_step_per_rank"][0] - d["ms_per_step"]) < 1e-2 and d["dp"]["n_buckets"] == len(d["dp"]["bucket_bytes"])
+    assert isinstance(d["dp"]["rccl"], list) and len(d["dp"]["rccl"]) >= 1, d["dp"]["rccl"]
     cfg = make_config("resnet50", 512, 640, batch=32, regress_ori=False, ori_bins=16, dtype="bfloat16")
     from ursonet_amd.graph import build_graph
     # trainable parameters as the flat gradient buffer lays them out (each tensor padded to 4 floats; moving statistics are not gradients)

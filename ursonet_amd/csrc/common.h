@@ -29,7 +29,9 @@ struct UrsoOptions {
     int grid_cap = 0;        // > 0: cap the block count of the persistent conv kernels (tests: forces the multi-tile stream on small shapes)
     int hconv = 1;           // conv_halo.hip (8-wave halo-tile kernel) for qualifying 3x3 layers
     int pair = 1;            // conv_pair.hip: fused pointwise pairs of stages 2-3 (read by the host plan, ursonet_amd/engine.py)
+    int pair_single = 3;     // conv_pair.hip takes the single c -> 4c layers of stage 4 (bit 0) / stage 5 (bit 1); cleared bits leave them to conv_pwx.hip
     int c3 = 1;              // conv_c3.hip (register-resident 3x3 filter) for 64-channel / 64-filter 3x3 layers
+    int c3v = 1;             // 128-channel 3x3 layers on 8 x 16 tiles: 1 c3v_kernel (16 filters per wave over the whole reduction, no exchange), 0 c3w_kernel
     int stem = 1;            // conv_stem.hip (im2col on the LDS read side) for the packed 7x7 stem
     int stem_pool = 1;       // conv1 + ReLU + max-pool in one kernel (urso_stem_conv_pool); 0: the engine runs the two kernels
     int cus = 0;             // > 0: CUs the persistent grids and the weight-gradient split may fill (rounded down to whole XCD rows of 8);

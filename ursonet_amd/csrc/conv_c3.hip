@@ -15,6 +15,7 @@
 //   * the result goes through a 16 KiB LDS tile to row-contiguous 16-byte stores (+ the ReLU mask of the data gradient, loaded with the
 //     same coalesced addresses); 72 KiB of LDS -> two blocks per CU.
 #include "common.h"
+#include <utility>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -437,6 +438,199 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------- 128 channels, second form: every wave owns 16 filters over the WHOLE reduction
+// c3w_kernel splits the 1152-deep reduction between two wave groups (64 channels each) because a 32-filter MFMA row operand over all
+// 128 channels x 9 taps would be 288 registers; the price is an fp32 exchange of half the accumulators through LDS and five barriers per
+// 128-pixel tile -- 7 of its 11 us per tile, with one block per CU and nothing to hide them behind.
+// Here the filter slab of a wave is 16 filters x 1152 (the same 144 registers) under v_mfma_f32_16x16x32: eight waves x 16 filters = the layer's
+// 128 filters, every wave reduces over everything itself.  No exchange, two barriers per tile (patch landed / output tile complete):
+//   * tile = 8 rows x 16 pixels (one MFMA pixel operand = 16 consecutive pixels of one row), halo patch 10 x 18 pixels x 256 B = 45 KiB,
+//     double-buffered by LDS-DMA one tile ahead, out-of-image pixels zero-filled by the descriptor;
+//   * a fragment (halo row hr, column shift kx, 32-channel step j) is read once and multiplied with the taps ky = 0..2 it serves (output rows
+//     hr - ky): 120 ds_read_b128 per 288 MFMAs and wave; every wave reads the whole patch (960 KiB of LDS reads per tile: 42 % of the port at the
+//     matrix pipe's pace);
+//   * pixel rows are 256 B = 16 slots, slot ^ (halo column & 15): conflict-free for kx = 0 and 2, two 2-way conflicts per instruction for kx = 1
+//     (ds_read_b128 serves lanes {0-3, 12-15, 20-27} together: the k groups' pixel sets shift with kx);
+//   * the accumulators (lane: one pixel, 4 consecutive filters) go through a 32 KiB output tile (8-byte stores, slot ^ (pixel & 15)) to
+//     row-contiguous 16-byte stores; that tile is separate from the patch buffers, so the next tile's MFMAs wait for nothing but their patch.
+constexpr int C3V_HW = 18, C3V_HPIX = 10 * C3V_HW, C3V_PATCH = C3V_HPIX * 256;       // 180 halo pixels, 45 KiB
+constexpr int C3V_NA = 6;                                                             // DMA instructions per lane: 8 waves x 6 >= 45 (4 pixels each)
+#ifndef C3V_PF
+#define C3V_PF 3
+#endif
+#ifndef C3V_DBG                    // kernel-development switches (compile time: tools/probes/c3v_probe.py builds variants): 1 no MFMAs, 2 no fragment reads, 4 no epilogue
+#define C3V_DBG 0
+#endif
+// order of the 120 (halo row, kx, j) steps: halo rows 0-4 and 5-9 alternate, so that consecutive steps accumulate into disjoint output rows
+// (a step's MFMAs go to rows hr, hr - 1, hr - 2; the same three again one step later is a dependent chain three MFMAs long)
+#ifdef C3V_SEQ
+__host__ __device__ constexpr int c3v_step(int t) { return t; }
+#else
+__host__ __device__ constexpr int c3v_step(int t) { return (t >> 1) + (t & 1) * 60; }
+#endif
+#ifdef C3V_NOSB                    // (variant: no scheduling fences around a step's MFMAs)
+#define C3V_SB() do {} while (0)
+#else
+#define C3V_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+constexpr int C3V_OOFF = 2 * C3V_PATCH, C3V_BOFF = C3V_OOFF + 2 * 128 * 256, C3V_LDS = C3V_BOFF + 512;      // two patches, two output tiles, bias
+
+template <class F, int... I> __device__ __forceinline__ void c3_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void c3_static_for(F&& f) { c3_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+template <typename T, bool MASK>
+__global__ __launch_bounds__(512, 2) void c3v_kernel(const C3Args a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    __shared__ __attribute__((aligned(1024))) char smem[C3V_LDS];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int cpx = ceil_div(a.ntiles, 8);
+    const int t_end = min((xcd + 1) * cpx, a.ntiles);
+    int tile = xcd * cpx + lb;
+    if (tile >= t_end) return;
+
+    const i32x4_t rs = c3_rsrc(a.src, a.bytes);
+    const __amdgpu_buffer_rsrc_t rds = make_rsrc(a.dst, a.bytes);
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(MASK ? a.mask : a.dst, MASK ? a.bytes : 0u);
+
+    int lane_d = lane;
+    auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+        const int tx = t % a.tiles_x, q = t / a.tiles_x;
+        const int ty = q % a.tiles_y;
+        b = q / a.tiles_y; y0 = ty * 8; x0 = tx * 16;
+    };
+    // instruction ii = wave + 8 i fills 1 KiB = 4 halo pixels (lane >> 4) x 16 slots (lane & 15); the slot swizzle is applied on the source side
+    auto dma_tile = [&](int t, int buf) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        const int base = ((b * a.H + y0 - 1) * a.W + x0 - 1) * 256;       // may be negative: only used for in-image pixels
+        asm volatile("" : "+v"(lane_d));
+#pragma unroll
+        for (int i = 0; i < C3V_NA; ++i) {
+            const int ii = wave + 8 * i;
+            const int hp = 4 * ii + (lane_d >> 4);
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * C3V_HW;      // hp / 18 for hp < 256
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = ii < 45 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + (((lane_d & 15) ^ (hx & 15)) << 4));
+            if (ii < 45) c3_dma16(rs, lds0 + buf * C3V_PATCH + ii * 1024, ok ? off : URSO_OOB_SHIFT);
+        }
+    };
+
+    // filter slab: rows 16 wave + fr, the 8 channels 32 j + 8 fg .. + 7 of tap t (weights [n][tap][c], urso_conv_weight_prep)
+    i32x4_t wfr[9][4];
+    {
+        const char* wrow = (const char*)a.wgt + (size_t)(16 * wave + fr) * (9 * 128 * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wfr[t][j] = *(const i32x4_t*)(wrow + (t * 128 + 32 * j + 8 * fg) * 2);
+    }
+    if (tid < 128) *(float*)(smem + C3V_BOFF + tid * 4) = a.bias ? a.bias[tid] : 0.f;
+
+    // fragment read addresses: pixel (hr, fr + kx) of the patch, slot (4 j + fg) ^ ((fr + kx) & 15) -- the lane part per kx, hr and j added at use
+    uint32_t ea[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) ea[kx] = (uint32_t)((fr + kx) * 256 + ((fg ^ ((fr + kx) & 15)) << 4));
+    constexpr int NST = 4;                                     // 128 pixels x 16 slots = 2048 vectors / 512 threads
+    // The output tile is double-buffered and its way to memory is deferred by one tile: a tile's epilogue only writes the accumulators into
+    // its LDS tile (and requests the mask vectors); the row-contiguous reads of that tile and the global stores run at the top of the NEXT
+    // tile, behind the barrier that tile needs anyway for its patch -- one barrier per tile, and the stores leave under the next tile's MFMAs.
+    uint32_t so[NST] = {URSO_OOB_SHIFT, URSO_OOB_SHIFT, URSO_OOB_SHIFT, URSO_OOB_SHIFT};
+    i32x4_t mv[NST];
+    auto flush = [&](int ob) {                                 // output tile ob -> memory (so / mv were formed by that tile's epilogue)
+        const char* sO = smem + C3V_OOFF + ob * (128 * 256);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            i32x4_t v = *(const i32x4_t*)(sO + (wave + 8 * i) * 1024 + lane * 16);
+            if constexpr (MASK) {
+                T x[8], m[8];
+                __builtin_memcpy(x, &v, 16); __builtin_memcpy(m, &mv[i], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = Elem<T>::to_f(m[e]) > 0.f ? x[e] : Elem<T>::from_f(0.f);
+                __builtin_memcpy(&v, x, 16);
+            }
+            buf_store16(rds, so[i], v);
+        }
+    };
+    dma_tile(tile, 0);
+    int buf = 0, ob = 0;
+    bool pend = false;
+    while (true) {
+        const bool has_next = tile + bpx < t_end;
+        c3_wait_vm<0>();                                       // this tile's patch (requested one tile ago) and the previous tile's mask vectors
+        c3_barrier();                                          // every wave's part of the patch has landed; the previous output tile is complete
+        if (has_next) dma_tile(tile + bpx, buf ^ 1);
+        if (pend) flush(ob ^ 1);
+        f32x4_t acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint32_t eb[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) eb[kx] = ea[kx] + (uint32_t)(buf * C3V_PATCH);
+        // step s = (halo row hr of 10, column shift kx, 32-channel step j): one fragment for the output rows r = hr - ky, ky = 0..2
+        constexpr int PF = C3V_PF, RING = PF + 1;              // fragments requested PF steps ahead of their MFMAs
+        i32x4_t f[RING];
+        auto rd = [&](i32x4_t& fs, int s) {
+            const int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            if ((s & 3) == 0) asm volatile("" : "+v"(eb[kx]));           // (opaque per (row, kx): no 30 pre-formed addresses next to the 144 filter registers)
+            if (!(C3V_DBG & 2) || s < PF) fs = *(const i32x4_t*)(smem + hr * C3V_HW * 256 + (eb[kx] ^ (uint32_t)(j << 6)));
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t) rd(f[t], c3v_step(t));
+        // (a compile-time step index: as a plain 120-trip loop hipcc leaves the register arrays behind s_set_gpr_idx -- dynamic indexing)
+        c3_static_for<120>([&](auto sc) {
+            constexpr int t = decltype(sc)::value, s = c3v_step(t);
+            if constexpr (t + PF < 120) rd(f[(t + PF) % RING], c3v_step(t + PF));
+            C3V_SB();
+            constexpr int hr = s / 12, kx = (s / 4) % 3, j = s & 3;
+            if (!(C3V_DBG & 1)) {
+                if constexpr (hr >= 0 && hr < 8) Mma<T>::run(wfr[kx][j], f[t % RING], acc[hr]);
+                if constexpr (hr - 1 >= 0 && hr - 1 < 8) Mma<T>::run(wfr[3 + kx][j], f[t % RING], acc[hr - 1]);
+                if constexpr (hr - 2 >= 0 && hr - 2 < 8) Mma<T>::run(wfr[6 + kx][j], f[t % RING], acc[hr - 2]);
+            }
+            C3V_SB();
+        });
+        if (C3V_DBG & 4) { if (!has_next) break; tile += bpx; buf ^= 1; continue; }
+
+        // ---- output tile [128 pixels][16 slots]: the lane's 4 filters (16 wave + 4 fg ..) of pixel 16 r + fr: 8 bytes of slot (2 wave + fg / 2) ^ (pixel & 15)
+        {
+            char* sO = smem + C3V_OOFF + ob * (128 * 256);
+            const f32x4_t bq = *(const f32x4_t*)(smem + C3V_BOFF + (16 * wave + 4 * fg) * 4);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int px = 16 * r + fr;
+                float y0v = acc[r].x + bq.x, y1v = acc[r].y + bq.y, y2v = acc[r].z + bq.z, y3v = acc[r].w + bq.w;
+                if (a.relu) { y0v = fmaxf(y0v, 0.f); y1v = fmaxf(y1v, 0.f); y2v = fmaxf(y2v, 0.f); y3v = fmaxf(y3v, 0.f); }
+                T o[4] = {Elem<T>::from_f(y0v), Elem<T>::from_f(y1v), Elem<T>::from_f(y2v), Elem<T>::from_f(y3v)};
+                i32x2_t ov; __builtin_memcpy(&ov, o, 8);
+                *(i32x2_t*)(sO + px * 256 + ((((2 * wave + (fg >> 1)) ^ (px & 15))) << 4) + (fg & 1) * 8) = ov;
+            }
+        }
+        {
+            int b, y0, x0;
+            tile_origin(tile, b, y0, x0);
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int p = (wave + 8 * i) * 64 + lane, px = p >> 4;
+                const int y = y0 + (px >> 4), x = x0 + (px & 15);
+                so[i] = (y < a.H && x < a.W) ? (uint32_t)(((b * a.H + y) * a.W + x) * 256 + (((p & 15) ^ (px & 15)) << 4)) : URSO_OOB_SHIFT;
+                if constexpr (MASK) mv[i] = buf_load16(rmk, so[i]);
+            }
+        }
+        pend = true;
+        if (!has_next) break;
+        tile += bpx; buf ^= 1; ob ^= 1;
+    }
+    if constexpr (MASK) c3_wait_vm<0>();
+    c3_barrier();                                              // the last output tile is complete
+    flush(ob);
+}
+
 static int c3_device_cus() { return urso_usable_cus(); }      // runtime.hip: the device's CUs, or option `cus`
 
 // 128-channel form: percentage of the tiles' pixels that lie inside the image, for the 4 x 32 (tw = 32) or 8 x 16 (tw = 16) geometry
@@ -478,6 +672,12 @@ int urso_c3_launch(const urso_conv_geom* g, int dt, int relu, const void* src, c
     if (wide) {
 #define URSO_C3W(TT, TWV) do { if (mask) URSO_KLAUNCH((c3w_kernel<TT, true, TWV>), grid, blk, 0, st, a); \
                                else URSO_KLAUNCH((c3w_kernel<TT, false, TWV>), grid, blk, 0, st, a); } while (0)
+        if (tw == 16 && g_urso_opt.c3v) {
+            // 8 x 16 tiles: the form without the channel-half exchange (c3v_kernel); option c3v = 0 keeps c3w_kernel (A/B, bit-different sums)
+            if (dt == URSO_BF16) { if (mask) URSO_KLAUNCH((c3v_kernel<__bf16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((c3v_kernel<__bf16, false>), grid, blk, 0, st, a); }
+            else { if (mask) URSO_KLAUNCH((c3v_kernel<_Float16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((c3v_kernel<_Float16, false>), grid, blk, 0, st, a); }
+            return urso_check_launch("urso_conv_igemm(3x3, 128 channels, 16-filter waves)");
+        }
         if (dt == URSO_BF16) { if (tw == 32) URSO_C3W(__bf16, 32); else URSO_C3W(__bf16, 16); }
         else { if (tw == 32) URSO_C3W(_Float16, 32); else URSO_C3W(_Float16, 16); }
 #undef URSO_C3W

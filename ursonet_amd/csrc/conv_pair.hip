@@ -475,8 +475,9 @@ bool urso_pair_single_fits(const urso_conv_geom* g, int dt, int flags, const voi
         g->OH != g->H || g->OW != g->W) return false;
     const long long M = (long long)g->B * g->OH * g->OW;
     if (M <= 0 || M * g->N * 2 >= 0x7FFFFF00ll) return false;
-    if (g->C == PairS4::CM) return g->N >= PairS4::CW && g->N % PairS4::CW == 0 && M % PairS4::BM == 0;
-    if (g->C == PairS5::CM) return g->N >= PairS5::CW && g->N % PairS5::CW == 0 && M % PairS5::BM == 0;
+    // option pair_single (A/B): bit 0 the stage-4 single layers (256 channels), bit 1 the stage-5 ones (512) here; cleared, conv_pwx.hip gets them
+    if (g->C == PairS4::CM) return (g_urso_opt.pair_single & 1) && g->N >= PairS4::CW && g->N % PairS4::CW == 0 && M % PairS4::BM == 0;
+    if (g->C == PairS5::CM) return (g_urso_opt.pair_single & 2) && g->N >= PairS5::CW && g->N % PairS5::CW == 0 && M % PairS5::BM == 0;
     if (mbits) return false;                                  // stages 2-3 run that layer inside the fused backward pair
     return g->N == 4 * g->C && urso_conv_pair_ok(M, dt, g->C, g->N) != 0;
 }

@@ -314,7 +314,8 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
     if (mode == 1) {
         // the HBM-bound c -> 4c layers stay where they are (register-filter kernel / conv_pw.hip); this kernel takes the reduction-heavy
         // ones: K >= 512 with at least 128 filters, on pixel counts where a 160-row tile grid fills the chip
-        if (K < 512 || N < 128 || M < 160 * 64) return 0;
+        const bool s4_wide = K == 256 && N >= 1024 && !(g_urso_opt.pair_single & 1);      // (A/B: the stage-4 c -> 4c layers when conv_pair.hip is told to leave them)
+        if ((K < 512 && !s4_wide) || N < 128 || M < 160 * 64) return 0;
     }
     PxArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst; a.bits_out = bits_out;

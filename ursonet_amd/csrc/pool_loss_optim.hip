@@ -558,6 +558,17 @@ __global__ void expand2_kernel(int B, int H, int W, int rv, const i32x4_t* __res
     }
 }
 
+// the same, writing ONLY the even pixels: the caller cleared the dense buffer once and nothing else ever writes it
+__global__ void scatter2_kernel(int B, int H, int W, int rv, const i32x4_t* __restrict__ in, i32x4_t* __restrict__ out) {
+    const int OH = H / 2, OW = W / 2;
+    const uint32_t total = (uint32_t)B * OH * OW * rv;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int v = (int)(i % (uint32_t)rv); uint32_t p = i / (uint32_t)rv;
+        const int ox = (int)(p % (uint32_t)OW); p /= (uint32_t)OW; const int oy = (int)(p % (uint32_t)OH); const int b = (int)(p / (uint32_t)OH);
+        out[(((size_t)b * H + 2 * oy) * W + 2 * ox) * rv + v] = in[i];
+    }
+}
+
 // The ReLU bit mask (or any per-pixel byte rows) of the pixels a stride-2 pointwise layer samples: out[b][y/2][x/2][:] = in[b][y][x][:].
 extern "C" int urso_rows_subsample2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
     if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
@@ -598,4 +609,16 @@ extern "C" int urso_rows_expand2(int B, int H, int W, int row_bytes, const void*
     ProfScope ps(st, URSO_K_POOL, 0, (double)total * 16 * 1.25);
     URSO_KLAUNCH(expand2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
     return urso_check_launch("urso_rows_expand2");
+}
+
+extern "C" int urso_rows_scatter2(int B, int H, int W, int row_bytes, const void* in_d, void* out_d, void* stream) {
+    if (!in_d || !out_d || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || row_bytes <= 0 || (row_bytes & 15) ||
+        ((((uintptr_t)in_d) | ((uintptr_t)out_d)) & 15)) { urso_set_error("urso_rows_scatter2: bad argument (even H, W; 16-byte rows)"); return URSO_EINVAL; }
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (row_bytes / 16);      // vectors written (the even pixels); the dense index must fit as well
+    if ((size_t)B * H * W * (row_bytes / 16) >= 0x7FFFFFFFull) { urso_set_error("urso_rows_scatter2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
+    if (total >= 0x7FFFFFFFull) { urso_set_error("urso_rows_scatter2: tensor too large for 32-bit indexing"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_POOL, 0, (double)total * 32);
+    URSO_KLAUNCH(scatter2_kernel, dim3(pool_blocks(total)), dim3(256), 0, st, B, H, W, row_bytes / 16, (const i32x4_t*)in_d, (i32x4_t*)out_d);
+    return urso_check_launch("urso_rows_scatter2");
 }

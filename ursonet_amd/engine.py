@@ -645,8 +645,10 @@ class Engine(object):
                     raise AssertionError("unexpected second residual consumer for %s" % node.name)
                 if R.spec.relu and c.dst.compact is not None and c.dst.residual_needs_dense:
                     # no fused pair on the residual side: hand over the dense form (zeros written once, by the expansion)
-                    c.dst.grad_dense = torch.empty(c.dst.numel, dtype=self.tdt, device=dev)
-                    self.bwd_ops.append((None, lambda X=c.dst: hip.rows_expand2(B, X.compact[0], X.compact[1], X.spec.c * 2, X.grad, X.grad_dense)))
+                    # (the dense form is zero off the even grid in every step and nothing else writes it: cleared once, here; a step rewrites
+                    # the even pixels only -- urso_rows_scatter2, a quarter of the bytes of the full expansion urso_rows_expand2)
+                    c.dst.grad_dense = torch.zeros(c.dst.numel, dtype=self.tdt, device=dev)
+                    self.bwd_ops.append((None, lambda X=c.dst: hip.rows_scatter2(B, X.compact[0], X.compact[1], X.spec.c * 2, X.grad, X.grad_dense)))
                     self.labels["bwd"].append("expand:" + node.name)
                     R.pending = c.dst.grad_dense
                 elif R.spec.relu:
@@ -737,9 +739,19 @@ class Engine(object):
                 mask = (X.bits if X.bits is not None else X.data) if X.spec.relu else None
                 mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
                 if getattr(c, "gd_scatter", False):
-                    if add is None:                       # first contribution: everything off the sampled grid is zero
-                        self.bwd_ops.append((None, lambda t=dstg: hip.zero_fill(t)))
-                        self.labels["bwd"].append("zero:" + node.name)
+                    if add is None:
+                        # first (and only) contribution: everything off the sampled grid is zero -- and STAYS zero: the scattered data gradient
+                        # writes nothing but the sampled pixels, the tensor has a gradient buffer of its own and no other launch writes it, so
+                        # the buffer is cleared ONCE, here, instead of by a fill launch in every step (rounds 2-4: three launches, 33 us per
+                        # cfg2 step, 150 MB written for nothing).  URSO_ZERO_EVERY_STEP=1 restores the per-step fill (A/B, debugging).
+                        dstg.zero_()
+                        # (only when EVERY launch that writes this buffer is such a scattered data gradient: a dense one accumulating in place
+                        # behind this one would leave its values off the grid for the next step to find)
+                        writers = [cc for cc in self.convs.values() if cc.src is X and getattr(cc, "gd", None) is not None]
+                        once = all(getattr(cc, "gd_scatter", False) for cc in writers) and not any(cc.res is X for cc in self.convs.values())
+                        if not once or os.environ.get("URSO_ZERO_EVERY_STEP", "0") == "1":
+                            self.bwd_ops.append((None, lambda t=dstg: hip.zero_fill(t)))
+                            self.labels["bwd"].append("zero:" + node.name)
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg, mflag=mflag:

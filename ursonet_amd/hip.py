@@ -147,6 +147,7 @@ _SIGS = {
     "urso_conv_pointwise_sampled": (_i, [_gp, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _vp]),
     "urso_rows_subsample2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_rows_expand2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "urso_rows_scatter2": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "urso_zero_fill": (_i, [_vp, C.c_size_t, _vp]),
     "urso_rgb_to_grey3": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "urso_sim2real_op": (_i, [_i, _i, _i, _vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
@@ -173,7 +174,7 @@ def _chk(rc, what):
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "stem", "stem_pool", "cus")
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "c3v", "stem", "stem_pool", "cus")
 
 
 def set_option(name, value):
@@ -613,6 +614,11 @@ def zero_fill(t, stream=None):
 def rows_expand2(B, H, W, row_bytes, src, dst, stream=None):
     """urso_rows_expand2: dst[b, y, x, :] = src[b, y/2, x/2, :] at even (y, x), zero elsewhere."""
     _chk(_lib.urso_rows_expand2(B, H, W, row_bytes, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rows_expand2")
+
+
+def rows_scatter2(B, H, W, row_bytes, src, dst, stream=None):
+    """urso_rows_scatter2: dst[b, 2y, 2x, :] = src[b, y, x, :]; every other pixel of dst is left as it is (cleared once by the caller)."""
+    _chk(_lib.urso_rows_scatter2(B, H, W, row_bytes, ptr(src), ptr(dst), stream_ptr(stream)), "urso_rows_scatter2")
 
 
 def rows_subsample2(B, H, W, row_bytes, src, dst, stream=None):
