@@ -71,6 +71,11 @@ int         urso_abi_version(void);           /* bumped on any signature or data
  *                     workgroups hold) BEFORE it plans a step, so that a CU held by RCCL never gives a statically partitioned tile
  *                     stream a second wave; split counts (urso_*_splits, urso_conv_wgrad_ws_bytes) follow it, so it must not change
  *                     between planning and launching
+ *   bneck (1)         conv_bneck.hip for bottleneck_layer (3x3 / stride 2 / <= 32 filters, net.py:639-640): bit 0 its data gradient by parity
+ *                     class of the input pixel (only the real taps; bit-identical to the dilated general form), bit 1 its forward pass in
+ *                     one launch without a split-K workspace (slower than the split-K pair at cfg2: opt-in)
+ *   dense (1)         conv_dense.hip skinny GEMM (<= 32 rows) for the Dense heads and their data gradients; host plans may then put the
+ *                     layers of one depth into one urso_dense_multi launch (read by ursonet_amd/engine.py)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library
  *                     itself never fuses behind the caller's back); 1 also lets the stage-2 backward pair accumulate the block-closing
  *                     layer's weight gradient (urso_conv_pair_wgrad) and the first stage-2 forward pair take the projection shortcut in
@@ -222,6 +227,23 @@ int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, cons
  * fixed order (deterministic, reproducible from launch to launch).  CONTRACT: the first 4 KiB of that workspace are hand-over flags
  * -- zero on entry, left zero on return; a workspace shared with other entry points must be re-zeroed before the call.  Without a
  * workspace every block walks whole tiles. */
+/* Several Dense layers of the heads in ONE launch (net.py:288-352: 'loc_dense_0' / 'ori_dense_0' read the same flattened bottleneck
+ * features, 'loc_final' / 'ori_final' are independent of each other; conv_dense.hip): per layer
+ *     dst[M][N] = epilogue(src0 [M][K0] wgt0^T + (src1 [M][K1] wgt1^T) + bias + add), M <= 32,
+ * wgt* in the [N][K] layouts urso_conv_weight_prep writes (wf forward, wd for a data gradient), flags = URSO_EPI_RELU / URSO_EPI_OUT_F32,
+ * mask = a dt tensor like dst (keep where > 0), applied last as in urso_conv_igemm.  The optional SECOND segment (src1 != NULL) makes the
+ * data gradient into a tensor two branches read one layer: dX = dZ_loc Wd_loc^T + dZ_ori Wd_ori^T, with no accumulate between launches.
+ * A layer with one segment computes exactly what urso_conv_igemm computes for it (same kernel body). */
+#define URSO_DENSE_MULTI_MAX 4
+typedef struct urso_dense_layer {
+    const void* src0; const void* wgt0; const void* src1; const void* wgt1;   /* dt [M][K0], dt [N][K0], optional dt [M][K1], dt [N][K1] */
+    const float* bias;                     /* fp32 [N] or NULL */
+    const void* add; const void* mask;     /* dt [M][N] or NULL */
+    void* dst;                             /* dt [M][N] (fp32 with URSO_EPI_OUT_F32) */
+    int32_t M, N, K0, K1, flags;
+} urso_dense_layer;
+int urso_dense_multi(int nlayers, const urso_dense_layer* layers, int dt, void* stream);
+
 /* Algorithmic FLOPs and bytes of a urso_conv_igemm_ex launch: the figures the launch profiler records and bench.py prices against the roofline
  * (each tensor once; a scattered destination and its residual / mask operands at the computed pixels only; host arithmetic, no GPU needed). */
 int urso_conv_igemm_algorithmic(const urso_conv_geom* g, int dt, int flags, int has_add, int has_mask, double* flops_out, double* bytes_out);

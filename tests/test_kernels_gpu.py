@@ -1440,6 +1440,114 @@ def test_dense_head_skinny_gemm(dt, case):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M", [32, 5])
+def test_dense_heads_in_one_launch(dt, M):
+    """urso_dense_multi (conv_dense.hip): (a) four Dense layers side by side -- loc_dense_0 / ori_dense_0 on the same input, an fp32 final
+    layer padded to 8 outputs, a masked data gradient with a residual operand -- each BIT FOR BIT what urso_conv_igemm's Dense kernel
+    computes for it alone; (b) a layer with two reduction segments (the data gradient into the bottleneck features: dZ_ori Wd_ori^T +
+    dZ_loc Wd_loc^T) against the fp32 CPU reference and against the two-launch form (second launch accumulating in place: one more
+    rounding, so tolerance)."""
+    hip = _hip()
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(7 * M + dt)
+    feat = dev(torch.randn(M, 2560), dt)
+    specs = [(feat, 2560, 1024, hip.EPI_RELU, True, False, False), (feat, 2560, 1024, hip.EPI_RELU, True, False, False),
+             (dev(torch.randn(M, 1024), dt), 1024, 8, hip.EPI_OUT_F32, True, False, False), (dev(torch.randn(M, 4096), dt), 4096, 1024, 0, False, True, True)]
+    layers, singles = [], []
+    for (x, K, N, flags, has_bias, has_add, has_mask) in specs:
+        w = dev(torch.randn(N, K) / K ** 0.5, dt)
+        bias = dev(torch.randn(N) * 0.3) if has_bias else None
+        add = dev(torch.randn(M, N), dt) if has_add else None
+        mask = dev(torch.randn(M, N), dt) if has_mask else None
+        ot = torch.float32 if flags & hip.EPI_OUT_F32 else tdt
+        y = torch.full((M, N), 3.0, dtype=ot, device="cuda")
+        y1 = torch.full((M, N), 5.0, dtype=ot, device="cuda")
+        layers.append(dict(src0=x, wgt0=w, K0=K, N=N, M=M, bias=bias, add=add, mask=mask, dst=y, flags=flags))
+        hip.conv_igemm(hip.geom(M, 1, 1, K, 1, 1, N, 1, 1), dt, flags, x, w, bias, add, mask, y1)
+        singles.append(y1)
+    hip.DenseMulti(layers, dt).run()
+    torch.cuda.synchronize()
+    for L, y1 in zip(layers, singles):
+        assert torch.equal(L["dst"], y1)
+    # ---- two segments
+    dz0, dz1 = dev(torch.randn(M, 1024), dt), dev(torch.randn(M, 1024), dt)
+    w0, w1 = dev(torch.randn(2560, 1024) / 32.0, dt), dev(torch.randn(2560, 1024) / 32.0, dt)
+    y = torch.full((M, 2560), 3.0, dtype=tdt, device="cuda")
+    hip.DenseMulti([dict(src0=dz0, wgt0=w0, K0=1024, src1=dz1, wgt1=w1, K1=1024, N=2560, M=M, dst=y)], dt).run()
+    y2 = torch.empty_like(y)
+    g = hip.geom(M, 1, 1, 1024, 1, 1, 2560, 1, 1)
+    hip.conv_igemm(g, dt, 0, dz0, w0, None, None, None, y2)
+    hip.conv_igemm(g, dt, 0, dz1, w1, None, y2, None, y2)
+    torch.cuda.synchronize()
+    ref = dz0.float().cpu() @ w0.float().cpu().T + dz1.float().cpu() @ w1.float().cpu().T
+    assert relerr(y, ref) < (6e-3 if dt == 1 else 8e-4)
+    assert relerr(y2, ref) < (1.2e-2 if dt == 1 else 1.5e-3)
+    with pytest.raises(hip.UrsoHipError):
+        hip.DenseMulti([dict(src0=dz0, wgt0=w0, K0=1024, N=2560, M=64, dst=y)], dt).run()          # more than 32 rows
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(3, 16, 20, 128, 32, 0), (32, 16, 20, 2048, 32, 0), (2, 20, 30, 256, 32, 0), (2, 9, 11, 64, 32, 1), (2, 4, 4, 512, 32, 0), (2, 16, 20, 64, 24, 0)],
+                         ids=["tfsame_small", "cfg2_full", "cfg5_grid", "odd_grid_pad1", "cfg1_r18", "n24"])
+def test_bottleneck_layer_kernels(dt, shape):
+    """conv_bneck.hip through urso_conv_igemm_ex (option bneck: bit 0 = data gradient, default; bit 1 = forward, opt-in): bottleneck_layer (net.py:639-640: 3x3 / stride 2 / SAME, <= 32
+    filters) forward in one launch with the reduction split over the block's waves, and its data gradient by parity class (only the real
+    taps).  Forward against the CPU fp32 reference and the general split-K kernel (bneck = 0; other summation order: tolerance); the data
+    gradient -- same taps in the same order, zero taps skipped -- BIT FOR BIT against the general dilated kernel, with and without the ReLU
+    bit mask of the destination."""
+    hip = _hip()
+    B, H, W, Ci, N, pad = shape
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(B + H + Ci + dt)
+    OH, OW = ((H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1) if pad else (-(-H // 2), -(-W // 2))
+    x = rnd(torch.randn(B, H, W, Ci), dt)
+    w = torch.randn(3, 3, Ci, N) / (9 * Ci) ** 0.5
+    bias = torch.randn(N) * 0.3
+    npad = 32
+    wf, wd, biasf, _ = prep_weights(w, dt, bias, None, npad=npad)
+    g = hip.geom(B, H, W, Ci, OH, OW, npad, 3, 3, 2, 2, pad, pad)
+    ref = _ref_conv(x, rnd(w, dt), 2, (pad, pad), OH, OW) + bias
+    xd = dev(x, dt)
+    outs = []
+    for bneck in (3, 0):
+        ws = torch.empty(hip.conv_igemm_ws_bytes(g, dt) // 4 + 4, dtype=torch.float32, device="cuda")
+        for relu in (0, hip.EPI_RELU):
+            y = torch.full((B, OH, OW, npad), 3.0, dtype=tdt, device="cuda")
+            with hip.options(bneck=bneck):
+                hip.conv_igemm_ex(g, dt, relu, xd, wf, biasf, None, None, y, None, ws)
+            torch.cuda.synchronize()
+            r = torch.relu(ref) if relu else ref
+            assert relerr(y[..., :N], r) < TOL[dt], (bneck, relu)
+            assert float(y[..., N:].float().abs().max()) == 0.0 if N < npad else True       # padded filters: zero rows, zero bias
+            outs.append(y.float())
+    assert float((outs[0] - outs[2]).abs().max()) <= TOL[dt] * float(outs[2].abs().max())
+    # ---- data gradient: dz [B, OH, OW, 32] -> dx [B, H, W, Ci], gather form with dilation 2
+    dz = dev(torch.randn(B, OH, OW, npad), dt)
+    if N < npad:
+        dz[..., N:] = 0
+    gd = hip.geom(B, OH, OW, npad, H, W, Ci, 3, 3, 1, 1, 2 - pad, 2 - pad, 2, 2)
+    xr = torch.relu(xd.float()).to(tdt)
+    xpos = (xr.float() > 0).reshape(-1, 8).to(torch.int32)
+    xbits = (xpos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    got = {}
+    for bneck in (1, 0):
+        for mb in (0, 1, 2):                                  # no mask, ReLU bit mask, mask tensor (the destination's own activation)
+            dx = torch.full((B, H, W, Ci), 3.0, dtype=tdt, device="cuda")
+            with hip.options(bneck=bneck):
+                hip.conv_igemm_ex(gd, dt, hip.EPI_MASK_BITS if mb == 1 else 0, dz, wd, None, None, (None, xbits, xr)[mb], dx)
+            torch.cuda.synchronize()
+            got[(bneck, mb)] = dx
+    assert torch.equal(got[(1, 0)], got[(0, 0)]) and torch.equal(got[(1, 1)], got[(0, 1)]) and torch.equal(got[(1, 2)], got[(0, 2)])
+    assert torch.equal(got[(1, 1)], got[(1, 2)])
+    assert float((got[(1, 1)].float() != 0).float().mean()) > 0.1
+    # ... and against autograd on the CPU
+    x_r = x.clone().requires_grad_(True)
+    z = _ref_conv(x_r, rnd(w, dt), 2, (pad, pad), OH, OW)
+    (z * dz[..., :N].float().cpu()).sum().backward()
+    assert relerr(got[(1, 0)], x_r.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("shape", [(2, 16, 20, 128, 128), (3, 17, 23, 256, 128), (2, 9, 15, 64, 192), (4, 32, 40, 256, 256), (8, 64, 80, 128, 128),
                                    (2, 16, 20, 512, 512), (1, 7, 94, 128, 64)],
                          ids=["c128", "ragged_c256_n128", "c64_n192", "stage4_rows", "stage3_rows", "stage5_64_groups", "widest_row"])

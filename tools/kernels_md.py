@@ -32,6 +32,9 @@ FAMILIES = [
     ("hwgrad_kernel", "conv_hwgrad.hip", "one (64 ch, 64 filters) x 9 taps gradient group per block in registers, 8 waves, 128-virtual-pixel tiles, halo run + offset tables 160 KiB, 1 block/CU", "3x3 weight gradients (>= 128 channels)"),
     ("wgrad_tr64_kernel", "conv_wgrad.hip", "128 (k) x 64 (n) tile, 4 waves, 48 KiB LDS, 3 blocks/CU, split over pixels", "weight gradient, <= 64 filters"),
     ("wgrad_tr_kernel", "conv_wgrad.hip", "128 (k) x 128 (n) tile, 4 waves, 64 KiB LDS, 2 blocks/CU, transposing LDS reads, split over pixels to 512 blocks", "weight gradient (1x1 and 3x3)"),
+    ("bneck_fwd_kernel", "conv_bneck.hip", "16 px x all (<= 32) filters per block, 16 waves split K = 9 C, wave-order sum through LDS", "bottleneck_layer forward (3x3 / stride 2), one launch, no split-K workspace"),
+    ("bneck_dgrad_kernel", "conv_bneck.hip", "parity class x 256 channels x pixel chunk per block, 4 waves x 64 channels, class taps in registers", "bottleneck_layer data gradient: only the 4 / 2 / 2 / 1 real taps of a pixel's parity class"),
+    ("dense_multi_kernel", "conv_dense.hip", "dense_kernel's body, a block belongs to one of <= 4 layers; optional second reduction segment", "Dense heads: the layers of one depth in one launch; the two gradients into the bottleneck features as one layer"),
     ("igemm_kernel", "conv_igemm.hip", "128 x {128,64}, register-staged, split-K + finish", "fp32, Dense heads, bottleneck_layer (small grids)"),
     ("reduce_partials", "conv_wgrad.hip", "batched over a gradient bucket", "fixed-order sum of the weight-gradient partials"),
     ("finalize_", "prep.hip", "batched over a gradient bucket", "dW scale, BN gamma/beta gradients, L2 term"),
@@ -56,7 +59,7 @@ def family(sym):
 
 
 def layer_class(label):
-    m = re.match(r"(fwd|dgrad|wgrad)(?:\+wgrad)?:(.*)", label)
+    m = re.match(r"(fwd|dgrad|wgrad)(?:_heads)?(?:\+wgrad)?:(.*)", label)
     if not m:
         return label.split(":")[0], label
     kind, rest = m.group(1), m.group(2)

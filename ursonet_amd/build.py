@@ -10,7 +10,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # (e.g. "-DURSO_PW_NT=1"), so that two compile-time variants can be compared inside ONE gpurun call on the same box.
 VARIANT = os.environ.get("URSO_LIB_VARIANT", "")
 LIB = os.path.join(LIBDIR, "liburso_hip%s.so" % (("_" + VARIANT) if VARIANT else ""))
-SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_pw.hip", "conv_pwx.hip", "conv_dense.hip", "conv_halo.hip", "conv_halo2.hip", "conv_winograd.hip", "conv_pair.hip", "conv_pairw.hip", "conv_pairx.hip", "conv_pairs.hip", "conv_c3.hip", "conv_c3g.hip", "conv_hwgrad.hip", "conv_stem.hip", "conv_stemw.hip", "conv_wgrad.hip", "prep.hip", "pool_loss_optim.hip", "augment.hip", "bn_train.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "conv_igemm.hip", "conv_pw.hip", "conv_pwx.hip", "conv_dense.hip", "conv_bneck.hip", "conv_halo.hip", "conv_halo2.hip", "conv_winograd.hip", "conv_pair.hip", "conv_pairw.hip", "conv_pairx.hip", "conv_pairs.hip", "conv_c3.hip", "conv_c3g.hip", "conv_hwgrad.hip", "conv_stem.hip", "conv_stemw.hip", "conv_wgrad.hip", "prep.hip", "pool_loss_optim.hip", "augment.hip", "bn_train.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 

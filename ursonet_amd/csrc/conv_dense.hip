@@ -105,3 +105,123 @@ int urso_dense_launch(const urso_conv_geom* g, int dt, int flags, const void* sr
     else { if (o32) URSO_KLAUNCH((dense_kernel<_Float16, true>), grid, blk, 0, st, a); else URSO_KLAUNCH((dense_kernel<_Float16, false>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_conv_igemm(dense)");
 }
+
+// ---------------------------------------------------------------- several Dense layers in one launch (urso_dense_multi)
+// The heads are two branches of the same shape (net.py:288-352: loc_dense_0 / ori_dense_0 read the same flattened bottleneck features,
+// loc_final / ori_final are independent): launched one by one each layer costs 6-11 us of launch + first-load latency for 1-2 us of
+// bytes.  Here up to URSO_DENSE_MULTI_MAX layers run side by side (a block belongs to one layer: blocks [blk0, blk0 + N / 16)), and a layer
+// may have TWO reduction segments (src0 W0^T + src1 W1^T): the data gradient into the tensor both branches read is one layer whose second
+// segment is the other branch (no in-place accumulate between two launches).  Per layer the arithmetic is dense_kernel's: same slabs per
+// wave, same wave-order sum; a two-segment layer adds its segments in order (segment 0's slabs, then segment 1's, dealt round-robin to the
+// waves as one list).
+struct DnmLayer {
+    const void* src[2]; const void* wgt[2]; uint32_t src_bytes[2], wgt_bytes[2]; int K[2];
+    const float* bias; const void* add; const void* mask; void* dst;
+    int M, N, relu, out32, blk0;
+};
+struct DnmArgs { DnmLayer L[URSO_DENSE_MULTI_MAX]; int nlayers; };
+
+template <typename T>
+__global__ __launch_bounds__(512) void dense_multi_kernel(const DnmArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    __shared__ f32x4_t red[8][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < URSO_DENSE_MULTI_MAX; ++i) if (i < a.nlayers && (int)blockIdx.x >= a.L[i].blk0) li = i;
+    const DnmLayer& L = a.L[li];
+    const int n0 = ((int)blockIdx.x - L.blk0) * 16;
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const bool wok = n0 + fr < L.N, a0ok = fr < L.M, a1ok = 16 + fr < L.M;
+    constexpr int UN = URSO_DENSE_UN;
+    const int ns0 = ceil_div(L.K[0], 32), ns1 = L.src[1] ? ceil_div(L.K[1], 32) : 0;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(L.src[0], L.src_bytes[0]), rw0 = make_rsrc(L.wgt[0], L.wgt_bytes[0]);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(L.src[1] ? L.src[1] : L.src[0], L.src[1] ? L.src_bytes[1] : 0u);
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(L.src[1] ? L.wgt[1] : L.wgt[0], L.src[1] ? L.wgt_bytes[1] : 0u);
+    for (int s0 = wave; s0 < ns0 + ns1; s0 += 8 * UN) {
+        i32x4_t fw[UN], fa0[UN], fa1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int sl = s0 + 8 * u;
+            const bool seg1 = sl >= ns0;                              // wave-uniform
+            const int K = seg1 ? L.K[1] : L.K[0];
+            const int k = (seg1 ? sl - ns0 : sl) * 32 + fg * 8;
+            const bool kok = sl < ns0 + ns1 && k + 8 <= K;
+            const uint32_t ko = (uint32_t)k * 2u, rowb = (uint32_t)K * 2u;
+            const uint32_t wo = (wok && kok) ? (uint32_t)(n0 + fr) * rowb + ko : URSO_OOB_SHIFT;
+            const uint32_t o0 = (a0ok && kok) ? (uint32_t)fr * rowb + ko : URSO_OOB_SHIFT;
+            const uint32_t o1 = (a1ok && kok) ? (uint32_t)(16 + fr) * rowb + ko : URSO_OOB_SHIFT;
+            if (seg1) { fw[u] = buf_load16(rw1, wo); fa0[u] = buf_load16(rs1, o0); fa1[u] = buf_load16(rs1, o1); }
+            else      { fw[u] = buf_load16(rw0, wo); fa0[u] = buf_load16(rs0, o0); fa1[u] = buf_load16(rs0, o1); }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            Mma<T>::run(fw[u], fa0[u], acc[0]);
+            Mma<T>::run(fw[u], fa1[u], acc[1]);
+        }
+    }
+    red[wave][0][lane] = acc[0]; red[wave][1][lane] = acc[1];
+    __syncthreads();
+    if (wave != 0) return;
+    const int nb = n0 + fg * 4;
+    if (nb >= L.N) return;
+    f32x4_t bias = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (L.bias) bias = *(const f32x4_t*)(L.bias + nb);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = 16 * t + fr;
+        if (m >= L.M) continue;
+        f32x4_t y = red[0][t][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) y += red[w][t][lane];
+        y += bias;
+        const size_t e = (size_t)m * L.N + nb;
+        T ea[4], em[4];
+        if (L.add) { *(i32x2_t*)ea = *(const i32x2_t*)((const T*)L.add + e); }
+        if (L.mask) { *(i32x2_t*)em = *(const i32x2_t*)((const T*)L.mask + e); }
+        float v[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (L.add) v[r] += Elem<T>::to_f(ea[r]);
+            if (L.relu) v[r] = fmaxf(v[r], 0.f);
+            if (L.mask) v[r] = (Elem<T>::to_f(em[r]) > 0.f) ? v[r] : 0.f;
+        }
+        if (L.out32) *(f32x4_t*)((float*)L.dst + e) = f32x4_t{v[0], v[1], v[2], v[3]};
+        else { T o[4] = {Elem<T>::from_f(v[0]), Elem<T>::from_f(v[1]), Elem<T>::from_f(v[2]), Elem<T>::from_f(v[3])}; *(i32x2_t*)((T*)L.dst + e) = *(i32x2_t*)o; }
+    }
+}
+
+extern "C" int urso_dense_multi(int nlayers, const urso_dense_layer* layers, int dt, void* stream) {
+    if (nlayers < 1 || nlayers > URSO_DENSE_MULTI_MAX || !layers || (dt != URSO_BF16 && dt != URSO_F16)) {
+        urso_set_error("urso_dense_multi: 1..%d layers, 16-bit dt", URSO_DENSE_MULTI_MAX); return URSO_EINVAL; }
+    DnmArgs a;
+    a.nlayers = nlayers;
+    int blocks = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const urso_dense_layer& s = layers[i];
+        DnmLayer& L = a.L[i];
+        if (!s.src0 || !s.wgt0 || !s.dst || s.M < 1 || s.M > 32 || s.N < 4 || (s.N % 4) || s.K0 < 8 || (s.K0 % 8) || (s.src1 && (!s.wgt1 || s.K1 < 8 || (s.K1 % 8))) ||
+            (long long)s.N * (s.K0 + (s.src1 ? s.K1 : 0)) >= (1ll << 30)) {
+            urso_set_error("urso_dense_multi: layer %d: M <= 32, N %% 4 == 0, K %% 8 == 0, src / wgt / dst required", i); return URSO_EINVAL; }
+        L.src[0] = s.src0; L.wgt[0] = s.wgt0; L.K[0] = s.K0; L.src_bytes[0] = (uint32_t)((size_t)s.M * s.K0 * 2); L.wgt_bytes[0] = (uint32_t)((size_t)s.N * s.K0 * 2);
+        L.src[1] = s.src1; L.wgt[1] = s.src1 ? s.wgt1 : nullptr; L.K[1] = s.src1 ? s.K1 : 0;
+        L.src_bytes[1] = s.src1 ? (uint32_t)((size_t)s.M * s.K1 * 2) : 0u; L.wgt_bytes[1] = s.src1 ? (uint32_t)((size_t)s.N * s.K1 * 2) : 0u;
+        L.bias = s.bias; L.add = s.add; L.mask = s.mask; L.dst = s.dst; L.M = s.M; L.N = s.N;
+        L.relu = (s.flags & URSO_EPI_RELU) ? 1 : 0; L.out32 = (s.flags & URSO_EPI_OUT_F32) ? 1 : 0;
+        if (s.flags & ~(URSO_EPI_RELU | URSO_EPI_OUT_F32)) { urso_set_error("urso_dense_multi: layer %d: only URSO_EPI_RELU / URSO_EPI_OUT_F32", i); return URSO_EINVAL; }
+        L.blk0 = blocks;
+        blocks += ceil_div(s.N, 16);
+        const double Kt = (double)s.K0 + (s.src1 ? s.K1 : 0);
+        flops += 2.0 * s.M * s.N * Kt;
+        bytes += 2.0 * (s.M * Kt + s.N * Kt) + (double)s.M * s.N * (L.out32 ? 4 : 2) * (1 + (s.add ? 1 : 0) + (s.mask ? 1 : 0));
+    }
+    for (int i = nlayers; i < URSO_DENSE_MULTI_MAX; ++i) { a.L[i] = a.L[0]; a.L[i].blk0 = 0x7FFFFFFF; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
+    const dim3 grid(blocks), blk(512);
+    if (dt == URSO_BF16) URSO_KLAUNCH((dense_multi_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((dense_multi_kernel<_Float16>), grid, blk, 0, st, a);
+    return urso_check_launch("urso_dense_multi");
+}

@@ -411,6 +411,10 @@ int urso_hconv_launch(const urso_conv_geom* g, int dt, int relu, const void* src
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, void* ws, size_t ws_bytes,
                       hipStream_t st);
 size_t urso_hconv_ws_bytes();
+bool urso_bneck_fwd_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);                                 // conv_bneck.hip
+int urso_bneck_fwd_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, void* dst, hipStream_t st);
+bool urso_bneck_dgrad_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask);
+int urso_bneck_dgrad_launch(const urso_conv_geom* g, int dt, int flags, const void* dz, const void* wd, const void* mask, void* dst, hipStream_t st);
 bool urso_dense_fits(const urso_conv_geom* g, int dt, int flags, int pointwise, long long M);                                      // conv_dense.hip
 int urso_dense_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, const void* add,
                       const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, hipStream_t st);
@@ -577,6 +581,10 @@ extern "C" int urso_conv_igemm_ex(const urso_conv_geom* g, int dt, int flags,
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
     if (urso_dense_fits(g, dt, flags, a.pointwise, a.M))          // Dense heads: <= 32 rows, weights streamed once (conv_dense.hip)
         return urso_dense_launch(g, dt, flags, src_d, wgt_d, bias_d, add_d, mask_d, dst_d, a.src_bytes, a.wgt_bytes, a.dst_bytes, st);
+    if (urso_bneck_fwd_fits(g, dt, flags, add_d, mask_d))         // bottleneck_layer: 16 pixels x all filters per block, K over 16 waves (conv_bneck.hip)
+        return urso_bneck_fwd_launch(g, dt, flags, src_d, wgt_d, bias_d, dst_d, st);
+    if (urso_bneck_dgrad_fits(g, dt, flags, add_d, mask_d))       // ... and its data gradient by parity class
+        return urso_bneck_dgrad_launch(g, dt, flags, src_d, wgt_d, mask_d, dst_d, st);
     // 16-bit layers with the vector epilogue, whole-tap K-tiles and no split-K: the DMA-staged kernel of conv_pw.hip
     {
         const int use_pw = g_urso_opt.pw_kernel;     // 0 off, 1 pointwise only, 2 + whole-tap convs, 3 + the stem

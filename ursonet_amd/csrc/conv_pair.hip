@@ -92,6 +92,9 @@ using PairS5 = PairShape<512, 8, 32, 3, 256>;
 // VAR 0: the pair.  VAR 1 / 2: ONLY the first layer (c -> 4c pointwise, MODE 0) with / without a residual operand -- the same input
 // pipeline, filters in registers and row-contiguous stores for the block-closing layers that have no partner (res2c/res3d_branch2c,
 // the stride-1 shortcut conv): urso_conv_igemm_ex sends them here.
+#ifndef PAIR_DBG                   // kernel-development switches (compile time; tools/probes/pair_probe.py builds variants): 1 no MFMAs, 2 no stores of mid,
+#define PAIR_DBG 0                 // 4 no DMA of the add tile, 8 no epilogue arithmetic (the add tile is stored as it came)
+#endif
 template <typename T, int MODE, bool EMIT, typename S, int VAR, bool SPARSE = false>
 __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
     static_assert(!SPARSE || (MODE == 1 && VAR == 0) || (MODE == 0 && VAR != 0), "SPARSE: compact add operand of the backward pair, or sampled second output of a single forward layer");
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
         for (int i = 0; i < NA; ++i) pr_dma16(rs, lds0 + buf * S::ABUF + (wave + NW * i) * 1024, nb + aoff[i]);
         if constexpr (HAS_ADD && !SPADD) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, wb + rgo[i]);
+            for (int i = 0; i < NR; ++i) pr_dma16(ra, lds0 + S::ROFF + buf * S::RBUF + (wave + NW * i) * 1024, (PAIR_DBG & 4) ? URSO_OOB_SHIFT : wb + rgo[i]);
         }
         if constexpr (SPADD) {
             // row -> pixel (b, y, x) of the dense grid; odd y or x: the gradient is zero there (out-of-range offset = zero fill),
@@ -286,14 +289,16 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
             i32x4_t px[PT1];
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt) px[pt] = *(const i32x4_t*)(sA + g1rd[pt][0] + ((((uint32_t)(2 * j + h)) ^ g1rd[pt][1]) << 4));
+            if constexpr (!(PAIR_DBG & 1)) {
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt)
 #pragma unroll
                 for (int c2 = 0; c2 < C2T; ++c2) PrMma32<T>::run(w1f[c2][j], px[pt], acc[pt][c2]);
+            } else { asm volatile("" :: "v"(px[0])); }
         }
         // ---- epilogue 1, in place in the add tile: mid = act(acc + add)
 #pragma unroll
-        for (int pt = 0; pt < PT1; ++pt) {
+        for (int pt = 0; pt < ((PAIR_DBG & 8) ? 0 : PT1); ++pt) {
             uint32_t keep[2] = {0u, 0u};
 #pragma unroll
             for (int c2 = 0; c2 < C2T; ++c2) {
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(S::NW * 64, 2) void pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) v[i] = *(const i32x4_t*)(sR + (wave + NW * i) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < NR; ++i) buf_store16(rmid, wb + rgo[i], v[i]);
+            for (int i = 0; i < NR; ++i) buf_store16(rmid, (PAIR_DBG & 2) ? URSO_OOB_SHIFT : wb + rgo[i], v[i]);
             if constexpr (CMPW) {
                 // the same vectors once more for the pixels at even (y, x): row -> pixel (b, y, x) -> [b][y/2][x/2] of the sampled copy
                 const __amdgpu_buffer_rsrc_t rcmp = make_rsrc((char*)a.cmp + gwide, a.cmp_bytes - gwide);

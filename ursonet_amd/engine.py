@@ -402,6 +402,7 @@ class Engine(object):
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(147, c.N))
         self._fuse_pointwise_pairs()
+        self._fuse_dense_heads()
         self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
         self.bn_ws = torch.empty(max_bn_ws // 8 + 32, dtype=torch.float64, device=dev) if max_bn_ws else None
         self._descs = descs
@@ -500,7 +501,8 @@ class Engine(object):
                                     tail_bytes=self.grad_tail_bytes)
         bucket_of = {ln: k for k, (_, _, names) in enumerate(self.buckets) for ln in names}
         groups = OrderedDict()                      # bucket index -> [conv names], backward order
-        for node in reversed(g.nodes):
+        bwd_order = self._backward_order()
+        for node in bwd_order:
             if node.op == "pool" or node.stem:
                 continue
             folded_bn = node.bn and not self.convs[node.name].batch_bn      # batch-statistics BN finalises its own gamma/beta
@@ -520,7 +522,24 @@ class Engine(object):
                                      (node.residual is not None and need.get(node.residual.id, False)))
         self.grad_needed = need
         self._plan_compact_gradients(need)
-        for node in reversed(g.nodes):
+        # Data gradients of the Dense heads (urso_dense_multi): the layers of one depth behind the bottleneck features share a launch, and the
+        # two gradients into a tensor both branches read (loc_dense_0 / ori_dense_0 -> the bottleneck features) are the two reduction
+        # segments of ONE layer instead of a launch that writes and a launch that accumulates in place
+        dense_lv = self._dense_levels() if self.dense_multi else {}
+        pend_dd = []
+
+        def flush_dense_dgrads():
+            layers = list(pend_dd)
+            del pend_dd[:]
+            for i in range(0, len(layers), hip.DENSE_MULTI_MAX):
+                part = layers[i:i + hip.DENSE_MULTI_MAX]
+                m = hip.DenseMulti(part, dt)
+                self.bwd_ops.append((None, lambda m=m: m.run()))
+                self.labels["bwd"].append("dgrad_heads:" + "+".join(L["name"] for L in part))
+        for node in bwd_order:
+            lvl_n = dense_lv.get(node.name) if node.op != "pool" else None
+            if pend_dd and lvl_n != pend_dd[0]["level"]:
+                flush_dense_dgrads()
             if not need[node.dst.id]:
                 continue                                   # nothing trainable at or below this node
             if node.op == "pool":
@@ -738,6 +757,16 @@ class Engine(object):
                 dstg = X.grad_buf()
                 mask = (X.bits if X.bits is not None else X.data) if X.spec.relu else None
                 mflag = hip.EPI_MASK_BITS if (X.spec.relu and X.bits is not None) else 0
+                if lvl_n is not None and mflag == 0 and not getattr(c, "gd_scatter", False) and self._dense_multi_ok(c):
+                    prev = [L for L in pend_dd if L["dst"] is dstg]
+                    if prev and add is dstg and prev[-1].get("src1") is None:
+                        prev[-1].update(src1=G, wgt1=c.wd, K1=c.npad, name=prev[-1]["name"] + "+" + node.name)
+                    else:
+                        if prev:
+                            flush_dense_dgrads()           # a third writer of the same tensor: accumulate behind the launch that holds the first two
+                        pend_dd.append(dict(name=node.name, level=lvl_n, src0=G, wgt0=c.wd, K0=c.npad, N=node.cin, M=B, add=add, mask=mask, dst=dstg, flags=0))
+                    X.grad_written, X.pending = True, None
+                    continue
                 if getattr(c, "gd_scatter", False):
                     if add is None:
                         # first (and only) contribution: everything off the sampled grid is zero -- and STAYS zero: the scattered data gradient
@@ -759,6 +788,7 @@ class Engine(object):
                                                        self.halo_ws if (c.halo_d and add is None and not mflag) else (self.igemm_ws if c.ws_d else None))))
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
+        flush_dense_dgrads()
         flush_wgrads()
         flush_hw_pair()
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
@@ -873,7 +903,10 @@ class Engine(object):
                 continue
             P = prod[0]
             pw = lambda n: (not n.dense) and n.kh == 1 and n.kw == 1
-            if not (pw(P.node) and P.node.stride == 1 and P.N % 32 == 0 and all(pw(c.node) for c in cons)):
+            # ... or bottleneck_layer behind the trunk's last block: its parity-class data gradient (conv_bneck.hip) takes the bit mask too
+            bn_ = lambda c: (hip.get_option("bneck") and not c.node.dense and c.node.kh == 3 and c.node.kw == 3 and c.node.stride == 2 and
+                             c.npad == 32 and c.node.cin % 64 == 0 and not c.batch_bn)
+            if not (pw(P.node) and P.node.stride == 1 and P.N % 32 == 0 and all(pw(c.node) or bn_(c) for c in cons)):
                 continue
             if level == 1 and P.res is None:
                 continue
@@ -1103,6 +1136,62 @@ class Engine(object):
             return None
         return users[0]
 
+    def _dense_levels(self):
+        """Dense head layers (net.py:288-352) -> depth behind the bottleneck features (1 = reads them)."""
+        g, lv = self.graph, OrderedDict()
+        prod = {n.dst.id: n for n in g.nodes if n.op != "pool"}
+        for n in g.nodes:
+            if n.op == "pool" or not n.dense:
+                continue
+            p = prod.get(n.src.id)
+            lv[n.name] = lv[p.name] + 1 if (p is not None and p.name in lv) else 1
+        return lv
+
+    def _dense_multi_ok(self, c):
+        n = c.node
+        return bool(self.dense_multi and n.dense and not c.batch_bn and c.res is None and n.cin % 8 == 0 and c.npad % 8 == 0 and self.B <= 32)
+
+    def _backward_order(self):
+        """reversed(graph.nodes), with the Dense head layers taken depth by depth (both final layers, then both dense_0 layers ...) instead
+        of branch by branch, so that the data gradients of one depth can share a launch (urso_dense_multi)."""
+        nodes = list(reversed(self.graph.nodes))
+        if not getattr(self, "dense_multi", False):
+            return nodes
+        lv = self._dense_levels()
+        idx = [i for i, n in enumerate(nodes) if n.op != "pool" and n.name in lv]
+        if not idx or idx != list(range(idx[0], idx[0] + len(idx))):
+            return nodes
+        run = sorted(nodes[idx[0]:idx[-1] + 1], key=lambda n: -lv[n.name])        # stable: the branches keep their order inside a depth
+        return nodes[:idx[0]] + run + nodes[idx[-1] + 1:]
+
+    def _fuse_dense_heads(self):
+        """Forward plan rewrite: the Dense layers of one depth behind the bottleneck features (loc_dense_0 + ori_dense_0, loc_final + ori_final;
+        net.py:288-352) run side by side in one launch (urso_dense_multi: the same kernel body per layer, same results).  URSO_DENSE_MULTI=0
+        keeps one launch per layer."""
+        self.dense_multi = (os.environ.get("URSO_DENSE_MULTI", "1") != "0" and self.dt != hip.F32 and bool(hip.get_option("dense")))
+        if not self.dense_multi:
+            return
+        lv = self._dense_levels()
+        convs = [self.convs[nm] for nm in lv]
+        lab = self.labels["fwd"]
+        pos = [lab.index("fwd:" + c.name) if ("fwd:" + c.name) in lab else -1 for c in convs]
+        if (len(convs) < 2 or min(pos) < 0 or sorted(pos) != list(range(min(pos), min(pos) + len(pos))) or
+                not all(self._dense_multi_ok(c) for c in convs)):
+            self.dense_multi = False
+            return
+        ops, labels = [], []
+        for depth in sorted(set(lv.values())):
+            cs = [c for c in convs if lv[c.name] == depth]
+            for i in range(0, len(cs), hip.DENSE_MULTI_MAX):
+                part = cs[i:i + hip.DENSE_MULTI_MAX]
+                m = hip.DenseMulti([dict(src0=c.xin, wgt0=c.wf, K0=c.node.cin, N=c.npad, M=self.B, bias=c.biasf, dst=c.dst.data, flags=c.fwd_flags)
+                                    for c in part], self.dt)
+                ops.append(lambda m=m: m.run())
+                labels.append("fwd:" + "+".join(c.name for c in part))
+        a, b = min(pos), max(pos) + 1
+        self.fwd_ops[a:b] = ops
+        lab[a:b] = labels
+
     def _fuse_pointwise_pairs(self):
         """Forward plan rewrite: a block-closing pointwise layer (c -> 4c, + residual, ReLU; c = 64 or 128: stages 2 and 3) directly
         followed by the next block's opening pointwise layer (4c -> c, ReLU) becomes ONE launch (urso_conv_pair): the block output is written once and
@@ -1174,7 +1263,7 @@ class Engine(object):
         for op in self.opt_ops:
             op()
 
-    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair", "stem", "stem_pool", "c3")
+    PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair", "stem", "stem_pool", "c3", "bneck", "dense")
 
     def _planning_options(self):
         return tuple(hip.get_option(o) for o in self.PLAN_OPTIONS)

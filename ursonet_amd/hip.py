@@ -69,6 +69,13 @@ class ParamDesc(C.Structure):
                                            "dw_raw", "colsum", "dotpart", "gw", "gb", "ggamma", "gbeta")])
 
 
+class DenseLayer(C.Structure):
+    """urso_dense_layer (include/ursonet_hip.h): one Dense layer of a urso_dense_multi launch."""
+    _fields_ = ([(n, C.c_void_p) for n in ("src0", "wgt0", "src1", "wgt1", "bias", "add", "mask", "dst")] +
+                [(n, C.c_int32) for n in ("M", "N", "K0", "K1", "flags")])
+
+
+DENSE_MULTI_MAX = 4
 PB_PREP, PB_REDUCE, PB_FINALIZE_MAT, PB_FINALIZE_VEC = 0, 1, 2, 3
 WGRAD_PART_PAD = 64            # URSO_WGRAD_PART_PAD: floats between consecutive wgrad partial tensors
 _dp = C.POINTER(ParamDesc)
@@ -132,6 +139,7 @@ _SIGS = {
     "urso_comm_wait": (_i, [_vp, _vp]),
     "urso_comm_destroy": (_i, [_vp]),
     "urso_bucket_round_ef": (_i, [_sz, _fp, _fp, _vp, _vp]),
+    "urso_dense_multi": (_i, [_i, C.POINTER(DenseLayer), _i, _vp]),
     "urso_bucket_expand_bf16": (_i, [_sz, _vp, _fp, _vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
@@ -174,7 +182,7 @@ def _chk(rc, what):
         raise UrsoHipError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "c3v", "stem", "stem_pool", "cus")
+OPTION_NAMES = ("pw_kernel", "pw_small", "igemm_shortk", "wgrad_narrow", "wgrad_blocks", "wgrad_pipe", "grid_cap", "hconv", "hconv_dbg", "hconv2", "hconv2_shape", "hconv_streamk", "pair", "c3", "c3v", "stem", "stem_pool", "cus", "bneck")
 
 
 def set_option(name, value):
@@ -235,6 +243,26 @@ def geom(B, H, W, Cin, OH, OW, N, KH, KW, SH=1, SW=1, PH=0, PW=0, DH=1, DW=1, FH
 def conv_igemm(g, dt, flags, src, wgt, bias, add, mask, dst, stream=None):
     _chk(_lib.urso_conv_igemm(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst),
                               stream_ptr(stream)), "urso_conv_igemm")
+
+
+class DenseMulti(object):
+    """Up to DENSE_MULTI_MAX Dense layers of the heads in one launch (urso_dense_multi).  layers: dicts with src0, wgt0, dst, M, N, K0 and
+    optionally src1, wgt1, K1 (a second reduction segment), bias, add, mask, flags -- tensors are kept alive by the object."""
+
+    def __init__(self, layers, dt):
+        assert 1 <= len(layers) <= DENSE_MULTI_MAX
+        self.dt, self.n = dt, len(layers)
+        self.host = (DenseLayer * self.n)()
+        self.keep = []
+        for it, L in zip(self.host, layers):
+            for f in ("src0", "wgt0", "src1", "wgt1", "bias", "add", "mask", "dst"):
+                t = L.get(f)
+                self.keep.append(t)
+                setattr(it, f, t.data_ptr() if t is not None else None)
+            it.M, it.N, it.K0, it.K1, it.flags = int(L["M"]), int(L["N"]), int(L["K0"]), int(L.get("K1", 0)), int(L.get("flags", 0))
+
+    def run(self, stream=None):
+        _chk(_lib.urso_dense_multi(self.n, self.host, self.dt, stream_ptr(stream)), "urso_dense_multi")
 
 
 def bucket_round_ef(g, resid, c, stream=None):
