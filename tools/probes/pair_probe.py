@@ -9,6 +9,8 @@ sys.path.insert(0, ROOT)
 import torch
 from ursonet_amd import hip
 dt = hip.BF16
+for kv in os.environ.get("URSO_OPTS", "").split():          # e.g. URSO_OPTS="pair_s4=1"
+    hip.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 scratch = torch.empty(600 << 20, dtype=torch.uint8, device="cuda")
 out = []
 for (B, H, W, C, N) in [(32, 32, 40, 256, 1024), (32, 16, 20, 512, 2048)]:
@@ -31,4 +33,4 @@ for (B, H, W, C, N) in [(32, 32, 40, 256, 1024), (32, 16, 20, 512, 2048)]:
     for _ in range(10):
         scratch.fill_(1); e0.record(); fn(); e1.record(); torch.cuda.synchronize(); cold += e0.elapsed_time(e1)
     out.append("%dx%dx%d %d->%d: hot %.1f us cold %.1f us" % (B, H, W, C, N, best, cold / 10 * 1e3))
-print("variant %-8s %s" % (os.environ.get("URSO_LIB_VARIANT", "(default)"), "   ".join(out)), flush=True)
+print("variant %-8s %-12s %s" % (os.environ.get("URSO_LIB_VARIANT", "(default)"), os.environ.get("URSO_OPTS", ""), "   ".join(out)), flush=True)
