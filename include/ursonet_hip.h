@@ -233,7 +233,8 @@ int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, cons
  * wgt* in the [N][K] layouts urso_conv_weight_prep writes (wf forward, wd for a data gradient), flags = URSO_EPI_RELU / URSO_EPI_OUT_F32,
  * mask = a dt tensor like dst (keep where > 0), applied last as in urso_conv_igemm.  The optional SECOND segment (src1 != NULL) makes the
  * data gradient into a tensor two branches read one layer: dX = dZ_loc Wd_loc^T + dZ_ori Wd_ori^T, with no accumulate between launches.
- * A layer with one segment computes exactly what urso_conv_igemm computes for it (same kernel body). */
+ * A layer with one segment computes what urso_conv_igemm computes for it (the same kernel body: bit-identical while every reduction of the
+ * launch is shorter than 2048; a longer one is split over 16 waves instead of 8, i.e. summed in another order). */
 #define URSO_DENSE_MULTI_MAX 4
 typedef struct urso_dense_layer {
     const void* src0; const void* wgt0; const void* src1; const void* wgt1;   /* dt [M][K0], dt [N][K0], optional dt [M][K1], dt [N][K1] */

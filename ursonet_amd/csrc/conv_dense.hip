@@ -121,10 +121,12 @@ struct DnmLayer {
 };
 struct DnmArgs { DnmLayer L[URSO_DENSE_MULTI_MAX]; int nlayers; };
 
-template <typename T>
-__global__ __launch_bounds__(512) void dense_multi_kernel(const DnmArgs a) {
+// NW waves per block split the reduction: 8, or 16 when a layer's K is long (the data gradient of ori_final: K = 4096 is 16 slabs per wave at
+// 8 waves -- four dependent rounds of loads; 17 us alone)
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void dense_multi_kernel(const DnmArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ f32x4_t red[8][2][64];
+    __shared__ f32x4_t red[NW][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     int li = 0;
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(512) void dense_multi_kernel(const DnmArgs a) {
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(L.src[0], L.src_bytes[0]), rw0 = make_rsrc(L.wgt[0], L.wgt_bytes[0]);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(L.src[1] ? L.src[1] : L.src[0], L.src[1] ? L.src_bytes[1] : 0u);
     const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(L.src[1] ? L.wgt[1] : L.wgt[0], L.src[1] ? L.wgt_bytes[1] : 0u);
-    for (int s0 = wave; s0 < ns0 + ns1; s0 += 8 * UN) {
+    for (int s0 = wave; s0 < ns0 + ns1; s0 += NW * UN) {
         i32x4_t fw[UN], fa0[UN], fa1[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int sl = s0 + 8 * u;
+            const int sl = s0 + NW * u;
             const bool seg1 = sl >= ns0;                              // wave-uniform
             const int K = seg1 ? L.K[1] : L.K[0];
             const int k = (seg1 ? sl - ns0 : sl) * 32 + fg * 8;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512) void dense_multi_kernel(const DnmArgs a) {
         if (m >= L.M) continue;
         f32x4_t y = red[0][t][lane];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) y += red[w][t][lane];
+        for (int w = 1; w < NW; ++w) y += red[w][t][lane];
         y += bias;
         const size_t e = (size_t)m * L.N + nb;
         T ea[4], em[4];
@@ -220,8 +222,11 @@ extern "C" int urso_dense_multi(int nlayers, const urso_dense_layer* layers, int
     for (int i = nlayers; i < URSO_DENSE_MULTI_MAX; ++i) { a.L[i] = a.L[0]; a.L[i].blk0 = 0x7FFFFFFF; }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(st, URSO_K_IGEMM, flops, bytes);
-    const dim3 grid(blocks), blk(512);
-    if (dt == URSO_BF16) URSO_KLAUNCH((dense_multi_kernel<__bf16>), grid, blk, 0, st, a);
-    else URSO_KLAUNCH((dense_multi_kernel<_Float16>), grid, blk, 0, st, a);
+    int kmax = 0;
+    for (int i = 0; i < nlayers; ++i) kmax = max(kmax, a.L[i].K[0] + a.L[i].K[1]);
+    const bool wide = kmax >= 2048;
+    const dim3 grid(blocks), blk(wide ? 1024 : 512);
+    if (dt == URSO_BF16) { if (wide) URSO_KLAUNCH((dense_multi_kernel<__bf16, 16>), grid, blk, 0, st, a); else URSO_KLAUNCH((dense_multi_kernel<__bf16, 8>), grid, blk, 0, st, a); }
+    else { if (wide) URSO_KLAUNCH((dense_multi_kernel<_Float16, 16>), grid, blk, 0, st, a); else URSO_KLAUNCH((dense_multi_kernel<_Float16, 8>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_dense_multi");
 }

@@ -87,10 +87,11 @@ class _no_gc(object):
 
 
 class Engine(object):
-    def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False, grad_bucket_bytes=128 << 20):
+    def __init__(self, config, mode, batch=None, seed=1234, device=None, randomize_bn=False, grad_bucket_bytes=1 << 40):
         assert mode in ("training", "inference")
-        # gradient buckets: one batched reduction / finalisation per bucket.  One GPU: few big buckets (128 MiB: 8 launches and 0.45 ms against 13
-        # and 0.52 ms at 32 MiB, 41 and 0.68 ms at 8 MiB); ursonet_amd/dp.py re-plans with 32 MiB buckets, which the all-reduces overlap behind
+        # gradient buckets: one batched reduction / finalisation per bucket.  One GPU: ONE bucket (round 5: the 128 MiB default cut ResNet-50's
+        # 128.0 MiB of gradients into a big bucket and a two-layer tail: three more launches, 25 us; 32 MiB: 13 launches and 0.52 ms, 8 MiB: 41 and
+        # 0.68 ms); ursonet_amd/dp.py re-plans with 32 MiB buckets, which the all-reduces overlap behind
         self.grad_bucket_bytes = int(os.environ.get("URSO_GRAD_BUCKET_MIB", 0)) << 20 or int(grad_bucket_bytes)     # (env: A/B only)
         self.grad_tail_bytes = 0                       # > 0: the last bucket (stem side) is capped at this size; set by ursonet_amd/dp.py (plan_buckets)
         if not torch.cuda.is_available():
