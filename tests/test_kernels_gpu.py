@@ -1044,209 +1044,6 @@ def test_3x3_64_channel_layers_register_filter_kernel(case, dt, cap, c3):
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
-@pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0), (32, 32, 40, 0)],
-                         ids=["one_tile", "small", "capped", "multi_tile", "chip"])
-def test_fused_pointwise_pair_forward_and_backward(dt, shape, c):
-    """urso_conv_pair (conv_pair.hip) against a CPU fp32 reference with the same two rounding points (the 256-channel tensor and the
-    64-channel output are each rounded once to the storage dtype), forward form (bias + residual + ReLU, then bias + ReLU, with the
-    emitted ReLU bit mask) and backward form (residual-gradient add + bit mask, then activation mask); and against the two
-    urso_conv_igemm_ex launches it replaces.  'capped' / 'multi_tile' make every block walk several tiles, 'chip' gives every resident block of the chip a few; c = 64 / 128 are the
-    stage-2 (4 waves, 2 LDS stages) and stage-3 (8 waves, 3 LDS stages) shapes of the kernel."""
-    hip = _hip()
-    B, H, W, cap = shape
-    M = B * H * W
-    tdt = hip.TORCH_DT[dt]
-    torch.manual_seed(M + dt)
-    assert hip.conv_pair_ok(M, dt, c, 4 * c) and not hip.conv_pair_ok(M + 1, dt, c, 4 * c) and not hip.conv_pair_ok(M, 0, c, 4 * c)
-    assert not hip.conv_pair_ok(M, dt, 256, 1024) and not hip.conv_pair_ok(M, dt, c, 2 * c)
-    src, add, act = dev(torch.randn(M, c), dt), dev(torch.randn(M, 4 * c), dt), dev(torch.randn(M, c), dt)
-    w1, w2 = dev(torch.randn(4 * c, c) / c ** 0.5, dt), dev(torch.randn(c, 4 * c) / (2 * c ** 0.5), dt)
-    b1, b2 = torch.randn(4 * c, device="cuda") * 0.3, torch.randn(c, device="cuda") * 0.3
-    rnd = lambda t: t.to(tdt).float()
-    f = lambda t: t.float().cpu()
-    tol = 1.2e-2 if dt == 1 else 1.5e-3                     # one output rounding step on values of a few units
-    # ---- forward
-    mid = torch.full((M, 4 * c), 9.0, device="cuda").to(tdt); dst = torch.full((M, c), 9.0, device="cuda").to(tdt)
-    bits = torch.full((M, c // 2), 0xAA, dtype=torch.uint8, device="cuda")
-    with hip.options(grid_cap=cap):
-        hip.conv_pair(M, c, dt, 0, src, w1, b1, add, bits, mid, w2, b2, None, dst)
-        mid_nb = torch.empty_like(mid); dst_nb = torch.empty_like(dst)
-        hip.conv_pair(M, c, dt, 0, src, w1, b1, add, None, mid_nb, w2, b2, None, dst_nb)      # variant without the bit mask
-    torch.cuda.synchronize()
-    assert torch.equal(mid, mid_nb) and torch.equal(dst, dst_nb)
-    ref_mid = rnd(torch.relu(f(src) @ f(w1).T + b1.cpu() + f(add)))
-    assert float((f(mid) - ref_mid).abs().max()) <= tol * max(1.0, float(ref_mid.abs().max()))
-    ref_dst = rnd(torch.relu(f(mid) @ f(w2).T + b2.cpu()))                               # second layer from the STORED first output
-    assert float((f(dst) - ref_dst).abs().max()) <= tol * max(1.0, float(ref_dst.abs().max()))
-    pos = (mid.float() > 0).reshape(-1, 8).to(torch.int32)
-    exp = (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
-    assert torch.equal(bits.reshape(-1), exp) and 0.2 < float(pos.float().mean()) < 0.8
-    g1, g2 = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1), hip.geom(B, H, W, 4 * c, H, W, c, 1, 1)
-    m2, d2, bits2 = torch.empty_like(mid), torch.empty_like(dst), torch.empty_like(bits)
-    hip.conv_igemm_ex(g1, dt, hip.EPI_RELU | hip.EPI_EMIT_BITS, src, w1, b1, add, None, m2, bits2)
-    hip.conv_igemm_ex(g2, dt, hip.EPI_RELU, m2, w2, b2, None, None, d2)
-    torch.cuda.synchronize()
-    assert float((mid.float() - m2.float()).abs().max()) <= tol * float(m2.float().abs().max())
-    assert float((dst.float() - d2.float()).abs().max()) <= 2 * tol * float(d2.float().abs().max())
-    # ---- backward (no bias: bit-identical to the separate launches)
-    gbits = torch.randint(0, 256, (M, c // 2), dtype=torch.uint8, device="cuda")
-    with hip.options(grid_cap=cap):
-        hip.conv_pair(M, c, dt, 1, src, w1, None, add, gbits, mid, w2, None, act, dst)
-    hip.conv_igemm_ex(g1, dt, hip.EPI_MASK_BITS, src, w1, None, add, gbits, m2)
-    hip.conv_igemm_ex(g2, dt, 0, m2, w2, None, None, act, d2)
-    torch.cuda.synchronize()
-    assert torch.equal(mid, m2) and torch.equal(dst, d2)
-    keep = ((gbits.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, 4 * c).float()
-    ref_mid = rnd((f(src) @ f(w1).T + f(add)) * keep)
-    assert float((f(mid) - ref_mid).abs().max()) <= tol * max(1.0, float(ref_mid.abs().max()))
-    ref_dst = rnd((f(mid) @ f(w2).T) * (f(act) > 0))
-    assert float((f(dst) - ref_dst).abs().max()) <= tol * max(1.0, float(ref_dst.abs().max()))
-    assert float((dst.float() != 0).float().mean()) > 0.1
-    with pytest.raises(hip.UrsoHipError):
-        hip.conv_pair(M, c, dt, 1, src, w1, None, add, None, mid, w2, None, act, dst)          # backward form needs the bit mask
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("c", [64, 128, 256, 512], ids=["stage2", "stage3", "stage4", "stage5"])
-@pytest.mark.parametrize("variant", ["add_relu_bits", "add_relu", "plain", "relu_only", "add_maskbits"])
-def test_wide_pointwise_layers_take_the_register_filter_kernel(dt, c, variant):
-    """urso_conv_igemm_ex on a c -> 4c pointwise layer (res{2c,3d,4x}_branch2c, the stride-1 shortcut conv; stage 4 also the masked data
-    gradient of branch2a: 'add_maskbits') runs the single-layer form of conv_pair.hip (option pair, default on): against the CPU fp32
-    reference, against the DMA kernel (pair = 0) and, for an emitted bit mask, bit for bit against (stored output > 0); grid at
-    production size and capped to 8 blocks (multi-tile stream; stage 4 / 5: two / eight block groups of 512 / 256 filters)."""
-    hip = _hip()
-    if variant == "add_maskbits" and c < 256:
-        pytest.skip("stages 2-3 run that layer inside the fused backward pair")
-    B, H, W = (3, 40, 48) if c < 512 else (2, 16, 24)
-    M = B * H * W
-    tdt = hip.TORCH_DT[dt]
-    torch.manual_seed(c + dt)
-    x = dev(torch.randn(B, H, W, c), dt)
-    w = torch.randn(1, 1, c, 4 * c) / c ** 0.5
-    mb = variant == "add_maskbits"
-    wf, _, biasf, _ = prep_weights(w, dt, bias=torch.randn(4 * c) * 0.2)
-    if mb:
-        biasf = None
-    add = dev(torch.randn(B, H, W, 4 * c), dt) if variant.startswith("add") else None
-    relu = variant not in ("plain", "add_maskbits")
-    bits = torch.full((M * 4 * c // 8,), 0x55, dtype=torch.uint8, device="cuda") if variant.endswith("_bits") else None
-    mask = torch.randint(0, 256, (M * 4 * c // 8,), dtype=torch.uint8, device="cuda") if mb else None
-    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_EMIT_BITS if bits is not None else 0) | (hip.EPI_MASK_BITS if mb else 0)
-    g = hip.geom(B, H, W, c, H, W, 4 * c, 1, 1)
-    ref = x.float().cpu().reshape(M, c) @ wf.float().cpu().reshape(4 * c, c).T
-    if biasf is not None:
-        ref = ref + biasf.cpu()
-    if add is not None:
-        ref = ref + add.float().cpu().reshape(M, 4 * c)
-    if relu:
-        ref = torch.relu(ref)
-    if mb:
-        keep = ((mask.cpu().to(torch.int32).reshape(-1, 1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, 4 * c).float()
-        ref = ref * keep
-    outs = {}
-    for pair, cap in ((1, 0), (1, 8), (0, 0)):
-        y = torch.full((B, H, W, 4 * c), 5.0, device="cuda").to(tdt)
-        if bits is not None:
-            bits.fill_(0x55)
-        with hip.options(pair=pair, grid_cap=cap):
-            hip.conv_igemm_ex(g, dt, flags, x, wf, biasf, add, mask, y, bits)
-        torch.cuda.synchronize()
-        assert relerr(y.reshape(M, 4 * c), ref) < (1.2e-2 if dt == 1 else 1.5e-3)
-        if bits is not None:
-            pos = (y.float() > 0).reshape(-1, 8).to(torch.int32)
-            assert torch.equal(bits, (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8))
-        outs[(pair, cap)] = y.float()
-    assert torch.equal(outs[(1, 0)], outs[(1, 8)])
-    assert float((outs[(1, 0)] - outs[(0, 0)]).abs().max()) <= (1.6e-2 if dt == 1 else 2e-3) * float(outs[(0, 0)].abs().max())
-    # the same layer with the sampled second output (urso_conv_pointwise_sampled): dst and bit mask unchanged bit for bit, the second
-    # tensor = the even rows / columns of dst; stages 2-4 (the 512-channel shape and the masked form do not offer it)
-    if not mb and c < 512:
-        for cap in (0, 8):
-            y2 = torch.full((B, H, W, 4 * c), 5.0, device="cuda").to(tdt); ys = torch.full((B, H // 2, W // 2, 4 * c), 5.0, device="cuda").to(tdt)
-            bits2 = torch.full_like(bits, 0x55) if bits is not None else None
-            with hip.options(grid_cap=cap):
-                assert hip.conv_pointwise_sampled_ok(g, dt, flags, add is not None)
-                hip.conv_pointwise_sampled(g, dt, flags, x, wf, biasf, add, y2, bits2, ys)
-            torch.cuda.synchronize()
-            assert torch.equal(y2.float(), outs[(1, 0)]) and torch.equal(ys, y2[:, ::2, ::2]) and (bits is None or torch.equal(bits2, bits))
-    else:
-        assert not hip.conv_pointwise_sampled_ok(g, dt, flags, add is not None)
-
-
-C3W_CASES = [
-    (1, 4, 32, 128, 128, 3, 1, (1, 1), "c3w_one_tile"),
-    (3, 17, 45, 128, 128, 3, 1, (1, 1), "c3w_ragged"),
-    (2, 64, 96, 128, 128, 3, 1, (1, 1), "c3w_multi_tile"),
-    (8, 64, 80, 128, 128, 3, 1, (1, 1), "c3w_stage3_rows"),
-    (2, 21, 50, 128, 128, 3, 1, (1, 1), "c3w_ragged_16"),          # 8 x 16 tiles with partial rows and columns on both borders
-]
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("cap", [0, 8])
-@pytest.mark.parametrize("c3v", [1, 0], ids=["wave16", "halves"])
-@pytest.mark.parametrize("case", C3W_CASES, ids=[c[-1] for c in C3W_CASES])
-def test_3x3_128_channel_layers_register_filter_kernel(case, dt, cap, c3v):
-    """The 128-channel forms of conv_c3.hip, forced on every shape (option c3 = 3: the default policy takes them only where their tiles fit
-    the image width): forward, data gradient with mask and weight gradient against the CPU fp32 reference; ragged sizes, capped grid.
-    'halves' = c3w_kernel (8 waves, each 32 filters x one 64-channel half of the filter in registers, the two halves' sums exchanged through
-    LDS; the only form on 4 x 32 tiles); 'wave16' (option c3v, default) = c3v_kernel on the 8 x 16 tiles (c3w_ragged, c3w_stage3_rows:
-    every wave 16 filters over the whole reduction, no exchange)."""
-    hip = _hip()
-    with hip.options(c3=3, c3v=c3v, grid_cap=cap):
-        test_conv_forward_and_gradients(case, dt)
-
-
-C3_CASES = [
-    (1, 4, 32, 64, 64, 3, 1, (1, 1), "c3_one_tile"),
-    (2, 12, 20, 64, 64, 3, 1, (1, 1), "c3_narrow_image"),        # W < tile width: partial tiles, right border inside the patch
-    (3, 17, 45, 64, 64, 3, 1, (1, 1), "c3_ragged"),              # H % 4 != 0, W % 32 != 0
-    (2, 64, 96, 64, 64, 3, 1, (1, 1), "c3_multi_tile"),
-    (4, 256, 320, 64, 64, 3, 1, (1, 1), "c3_full_size_rows"),    # more tiles than resident blocks at production grid size
-]
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("cap", [0, 8])
-@pytest.mark.parametrize("c3", [1, 0], ids=["regfilter", "dma"])
-@pytest.mark.parametrize("case", C3_CASES, ids=[c[-1] for c in C3_CASES])
-def test_3x3_64_channel_layers_register_filter_kernel(case, dt, cap, c3):
-    """The 64-channel 3x3 layers (res2x_branch2b, forward and -- through the flipped filter -- data gradient with its ReLU mask) in
-    conv_c3.hip (option c3, default on) and, for reference, in the DMA kernel: forward, data gradient and weight gradient against the
-    CPU fp32 reference of test_conv_forward_and_gradients; image sizes that are not multiples of the 4 x 32 tile (zero-filled halo,
-    dropped out-of-image stores) and a grid capped to 8 blocks (double-buffered halo stream across several tiles)."""
-    hip = _hip()
-    with hip.options(c3=c3, grid_cap=cap):
-        test_conv_forward_and_gradients(case, dt)
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-def test_3x3_64_channel_three_buffer_kernel_equals_two_buffer_kernel_bit_for_bit(dt):
-    """c3d_kernel against c3_kernel at the production row length (more tiles than resident blocks: every block walks its stream three buffers
-    deep), forward and masked data gradient: same MFMAs in the same order, so not one bit may differ."""
-    hip = _hip()
-    tdt = hip.TORCH_DT[dt]
-    torch.manual_seed(5 + dt)
-    B, H, W = 6, 250, 318
-    x = dev(torch.randn(B, H, W, 64), dt)
-    wf = dev(torch.randn(64, 3, 3, 64) / 24.0, dt)
-    bias = dev(torch.randn(64) * 0.2)
-    mask = dev(torch.randn(B, H, W, 64), dt)
-    g = hip.geom(B, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 1)
-    outs = []
-    for deep in (1, 0):
-        with hip.options(c3_deep=deep):
-            y, dx = torch.full((B, H, W, 64), 3.0, dtype=tdt, device="cuda"), torch.full((B, H, W, 64), 3.0, dtype=tdt, device="cuda")
-            hip.conv_igemm(g, dt, hip.EPI_RELU, x, wf, bias, None, None, y)
-            hip.conv_igemm(g, dt, 0, x, wf, None, None, mask, dx)
-            torch.cuda.synchronize()
-            outs.append((y, dx))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert 0.2 < float((outs[0][1].float() != 0).float().mean()) < 0.8
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
 @pytest.mark.parametrize("shape", [(2, 8, 16, 0), (4, 8, 24, 0), (4, 64, 80, 8), (8, 64, 80, 0)], ids=["small", "rows_straddle_tiles", "capped", "multi_tile"])
 def test_backward_pair_with_compact_add_operand(dt, c, shape):
     """urso_conv_pair mode 1 with the residual gradient given in COMPACT form (only the even rows / columns of the pixel grid, the
