@@ -244,6 +244,15 @@ typedef struct urso_dense_layer {
     int32_t M, N, K0, K1, flags;
 } urso_dense_layer;
 int urso_dense_multi(int nlayers, const urso_dense_layer* layers, int dt, void* stream);
+/* ... and their weight gradients (Dense: dW = x^T dz over the <= 32 rows of the batch) in one launch: per layer part[k][n] (fp32, row
+ * pitch N) and colpart[n] = sum over rows of dz (may be NULL) -- the layout of a SINGLE split of urso_conv_wgrad_partial for the layer's
+ * forward geometry (B, 1, 1, K) -> (B, 1, 1, N), so urso_param_batch_run finishes them as it does any unsplit layer. */
+typedef struct urso_dense_wgrad_layer {
+    const void* x; const void* dz;         /* dt [M][K], dt [M][N] */
+    float* part; float* colpart;           /* fp32 [K][N], fp32 [N] or NULL */
+    int32_t M, K, N;
+} urso_dense_wgrad_layer;
+int urso_dense_wgrad_multi(int nlayers, const urso_dense_wgrad_layer* layers, int dt, void* stream);
 
 /* Algorithmic FLOPs and bytes of a urso_conv_igemm_ex launch: the figures the launch profiler records and bench.py prices against the roofline
  * (each tensor once; a scattered destination and its residual / mask operands at the computed pixels only; host arithmetic, no GPU needed). */

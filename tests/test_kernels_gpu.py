@@ -1441,6 +1441,35 @@ def test_dense_head_skinny_gemm(dt, case):
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("M", [32, 5])
+def test_dense_head_weight_gradients_in_one_launch(dt, M):
+    """urso_dense_wgrad_multi (conv_dense.hip): dW = x^T dz and the column sums of dz for four Dense layers of the heads' shapes (incl. the final
+    layer padded to 8 outputs and a ragged 2,600 x 1,000) in one launch, against urso_conv_wgrad_partial's single split for the same layer
+    (one 32-deep MFMA step either way) and the fp32 CPU reference."""
+    hip = _hip()
+    torch.manual_seed(3 * M + dt)
+    layers, refs = [], []
+    for (K, N) in [(2560, 1024), (1024, 8), (1024, 4096), (2600, 1000)]:
+        x, dz = dev(torch.randn(M, K), dt), dev(torch.randn(M, N), dt)
+        part, col = torch.full((K * N + 64,), 7.0, device="cuda"), torch.full((N,), 7.0, device="cuda")
+        layers.append(dict(x=x, dz=dz, part=part, colpart=col, M=M, K=K, N=N))
+        refs.append((x.float().cpu().T @ dz.float().cpu(), dz.float().cpu().sum(0)))
+    hip.DenseWgradMulti(layers, dt).run()
+    torch.cuda.synchronize()
+    for L, (rw, rc) in zip(layers, refs):
+        K, N = L["K"], L["N"]
+        assert relerr(L["part"][:K * N].reshape(K, N), rw) < 2e-5 and relerr(L["colpart"], rc) < 2e-5
+        assert float(L["part"][K * N:].min()) == 7.0                                   # nothing written behind the matrix
+        if K % 8 == 0 and N % 8 == 0:
+            g = hip.geom(M, 1, 1, K, 1, 1, N, 1, 1)
+            assert hip.conv_wgrad_splits(g, dt) == 1
+            ws = torch.empty(hip.conv_wgrad_ws_bytes(g, dt) // 4 + 64, device="cuda")
+            hip.conv_wgrad_partial(g, dt, L["x"], L["dz"], ws)
+            torch.cuda.synchronize()
+            assert relerr(L["part"][:K * N], ws[:K * N]) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M", [32, 5])
 def test_dense_heads_in_one_launch(dt, M):
     """urso_dense_multi (conv_dense.hip): (a) four Dense layers side by side -- loc_dense_0 / ori_dense_0 on the same input, an fp32 final
     layer padded to 8 outputs, a masked data gradient with a residual operand -- each what urso_conv_igemm's Dense kernel computes for it

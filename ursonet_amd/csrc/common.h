@@ -53,7 +53,8 @@ int urso_usable_cus();      // the same, or option `cus` when that is smaller: w
 
 // Layers whose weight gradient was cut into at most this many split partials (the grouped launches: 2-8) skip the reduction pass: the batched
 // finalisation sums the partials itself, in the reduction's order (one split-lane up to 48 splits: bit-identical), and the fp32 sum is
-// neither written nor read back
+// neither written nor read back.  (48 instead of 16 -- the eight stage-3 layers with 18 / 32 partials as well -- measured WORSE in round 5:
+// reduction 73 -> 63 us, but finalisation 140 -> 175 + 11 -> 19 us: a thread then walks 32 partials one behind the other.)
 #define URSO_FUSE_REDUCE_MAX 16
 static __host__ __device__ inline bool urso_fuse_reduce(int splits) { return splits > 1 && splits <= URSO_FUSE_REDUCE_MAX; }
 

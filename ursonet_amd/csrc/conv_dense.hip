@@ -230,3 +230,81 @@ extern "C" int urso_dense_multi(int nlayers, const urso_dense_layer* layers, int
     else { if (wide) URSO_KLAUNCH((dense_multi_kernel<_Float16, 16>), grid, blk, 0, st, a); else URSO_KLAUNCH((dense_multi_kernel<_Float16, 8>), grid, blk, 0, st, a); }
     return urso_check_launch("urso_dense_multi");
 }
+
+// ---------------------------------------------------------------- weight gradients of the Dense heads in one launch (urso_dense_wgrad_multi)
+// dW[k][n] = sum_m x[m][k] dz[m][n] with M <= 32 rows: the whole reduction is ONE 16x16x32 MFMA step per 16 x 16 output block, the result
+// (9.4 M fp32 at cfg2: 38 MB) is all there is to move.  The general kernel runs each layer as a launch of its own (6-9 us each for 1-3 us
+// of bytes); here a block owns 64 k x 64 n of one layer, its 4 waves 16 k each; both operands are gathered transposed straight from the
+// (L2-resident, <= 256 KB) activation / gradient matrices, element by element.  colsum[n] = sum_m dz[m][n] in row order, by the blocks of k-tile 0.
+// Output layout = a single split of urso_conv_wgrad_partial: part[k][n] (row pitch N) + colpart[n].
+struct DwmLayer { const void* x; const void* dz; float* part; float* colpart; int M, K, N, blk0, ntn; };
+struct DwmArgs { DwmLayer L[URSO_DENSE_MULTI_MAX]; int nlayers; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_wgrad_multi_kernel(const DwmArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit element types only");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < URSO_DENSE_MULTI_MAX; ++i) if (i < a.nlayers && (int)blockIdx.x >= a.L[i].blk0) li = i;
+    const DwmLayer& L = a.L[li];
+    const int lb = (int)blockIdx.x - L.blk0, kt = lb / L.ntn, nt = lb - kt * L.ntn;
+    const int k0 = kt * 64 + wave * 16, n0 = nt * 64;
+    const T* x = (const T*)L.x; const T* dz = (const T*)L.dz;
+    const T zero = Elem<T>::from_f(0.f);
+    // A: rows = k (k0 + fr), reduction m = 8 fg .. + 7;  B: rows = n (n0 + 16 t + fr), the same m
+    T av[8], bv[4][8];
+    const bool kok = k0 + fr < L.K;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int m = 8 * fg + e;
+        av[e] = (kok && m < L.M) ? x[(size_t)m * L.K + k0 + fr] : zero;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t][e] = (n0 + 16 * t + fr < L.N && m < L.M) ? dz[(size_t)m * L.N + n0 + 16 * t + fr] : zero;
+    }
+    i32x4_t fa; __builtin_memcpy(&fa, av, 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        i32x4_t fb; __builtin_memcpy(&fb, bv[t], 16);
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        Mma<T>::run(fa, fb, acc);                              // D[i = 4 fg + r -> k][j = fr -> n]
+        const int n = n0 + 16 * t + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + 4 * fg + r;
+            if (k < L.K && n < L.N) L.part[(size_t)k * L.N + n] = acc[r];
+        }
+    }
+    if (kt == 0 && L.colpart && tid < 64 && n0 + tid < L.N) {
+        float s = 0.f;
+        for (int m = 0; m < L.M; ++m) s += Elem<T>::to_f(dz[(size_t)m * L.N + n0 + tid]);
+        L.colpart[n0 + tid] = s;
+    }
+}
+
+extern "C" int urso_dense_wgrad_multi(int nlayers, const urso_dense_wgrad_layer* layers, int dt, void* stream) {
+    if (nlayers < 1 || nlayers > URSO_DENSE_MULTI_MAX || !layers || (dt != URSO_BF16 && dt != URSO_F16)) {
+        urso_set_error("urso_dense_wgrad_multi: 1..%d layers, 16-bit dt", URSO_DENSE_MULTI_MAX); return URSO_EINVAL; }
+    DwmArgs a;
+    a.nlayers = nlayers;
+    int blocks = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const urso_dense_wgrad_layer& s = layers[i];
+        if (!s.x || !s.dz || !s.part || s.M < 1 || s.M > 32 || s.K < 1 || s.N < 1) {
+            urso_set_error("urso_dense_wgrad_multi: layer %d: x / dz / part required, 1 <= M <= 32", i); return URSO_EINVAL; }
+        DwmLayer& L = a.L[i];
+        L.x = s.x; L.dz = s.dz; L.part = s.part; L.colpart = s.colpart; L.M = s.M; L.K = s.K; L.N = s.N;
+        L.ntn = ceil_div(s.N, 64); L.blk0 = blocks;
+        blocks += ceil_div(s.K, 64) * L.ntn;
+        flops += 2.0 * s.M * s.K * s.N;
+        bytes += 2.0 * s.M * (s.K + s.N) + 4.0 * s.K * s.N;
+    }
+    for (int i = nlayers; i < URSO_DENSE_MULTI_MAX; ++i) { a.L[i] = a.L[0]; a.L[i].blk0 = 0x7FFFFFFF; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_WGRAD, flops, bytes);
+    if (dt == URSO_BF16) URSO_KLAUNCH((dense_wgrad_multi_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, a);
+    else URSO_KLAUNCH((dense_wgrad_multi_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, a);
+    return urso_check_launch("urso_dense_wgrad_multi");
+}

@@ -537,10 +537,24 @@ class Engine(object):
                 m = hip.DenseMulti(part, dt)
                 self.bwd_ops.append((None, lambda m=m: m.run()))
                 self.labels["bwd"].append("dgrad_heads:" + "+".join(L["name"] for L in part))
+        # ... and their weight gradients (urso_dense_wgrad_multi): leaves of the backward pass, so all of them wait for one launch behind the
+        # last Dense data gradient (or the end of their gradient bucket)
+        pend_dwg = []
+
+        def flush_dense_wgrads():
+            layers = list(pend_dwg)
+            del pend_dwg[:]
+            for i in range(0, len(layers), hip.DENSE_MULTI_MAX):
+                part = layers[i:i + hip.DENSE_MULTI_MAX]
+                m = hip.DenseWgradMulti(part, dt)
+                self.bwd_ops.append((tuple(L["name"] for L in part), lambda m=m: m.run()))
+                self.labels["bwd"].append("wgrad_heads:" + "+".join(L["name"] for L in part))
         for node in bwd_order:
             lvl_n = dense_lv.get(node.name) if node.op != "pool" else None
             if pend_dd and lvl_n != pend_dd[0]["level"]:
                 flush_dense_dgrads()
+            if pend_dwg and lvl_n is None:
+                flush_dense_wgrads()
             if not need[node.dst.id]:
                 continue                                   # nothing trainable at or below this node
             if node.op == "pool":
@@ -647,10 +661,15 @@ class Engine(object):
                         pend_wg.append(cand[-1])
                         if len(pend_wg) >= wg_max:
                             flush_wgrads()
+                    elif lvl_n is not None and c.splits == 1 and gf_w is c.gf and self._dense_multi_ok(c):
+                        pend_dwg.append(dict(name=node.name, x=xw, dz=G, part=c.wg_ws, colpart=c.wg_ws[c.wg_npart:], M=B, K=c.K_raw, N=c.npad))
                     else:
                         self.bwd_ops.append((node.name, lambda c=c, G=G, gf_w=gf_w, xw=xw: hip.conv_wgrad_partial(gf_w, dt, xw, G, c.wg_ws)))
                         self.labels["bwd"].append("wgrad:" + node.name)
                 if node.name in last_of_group:
+                    if pend_dwg and any(L["dz"] is P["dst"] for L in pend_dwg for P in pend_dd):
+                        flush_dense_dgrads()               # (a waiting weight gradient reads what a waiting data gradient writes)
+                    flush_dense_wgrads()
                     flush_wgrads()                         # the bucket's reduction reads every partial of the bucket
                     flush_hw_pair()
                     k = last_of_group[node.name]
@@ -790,6 +809,7 @@ class Engine(object):
                 self.labels["bwd"].append("dgrad:" + node.name)
                 X.grad_written, X.pending = True, None
         flush_dense_dgrads()
+        flush_dense_wgrads()
         flush_wgrads()
         flush_hw_pair()
         # the descriptor table is complete: upload it, plan the block maps and resolve the batched placeholders
@@ -872,7 +892,7 @@ class Engine(object):
             return run
         ops = []
         for (tag, op), lab in zip(self.bwd_ops, self.labels["bwd"]):
-            if lab.startswith("wgrad:"):
+            if lab.startswith(("wgrad:", "wgrad_heads:")):
                 op = on_side(op)
             elif lab.split(":")[0] in ("reduce", "finalize_mat", "finalize_vec", "finalize", "unpack"):
                 op = joined(op)

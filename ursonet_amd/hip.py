@@ -75,6 +75,11 @@ class DenseLayer(C.Structure):
                 [(n, C.c_int32) for n in ("M", "N", "K0", "K1", "flags")])
 
 
+class DenseWgradLayer(C.Structure):
+    """urso_dense_wgrad_layer (include/ursonet_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("x", "dz", "part", "colpart")] + [(n, C.c_int32) for n in ("M", "K", "N")]
+
+
 DENSE_MULTI_MAX = 4
 PB_PREP, PB_REDUCE, PB_FINALIZE_MAT, PB_FINALIZE_VEC = 0, 1, 2, 3
 WGRAD_PART_PAD = 64            # URSO_WGRAD_PART_PAD: floats between consecutive wgrad partial tensors
@@ -140,6 +145,7 @@ _SIGS = {
     "urso_comm_destroy": (_i, [_vp]),
     "urso_bucket_round_ef": (_i, [_sz, _fp, _fp, _vp, _vp]),
     "urso_dense_multi": (_i, [_i, C.POINTER(DenseLayer), _i, _vp]),
+    "urso_dense_wgrad_multi": (_i, [_i, C.POINTER(DenseWgradLayer), _i, _vp]),
     "urso_bucket_expand_bf16": (_i, [_sz, _vp, _fp, _vp]),
     "urso_conv_pair_ok": (_i, [C.c_longlong, _i, _i, _i]),
     "urso_conv_pair": (_i, [C.c_longlong, _i, _i, _i, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _vp]),
@@ -263,6 +269,27 @@ class DenseMulti(object):
 
     def run(self, stream=None):
         _chk(_lib.urso_dense_multi(self.n, self.host, self.dt, stream_ptr(stream)), "urso_dense_multi")
+
+
+class DenseWgradMulti(object):
+    """The weight gradients of up to DENSE_MULTI_MAX Dense layers in one launch (urso_dense_wgrad_multi).  layers: dicts with x [M][K], dz [M][N],
+    part (fp32, >= K * N) and colpart (fp32, >= N, or None) tensors and M, K, N."""
+
+    def __init__(self, layers, dt):
+        assert 1 <= len(layers) <= DENSE_MULTI_MAX
+        self.dt, self.n = dt, len(layers)
+        self.host = (DenseWgradLayer * self.n)()
+        self.keep = []
+        for it, L in zip(self.host, layers):
+            assert L["part"].dtype == torch.float32 and L["part"].numel() >= L["K"] * L["N"]
+            for f in ("x", "dz", "part", "colpart"):
+                t = L.get(f)
+                self.keep.append(t)
+                setattr(it, f, t.data_ptr() if t is not None else None)
+            it.M, it.K, it.N = int(L["M"]), int(L["K"]), int(L["N"])
+
+    def run(self, stream=None):
+        _chk(_lib.urso_dense_wgrad_multi(self.n, self.host, self.dt, stream_ptr(stream)), "urso_dense_wgrad_multi")
 
 
 def bucket_round_ef(g, resid, c, stream=None):
