@@ -16,7 +16,8 @@ FAMILIES = [
     ("pw_kernel", "conv_pw.hip", "128 px x {128,64}, 4 waves, 2 LDS-DMA stages 64/48 KiB, 2-3 blocks/CU", "general 16-bit DMA implicit GEMM: pointwise, strided / sampled layers, 3x3 on small grids"),
     ("hconv2_kernel", "conv_halo2.hip", "128 MI virtual px x 64 NJ filters per tile, (MI, NJ) per layer (cfg2: 384 x 128 in stage 4, 384 x 64 in stage 5: one WHOLE tile per CU), 8 waves (32 MI x 32 NJ, 32x32x16 MFMA), halo double buffer + 2- / 4-slot filter ring 160 KiB, one LDS address register per tap", "3x3 / stride-1 layers with >= 128 channels (stages 4-5)"),
     ("hconv_kernel", "conv_halo.hip", "256 virtual px x 128 filters, 8 waves (64x64, 32x32x16 MFMA), halo tile + 3-slot filter ring 160 KiB, 1 block/CU, (tile, chunk) stream-K", "3x3 / stride-1 layers with >= 128 channels (stages 4-5)"),
-    ("c3w_kernel", "conv_c3.hip", "8x16 px x 128 filters, filters in registers, 2 blocks/CU", "3x3 layers with 128 channels (stage 3)"),
+    ("c3v_kernel", "conv_c3.hip", "8x16 px x 128 filters, 8 waves x 16 filters over the whole reduction (no channel-half exchange), deferred output tile: one barrier per tile, 1 block/CU", "3x3 layers with 128 channels (stage 3)"),
+    ("c3w_kernel", "conv_c3.hip", "8x16 / 4x32 px x 128 filters, wave = 32 filters x one channel half, exchange through LDS", "3x3 layers with 128 channels where the 4x32 geometry fits better (option c3v = 0: everywhere)"),
     ("c3_kernel", "conv_c3.hip", "4x32 px x 64 filters, 4 waves, filter (72 KiB) in registers, 72 KiB LDS, 2 blocks/CU", "3x3 layers with 64 channels (stage 2)"),
     ("c3g_kernel", "conv_c3g.hip", "whole 576 x 64 gradient in registers, one partial per block", "3x3 weight gradient, 64 channels"),
     ("pairs_kernel", "conv_pairs.hip", "32-px halves, 4 waves, W1|Ws + W2 in registers, 80 KiB LDS, 2 blocks/CU", "first stage-2 forward pair with the projection shortcut inside"),
@@ -34,6 +35,7 @@ FAMILIES = [
     ("wgrad_tr_kernel", "conv_wgrad.hip", "128 (k) x 128 (n) tile, 4 waves, 64 KiB LDS, 2 blocks/CU, transposing LDS reads, split over pixels to 512 blocks", "weight gradient (1x1 and 3x3)"),
     ("bneck_fwd_kernel", "conv_bneck.hip", "16 px x all (<= 32) filters per block, 16 waves split K = 9 C, wave-order sum through LDS", "bottleneck_layer forward (3x3 / stride 2), one launch, no split-K workspace"),
     ("bneck_dgrad_kernel", "conv_bneck.hip", "parity class x 256 channels x pixel chunk per block, 4 waves x 64 channels, class taps in registers", "bottleneck_layer data gradient: only the 4 / 2 / 2 / 1 real taps of a pixel's parity class"),
+    ("dense_wgrad_multi_kernel", "conv_dense.hip", "64 k x 64 n per block, one 32-deep MFMA step per 16 x 16 outputs, operands gathered transposed from L2", "Dense heads: all four weight gradients in one launch"),
     ("dense_multi_kernel", "conv_dense.hip", "dense_kernel's body, a block belongs to one of <= 4 layers; optional second reduction segment", "Dense heads: the layers of one depth in one launch; the two gradients into the bottleneck features as one layer"),
     ("igemm_kernel", "conv_igemm.hip", "128 x {128,64}, register-staged, split-K + finish", "fp32, Dense heads, bottleneck_layer (small grids)"),
     ("reduce_partials", "conv_wgrad.hip", "batched over a gradient bucket", "fixed-order sum of the weight-gradient partials"),

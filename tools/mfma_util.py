@@ -8,7 +8,7 @@ was executing (SQ_VALU_MFMA_BUSY_CYCLES counts pipe cycles, 32 per v_mfma_f32_32
 gpu_frac uses GRBM_GUI_ACTIVE x 256 CUs x 4 instead (includes idle CUs at the tail of a launch)."""
 import collections, csv, json, sys
 
-FAMILIES = [("stemw_kernel", "conv_stemw (stem weight gradient, un-pool in LDS)"), ("stem_pool_kernel", "conv_stem (7x7 stem + ReLU + 3x3/s2 max-pool in one kernel)"), ("stem_kernel", "conv_stem (7x7 stem, im2col on the LDS read side)"), ("c3g_kernel", "conv_c3g (3x3 weight gradient, 64 channels, gradient in registers)"), ("c3_kernel", "conv_c3 (3x3, 64 channels, filter in registers)"), ("c3w_kernel", "conv_c3 (3x3, 128 channels, filter in registers)"), ("pairw_kernel", "conv_pairw (backward pair + weight gradient)"), ("pairx_kernel", "conv_pairx (backward launch behind a stage's first block)"), ("pairs_kernel", "conv_pairs (forward pair + projection shortcut)"), ("pair_kernel", "conv_pair (fused pointwise pairs)"), ("hconv2_kernel", "conv_halo2 (3x3 halo tile, whole tiles of a per-layer shape)"), ("hconv_kernel", "conv_halo (3x3 halo tile)"), ("pwx_kernel", "conv_pwx (8-wave big-tile pointwise GEMM)"), ("pw_kernel", "conv_pw (DMA implicit GEMM)"), ("igemm_kernel", "conv_igemm (general)"),
+FAMILIES = [("stemw_kernel", "conv_stemw (stem weight gradient, un-pool in LDS)"), ("stem_pool_kernel", "conv_stem (7x7 stem + ReLU + 3x3/s2 max-pool in one kernel)"), ("stem_kernel", "conv_stem (7x7 stem, im2col on the LDS read side)"), ("c3g_kernel", "conv_c3g (3x3 weight gradient, 64 channels, gradient in registers)"), ("c3_kernel", "conv_c3 (3x3, 64 channels, filter in registers)"), ("c3v_kernel", "conv_c3 (3x3, 128 channels, 16 filters per wave)"), ("c3w_kernel", "conv_c3 (3x3, 128 channels, filter in registers)"), ("pairw_kernel", "conv_pairw (backward pair + weight gradient)"), ("pairx_kernel", "conv_pairx (backward launch behind a stage's first block)"), ("pairs_kernel", "conv_pairs (forward pair + projection shortcut)"), ("pair_kernel", "conv_pair (fused pointwise pairs)"), ("hconv2_kernel", "conv_halo2 (3x3 halo tile, whole tiles of a per-layer shape)"), ("hconv_kernel", "conv_halo (3x3 halo tile)"), ("pwx_kernel", "conv_pwx (8-wave big-tile pointwise GEMM)"), ("pw_kernel", "conv_pw (DMA implicit GEMM)"), ("igemm_kernel", "conv_igemm (general)"),
             ("wgrad_group_big_kernel", "wgrad 256x256, several layers per launch"), ("wgrad_group_kernel", "wgrad 128x128, several layers per launch"), ("hwgrad2_kernel", "conv_hwgrad (3x3 weight gradient, two layers per launch)"), ("hwgrad_kernel", "conv_hwgrad (3x3 weight gradient, gradient in registers)"), ("wgrad_tr64_kernel", "wgrad 128x64"), ("wgrad_tr_kernel", "wgrad 128x128"), ("wgrad_kernel", "wgrad fp32")]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)

@@ -6,7 +6,7 @@ dominant kernels up in `by_symbol` (the symbol is what hipKernelNameRefByPtr / r
 import collections, csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ursonet_amd.build import source_hash
-IGEMM = ("igemm_kernel", "pw_kernel", "pwx_kernel", "hconv_kernel", "hconv2_kernel", "pair_kernel", "pairw_kernel", "pairx_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "stem_kernel", "stem_pool_kernel")
+IGEMM = ("igemm_kernel", "pw_kernel", "pwx_kernel", "hconv_kernel", "hconv2_kernel", "pair_kernel", "pairw_kernel", "pairx_kernel", "pairs_kernel", "c3_kernel", "c3w_kernel", "c3v_kernel", "stem_kernel", "stem_pool_kernel", "bneck_fwd_kernel", "bneck_dgrad_kernel", "dense_kernel", "dense_multi_kernel")
 
 
 def load(path, counter):
