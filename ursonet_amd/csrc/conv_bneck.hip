@@ -90,11 +90,10 @@ struct BndArgs {
     int chunks;                          // pixel chunks per class (gridDim.x)
 };
 
-// data gradient: grid = (pixel chunks, C / (64 NW), 4 parity classes), NW waves, wave w = channels 64 NW blockIdx.y + 64 w .. + 63: a block writes
-// 128 NW contiguous bytes of each of its pixels (NW = 16: 2 KiB; with 4 waves the 512-byte pieces 8 KiB apart streamed at 1.9 TB/s)
+// data gradient: grid = (pixel chunks, C / 256, 4 parity classes), 4 waves, wave w = channels 256 blockIdx.y + 64 w .. + 63
 // MASKK: 0 none, 1 mask tensor like dst (keep where > 0), 2 ReLU BIT mask (1 byte per 16-byte vector of dst)
-template <typename T, int MASKK, int NW>
-__global__ __launch_bounds__(NW * 64) void bneck_dgrad_kernel(const BndArgs a) {
+template <typename T, int MASKK>
+__global__ __launch_bounds__(256) void bneck_dgrad_kernel(const BndArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void bneck_dgrad_kernel(const BndArgs a) {
     const int ky0 = (a.PH + py) & 1, kx0 = (a.PW + px) & 1;              // first valid tap index; the other one (if any) is + 2
     const int nky = ky0 == 0 ? 2 : 1, nkx = kx0 == 0 ? 2 : 1;
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz, a.dz_bytes), rw = make_rsrc(a.wd, a.wd_bytes);
-    const int cb = blockIdx.y * (64 * NW) + wave * 64;
+    const int cb = blockIdx.y * 256 + wave * 64;
     // filter fragments: MFMA set s, row 4 fg' + reg <-> channel cb + 16 fg' + 4 s + reg, so that a lane ends up with 16 consecutive
     // channels of its pixel; as the row operand lane (fr, fg) supplies row fr = 4 (fr >> 2) + (fr & 3): channel cb + 16 (fr >> 2) + 4 s + (fr & 3)
     i32x4_t wf[2][2][4];
@@ -218,15 +217,14 @@ int urso_bneck_dgrad_launch(const urso_conv_geom* g, int dt, int flags, const vo
     a.dz = dz; a.wd = wd; a.bits = (const uint8_t*)mask; a.mask = mask; a.dst = dst;
     a.B = g->B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.C = g->N; a.PH = g->PH; a.PW = g->PW;
     a.dz_bytes = (uint32_t)((size_t)g->B * g->H * g->W * 32 * 2); a.wd_bytes = (uint32_t)((size_t)g->N * 9 * 32 * 2);
-    constexpr int NW = 16;
-    const int cblocks = ceil_div(g->N, 64 * NW);
+    const int cblocks = ceil_div(g->N, 256);
     const int npx = g->B * ((g->OH + 1) / 2) * ((g->OW + 1) / 2);          // pixels of the largest class
-    int chunks = max(1, (2 * urso_usable_cus()) / (4 * cblocks));           // ~2 blocks (32 waves) per CU over the 4 classes
+    int chunks = max(1, (4 * urso_usable_cus()) / (4 * cblocks));           // ~4 blocks (16 waves) per CU over the 4 classes
     chunks = min(chunks, ceil_div(npx, 16));
     a.chunks = chunks;
-    const dim3 grid(chunks, cblocks, 4), blk(NW * 64);
-#define URSO_BND(TT) do { if (mk == 2) URSO_KLAUNCH((bneck_dgrad_kernel<TT, 2, NW>), grid, blk, 0, st, a); else if (mk == 1) URSO_KLAUNCH((bneck_dgrad_kernel<TT, 1, NW>), grid, blk, 0, st, a); \
-                          else URSO_KLAUNCH((bneck_dgrad_kernel<TT, 0, NW>), grid, blk, 0, st, a); } while (0)
+    const dim3 grid(chunks, cblocks, 4), blk(256);
+#define URSO_BND(TT) do { if (mk == 2) URSO_KLAUNCH((bneck_dgrad_kernel<TT, 2>), grid, blk, 0, st, a); else if (mk == 1) URSO_KLAUNCH((bneck_dgrad_kernel<TT, 1>), grid, blk, 0, st, a); \
+                          else URSO_KLAUNCH((bneck_dgrad_kernel<TT, 0>), grid, blk, 0, st, a); } while (0)
     if (dt == URSO_BF16) URSO_BND(__bf16); else URSO_BND(_Float16);
 #undef URSO_BND
     return urso_check_launch("urso_conv_igemm(bneck dgrad)");
