@@ -378,6 +378,19 @@ int urso_param_desc_init(urso_param_desc* d, int KH, int KW, int C, int N, int n
 int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, const int32_t* layer_ids, int n_ids,
                           int32_t* blockmap_h, int cap_blocks);
 int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream);
+/* The finalisation phases with the global norm folded in (keras clipnorm, net.py:980-981): block b of the launch ALSO writes the sum of squares
+ * of the gradient values it stored to sqpart_d[b] (fixed order inside the block), so that sum over all slots = |g|^2 without reading the
+ * gradient buffer back: urso_sqnorm_final adds the slots in index order into out_d[0] (what urso_sqnorm leaves there, up to fp32 summation
+ * order).  urso_param_grad_finalize_sq: the per-layer form (the stem), urso_param_grad_finalize_sq_slots(K, N) slots.  Only valid when every
+ * gradient slice is written by these launches and nothing (an all-reduce) changes the buffer afterwards. */
+int urso_param_batch_run_sq(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, float* sqpart_d, void* stream);
+int urso_param_grad_finalize_sq_slots(int K, int N);
+int urso_param_grad_finalize_sq(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
+                                const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
+                                const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
+                                float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                                float* ws_d, size_t ws_bytes, float* sqpart_d, void* stream);
+int urso_sqnorm_final(int nparts, const float* parts_d, float* out_d, void* stream);
 
 /*
  * Weight gradients of SEVERAL 16-bit layers in one launch -- the grouped form of urso_conv_wgrad_partial (same kernel body, same

@@ -467,6 +467,40 @@ def test_training_step_parity_16bit(dtype, tol_out, cos_min):
     assert _cos(np.concatenate(allg), np.concatenate(allr)) > 0.99
 
 
+@pytest.mark.parametrize("case", ["r50_bf16", "r18_f32_quat", "r50_bf16_heads_only", "r50_bf16_adam"])
+def test_gradient_norm_from_the_finalisation_blocks_equals_the_norm_pass(case, monkeypatch):
+    """Engine.fused_sqnorm (one gradient bucket, no all-reduce): the finalisation launches leave per-block sums of squares of every gradient value
+    they store and urso_sqnorm_final adds them -- the 134 MB gradient buffer is not read back for the clip norm.  Against urso_sqnorm over the
+    flat buffer of the same step (another fp32 summation order: 2e-6), against the plan with the separate pass (URSO_FUSE_SQNORM=0: same
+    gradients bit for bit, post-step weights within the norm's rounding), and with frozen layers (their slices are zero and belong to no block)."""
+    from ursonet_amd import hip
+    from ursonet_amd.engine import Engine
+    from ursonet_amd.graph import layer_regex
+    if case == "r18_f32_quat":
+        cfg = make_config(backbone="resnet18", h=128, w=128, batch=2, regress_ori=True, dtype="float32")
+    else:
+        cfg = make_config("resnet50", 128, 192, batch=4, regress_ori=False, ori_bins=4, dtype="bfloat16", lr=1e-2)
+        if case.endswith("adam"):
+            cfg.OPTIMIZER = "ADAM"
+    img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=9)
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("URSO_FUSE_SQNORM", fuse)
+        eng = Engine(cfg, "training", seed=3, randomize_bn=True)
+        if "heads_only" in case:
+            eng.set_trainable(layer_regex("heads"))
+        assert eng.fused_sqnorm == (fuse == "1") and len(eng.buckets) == 1
+        eng.load_batch(img, loc, ori)
+        eng.step(); torch.cuda.synchronize()
+        ref = torch.zeros(1, device="cuda")
+        hip.sqnorm(eng.n_flat, eng.flat_g, eng.sq_ws, ref)
+        torch.cuda.synchronize()
+        assert float(ref) > 0 and abs(float(eng.normsq) - float(ref)) <= 2e-6 * float(ref), (case, fuse, float(eng.normsq), float(ref))
+        res.append((eng.flat_g.clone(), eng.flat_w.clone(), float(eng.normsq)))
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-6 * float(res[1][1].abs().max())
+
+
 def test_frozen_layers_get_no_update():
     """set_trainable('heads') (net.py:1086-1095): backbone weights must not move."""
     from ursonet_amd.engine import Engine

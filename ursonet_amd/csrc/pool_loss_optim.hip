@@ -399,6 +399,13 @@ __global__ void sqnorm_final_kernel(int nb, const float* __restrict__ part, floa
     s = block_sum(s, sh);
     if (threadIdx.x == 0) out[0] = s;
 }
+extern "C" int urso_sqnorm_final(int nparts, const float* parts_d, float* out_d, void* stream) {
+    if (nparts < 1 || !parts_d || !out_d) { urso_set_error("urso_sqnorm_final: bad argument"); return URSO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, URSO_K_OPTIM, 0, (double)nparts * 4);
+    URSO_KLAUNCH(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, nparts, parts_d, out_d);
+    return urso_check_launch("urso_sqnorm_final");
+}
 extern "C" size_t urso_sqnorm_ws_bytes(size_t n) { (void)n; return SQN_BLOCKS * sizeof(float); }
 extern "C" int urso_sqnorm(size_t n, const float* g_d, void* ws_d, size_t ws_bytes, float* out_d, void* stream) {
     if (!g_d || !ws_d || !out_d || ws_bytes < urso_sqnorm_ws_bytes(n)) { urso_set_error("urso_sqnorm: bad argument"); return URSO_EINVAL; }

@@ -193,6 +193,18 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
     return urso_check_launch("urso_stem_wgrad_unpack");
 }
 
+// sum over the block's threads (256), waves in order: every thread gets the total
+__device__ __forceinline__ float block_sum_f(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
 // ------------------------------------------------------------------ parameter-gradient finalisation
 // pass 1: grid (ceil(N/64), KS): gW = s*dw_raw + c*W, partial column dots of W*dw_raw
 // nsum > 1: dwr is the first of `nsum` split partials, `pstride` floats apart, summed here in split order -- the order (and so the bits) of
@@ -200,8 +212,19 @@ extern "C" int urso_stem_wgrad_unpack(int N, const float* dw_packed_d, float* dw
 // pass reading it back
 __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
                                     const float* __restrict__ gamma, const float* __restrict__ var, float eps,
-                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart, int nsum = 1, size_t pstride = 0) {
+                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart, int nsum = 1, size_t pstride = 0,
+                                    float* __restrict__ sqslot = nullptr) {
+    // sqslot != NULL: the block also leaves the sum of squares of the gradient values it stores there (fixed order: a thread's rows, then the
+    // threads in lane order) -- the global-norm pass then has nothing to read back (urso_param_batch_run_sq)
     const int kbeg = by * kb, kend = min(K, kbeg + kb);
+    float sq = 0.f;
+    auto sq4 = [&](const f32x4_t& g) { sq += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w; };
+    auto sq_out = [&]() {
+        if (!sqslot) return;
+        __shared__ float shq[8];
+        const float t = block_sum_f(sq, shq);
+        if (threadIdx.x == 0) *sqslot = t;
+    };
     if (((N | ldn) & 3) == 0) {
         // 16 column quads (64 columns) x 16 row lanes, 16-byte loads/stores; the 16 row lanes are combined in lane order.  A row lane walks
         // its rows (k, k + 16, ...) TWO at a time: both rows' loads (the weight, the gradient and up to 16 split partials each) are issued
@@ -242,6 +265,7 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
                 if (!trainable) g0 = g1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 *(f32x4_t*)(gw + (size_t)k * N + n) = g0;
                 *(f32x4_t*)(gw + (size_t)(k + 16) * N + n) = g1;
+                sq4(g0); sq4(g1);
             }
             if (k < kend) {
                 const f32x4_t ww = *(const f32x4_t*)(w + (size_t)k * N + n);
@@ -250,6 +274,7 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
                 f32x4_t g = s * d + ww * regc;
                 if (!trainable) g = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 *(f32x4_t*)(gw + (size_t)k * N + n) = g;
+                sq4(g);
             }
         }
         red4[tk][tq] = dot;
@@ -260,6 +285,7 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
             for (int i = 1; i < 16; ++i) t += red4[i][tq];
             *(f32x4_t*)(dotpart + (size_t)by * N + n) = t;
         }
+        sq_out();
         return;
     }
     __shared__ float red[4][64];
@@ -273,27 +299,32 @@ __device__ __forceinline__ void finalize_mat_body(int bx, int by, int K, int N, 
             for (int q = 0; q < nsum; ++q) d += dwr[(size_t)q * pstride + (size_t)k * ldn + n];
             const float ww = w[(size_t)k * N + n];
             dot += ww * d;
-            gw[(size_t)k * N + n] = trainable ? (s * d + regc * ww) : 0.f;
+            const float gv = trainable ? (s * d + regc * ww) : 0.f;
+            gw[(size_t)k * N + n] = gv;
+            sq += gv * gv;
         }
     }
     red[tk][tn] = dot;
     __syncthreads();
     if (tk == 0 && n < N) dotpart[(size_t)by * N + n] = red[0][tn] + red[1][tn] + red[2][tn] + red[3][tn];
+    sq_out();
 }
 
 __global__ void finalize_mat_kernel(int K, int N, int ldn, int kb, const float* __restrict__ dwr, const float* __restrict__ w,
                                     const float* __restrict__ gamma, const float* __restrict__ var, float eps,
-                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart) {
-    finalize_mat_body(blockIdx.x, blockIdx.y, K, N, ldn, kb, dwr, w, gamma, var, eps, regc, trainable, gw, dotpart);
+                                    float regc, int trainable, float* __restrict__ gw, float* __restrict__ dotpart, float* __restrict__ sqpart) {
+    finalize_mat_body(blockIdx.x, blockIdx.y, K, N, ldn, kb, dwr, w, gamma, var, eps, regc, trainable, gw, dotpart, 1, 0,
+                      sqpart ? sqpart + blockIdx.y * gridDim.x + blockIdx.x : nullptr);
 }
 
-__global__ void finalize_mat_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+__global__ void finalize_mat_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap, float* __restrict__ sqpart) {
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
     const int gx = ceil_div(d.N, 64);
     const bool fused = urso_fuse_reduce(d.splits);
     finalize_mat_body(local % gx, local / gx, d.K, d.N, d.npad, d.kb, (d.splits == 1 || fused) ? d.part : d.dw_raw, d.w, d.gamma, d.var, d.eps,
-                      d.regc, d.trainable, d.gw, d.dotpart, fused ? d.splits : 1, (size_t)d.K * d.npad + URSO_WGRAD_PART_PAD);
+                      d.regc, d.trainable, d.gw, d.dotpart, fused ? d.splits : 1, (size_t)d.K * d.npad + URSO_WGRAD_PART_PAD,
+                      sqpart ? sqpart + blockIdx.x : nullptr);
 }
 
 // pass 2: one thread per channel
@@ -301,12 +332,14 @@ __device__ __forceinline__ void finalize_vec_body(int n, int N, int ks, const fl
                                     const float* __restrict__ b, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                     float regb, int trainable, int bn_trainable,
-                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta, int nsum = 1, int cstride = 0) {
-    if (n >= N) return;
+                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta, int nsum = 1, int cstride = 0,
+                                    float* __restrict__ sqslot = nullptr) {
+    float sq = 0.f;
+    if (n < N) {
     float cs = 0.f;
     if (colsum) for (int q = 0; q < nsum; ++q) cs += colsum[(size_t)q * cstride + n];        // nsum > 1: the split partials of the column sums, in split order
     const float s = bn_scale(gamma, var, eps, n);
-    if (gb) gb[n] = trainable ? (s * cs + regb * (b ? b[n] : 0.f)) : 0.f;
+    if (gb) { const float v = trainable ? (s * cs + regb * (b ? b[n] : 0.f)) : 0.f; gb[n] = v; sq += v * v; }
     if (ggamma) {
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
         int i = 0;
@@ -315,8 +348,16 @@ __device__ __forceinline__ void finalize_vec_body(int n, int N, int ks, const fl
         for (; i < ks; ++i) d0 += dotpart[(size_t)i * N + n];
         const float dot = (d0 + d1) + (d2 + d3);
         const float rstd = rsqrtf(var[n] + eps);
-        ggamma[n] = bn_trainable ? rstd * (dot + ((b ? b[n] : 0.f) - mean[n]) * cs) : 0.f;
-        gbeta[n] = bn_trainable ? cs : 0.f;
+        const float vg = bn_trainable ? rstd * (dot + ((b ? b[n] : 0.f) - mean[n]) * cs) : 0.f, vb = bn_trainable ? cs : 0.f;
+        ggamma[n] = vg;
+        gbeta[n] = vb;
+        sq += vg * vg + vb * vb;
+    }
+    }
+    if (sqslot) {                                             // (every thread of the block comes here)
+        __shared__ float shq[8];
+        const float t = block_sum_f(sq, shq);
+        if (threadIdx.x == 0) *sqslot = t;
     }
 }
 
@@ -324,17 +365,18 @@ __global__ void finalize_vec_kernel(int N, int ks, const float* __restrict__ dot
                                     const float* __restrict__ b, const float* __restrict__ gamma,
                                     const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                     float regb, int trainable, int bn_trainable,
-                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta) {
-    finalize_vec_body(blockIdx.x * blockDim.x + threadIdx.x, N, ks, dotpart, colsum, b, gamma, mean, var, eps, regb, trainable, bn_trainable, gb, ggamma, gbeta);
+                                    float* __restrict__ gb, float* __restrict__ ggamma, float* __restrict__ gbeta, float* __restrict__ sqpart) {
+    finalize_vec_body(blockIdx.x * blockDim.x + threadIdx.x, N, ks, dotpart, colsum, b, gamma, mean, var, eps, regb, trainable, bn_trainable, gb, ggamma, gbeta,
+                      1, 0, sqpart ? sqpart + blockIdx.x : nullptr);
 }
 
-__global__ void finalize_vec_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
+__global__ void finalize_vec_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap, float* __restrict__ sqpart) {
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
-    if (!d.gb && !d.ggamma) return;
+    if (!d.gb && !d.ggamma) { if (sqpart && threadIdx.x == 0) sqpart[blockIdx.x] = 0.f; return; }
     const bool fused = urso_fuse_reduce(d.splits);
     finalize_vec_body(local * blockDim.x + threadIdx.x, d.N, d.ks, d.dotpart, (d.splits == 1 || fused) ? d.colpart : d.colsum, d.b, d.gamma, d.mean, d.var, d.eps,
-                      d.regb, d.trainable, d.bn_trainable, d.gb, d.ggamma, d.gbeta, fused ? d.splits : 1, d.npad);
+                      d.regb, d.trainable, d.bn_trainable, d.gb, d.ggamma, d.gbeta, fused ? d.splits : 1, d.npad, sqpart ? sqpart + blockIdx.x : nullptr);
 }
 
 // Row splits of the finalisation: a block (64 columns x kb rows) should stream at least ~128 rows (eight rows per row lane) so that its fixed
@@ -349,11 +391,34 @@ static int finalize_ks(int K, int N) {
 }
 extern "C" size_t urso_param_grad_finalize_ws_bytes(int K, int N) { return (size_t)finalize_ks(K, N) * N * sizeof(float) + 256; }
 
+extern "C" int urso_param_grad_finalize_sq_slots(int K, int N) { return ceil_div(N, 64) * finalize_ks(K, N) + ceil_div(N, 256); }
+static int param_grad_finalize_impl(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
+                                        const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
+                                        const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
+                                        float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                                        float* ws_d, size_t ws_bytes, float* sqpart_d, void* stream);
 extern "C" int urso_param_grad_finalize(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
                                         const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
                                         const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
                                         float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
                                         float* ws_d, size_t ws_bytes, void* stream) {
+    return param_grad_finalize_impl(K, N, ldn, dw_raw_d, colsum_d, w_d, b_d, gamma_d, mean_d, var_d, eps, weight_decay, trainable, bn_trainable,
+                                    gw_d, gb_d, ggamma_d, gbeta_d, ws_d, ws_bytes, nullptr, stream);
+}
+extern "C" int urso_param_grad_finalize_sq(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
+                                           const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
+                                           const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
+                                           float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                                           float* ws_d, size_t ws_bytes, float* sqpart_d, void* stream) {
+    if (!sqpart_d) { urso_set_error("urso_param_grad_finalize_sq: sqpart_d required"); return URSO_EINVAL; }
+    return param_grad_finalize_impl(K, N, ldn, dw_raw_d, colsum_d, w_d, b_d, gamma_d, mean_d, var_d, eps, weight_decay, trainable, bn_trainable,
+                                    gw_d, gb_d, ggamma_d, gbeta_d, ws_d, ws_bytes, sqpart_d, stream);
+}
+static int param_grad_finalize_impl(int K, int N, int ldn, const float* dw_raw_d, const float* colsum_d,
+                                        const float* w_d, const float* b_d, const float* gamma_d, const float* mean_d,
+                                        const float* var_d, float eps, float weight_decay, int trainable, int bn_trainable,
+                                        float* gw_d, float* gb_d, float* ggamma_d, float* gbeta_d,
+                                        float* ws_d, size_t ws_bytes, float* sqpart_d, void* stream) {
     if (!dw_raw_d || !w_d || !gw_d || !ws_d || K <= 0 || N <= 0 || ldn < N) { urso_set_error("urso_param_grad_finalize: bad argument"); return URSO_EINVAL; }
     if ((gb_d || ggamma_d) && !colsum_d) { urso_set_error("urso_param_grad_finalize: colsum required for bias/BN gradients"); return URSO_EINVAL; }
     if (ggamma_d && (!gamma_d || !mean_d || !var_d || !gbeta_d)) { urso_set_error("urso_param_grad_finalize: incomplete BN tensors"); return URSO_EINVAL; }
@@ -362,9 +427,11 @@ extern "C" int urso_param_grad_finalize(int K, int N, int ldn, const float* dw_r
     const int ks = finalize_ks(K, N), kb = ceil_div(K, ks);
     const float regc = 2.0f * weight_decay / ((float)K * (float)N), regb = 2.0f * weight_decay / (float)N;
     ProfScope ps(st, URSO_K_FINALIZE, 0, (double)K * N * 12);
-    URSO_KLAUNCH(finalize_mat_kernel, dim3(ceil_div(N, 64), ks), dim3(256), 0, st, K, N, ldn, kb, dw_raw_d, w_d, gamma_d, var_d, eps, regc, trainable, gw_d, ws_d);
+    URSO_KLAUNCH(finalize_mat_kernel, dim3(ceil_div(N, 64), ks), dim3(256), 0, st, K, N, ldn, kb, dw_raw_d, w_d, gamma_d, var_d, eps, regc, trainable, gw_d, ws_d, sqpart_d);
+    float* sqv = sqpart_d ? sqpart_d + ceil_div(N, 64) * ks : nullptr;
     if (gb_d || ggamma_d)
-        URSO_KLAUNCH(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d);
+        URSO_KLAUNCH(finalize_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, N, ks, (const float*)ws_d, colsum_d, b_d, gamma_d, mean_d, var_d, eps, regb, trainable, bn_trainable, gb_d, ggamma_d, gbeta_d, sqv);
+    else if (sqv) hipMemsetAsync(sqv, 0, (size_t)ceil_div(N, 256) * sizeof(float), st);
     return urso_check_launch("urso_param_grad_finalize");
 }
 
@@ -411,7 +478,15 @@ extern "C" int urso_param_batch_plan(int phase, const urso_param_desc* descs_h, 
     return total;
 }
 
+static int param_batch_run_impl(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, float* sqpart_d, void* stream);
 extern "C" int urso_param_batch_run(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, void* stream) {
+    return param_batch_run_impl(phase, dt, descs_d, blockmap_d, nblocks, nullptr, stream);
+}
+extern "C" int urso_param_batch_run_sq(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, float* sqpart_d, void* stream) {
+    if (!sqpart_d || (phase != URSO_PB_FINALIZE_MAT && phase != URSO_PB_FINALIZE_VEC)) { urso_set_error("urso_param_batch_run_sq: FINALIZE phases only, sqpart_d required"); return URSO_EINVAL; }
+    return param_batch_run_impl(phase, dt, descs_d, blockmap_d, nblocks, sqpart_d, stream);
+}
+static int param_batch_run_impl(int phase, int dt, const urso_param_desc* descs_d, const int32_t* blockmap_d, int nblocks, float* sqpart_d, void* stream) {
     if (!descs_d || !blockmap_d || nblocks < 0) { urso_set_error("urso_param_batch_run: bad argument"); return URSO_EINVAL; }
     if (nblocks == 0) return URSO_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -425,9 +500,9 @@ extern "C" int urso_param_batch_run(int phase, int dt, const urso_param_desc* de
         break; }
     case URSO_PB_REDUCE: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0); urso_reduce_partials_batch_launch(descs_d, blockmap_d, nblocks, st); break; }
     case URSO_PB_FINALIZE_MAT: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
-        URSO_KLAUNCH(finalize_mat_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+        URSO_KLAUNCH(finalize_mat_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d, sqpart_d); break; }
     case URSO_PB_FINALIZE_VEC: { ProfScope ps(st, URSO_K_FINALIZE, 0, 0);
-        URSO_KLAUNCH(finalize_vec_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d); break; }
+        URSO_KLAUNCH(finalize_vec_batch_kernel, dim3(nblocks), dim3(256), 0, st, descs_d, blockmap_d, sqpart_d); break; }
     default: urso_set_error("urso_param_batch_run: bad phase"); return URSO_EINVAL;
     }
     return urso_check_launch("urso_param_batch_run");

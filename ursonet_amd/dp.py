@@ -232,6 +232,9 @@ class DataParallelEngine(object):
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
         if tail_bytes is None:
             tail_bytes = DEFAULT_TAIL_BYTES if self.world > 1 else eng.grad_tail_bytes
+        if getattr(eng, "fused_sqnorm", False) or not getattr(eng, "no_fused_sqnorm", False):
+            eng.no_fused_sqnorm = True                  # the clip norm is that of the AVERAGED gradient: taken after the all-reduces, by urso_sqnorm
+            replan = replan or bool(getattr(eng, "fused_sqnorm", False))
         if bucket_bytes != eng.grad_bucket_bytes or int(tail_bytes) != eng.grad_tail_bytes or replan:
             eng.grad_bucket_bytes = int(bucket_bytes)
             eng.grad_tail_bytes = int(tail_bytes)

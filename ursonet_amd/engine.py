@@ -500,6 +500,13 @@ class Engine(object):
             ext[ln] = (min(s0, o), max(e0, o + _round_up(n, 4)))
         self.buckets = plan_buckets(sorted(((ln, s0, e0) for ln, (s0, e0) in ext.items()), key=lambda t: t[1]), self.grad_bucket_bytes,
                                     tail_bytes=self.grad_tail_bytes)
+        # Global gradient norm without a pass of its own: with ONE gradient bucket and nothing between finalisation and optimizer (no all-reduce,
+        # no batch-statistics BN writing gamma / beta gradients elsewhere) every gradient slice is written by a finalisation launch, and each of
+        # their blocks leaves the sum of squares of what it stored (urso_param_batch_run_sq): urso_sqnorm_final adds the slots (-24 us of reading
+        # the 134 MB buffer back).  ursonet_amd/dp.py sets no_fused_sqnorm: there the norm is that of the all-reduced gradient.
+        self.fused_sqnorm = (os.environ.get("URSO_FUSE_SQNORM", "1") != "0" and not getattr(self, "no_fused_sqnorm", False) and
+                             len(self.buckets) == 1 and not any(c_.batch_bn for c_ in self.convs.values()))
+        sq_slots = [0]
         bucket_of = {ln: k for k, (_, _, names) in enumerate(self.buckets) for ln in names}
         groups = OrderedDict()                      # bucket index -> [conv names], backward order
         bwd_order = self._backward_order()
@@ -611,9 +618,16 @@ class Engine(object):
                 gb = self.gview(node.name, "bias").reshape(-1) if node.bias else None
                 gg = self.gview(node.bn, "gamma").reshape(-1) if (node.bn and not c.batch_bn) else None
                 gbe = self.gview(node.bn, "beta").reshape(-1) if (node.bn and not c.batch_bn) else None
-                self.bwd_ops.append((node.name, lambda c=c, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr:
-                                     hip.param_grad_finalize(147, c.N, c.N, c.dw_unp, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
-                                                             float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
+                if self.fused_sqnorm:
+                    s0, s1 = sq_slots[0], sq_slots[0] + hip.param_grad_finalize_sq_slots(147, c.N)
+                    sq_slots[0] = s1
+                    self.bwd_ops.append((node.name, lambda c=c, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr, s0=s0, s1=s1:
+                                         hip.param_grad_finalize_sq(147, c.N, c.N, c.dw_unp, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
+                                                                    float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws, self.sqpart[s0:s1])))
+                else:
+                    self.bwd_ops.append((node.name, lambda c=c, gw=gw, gb=gb, gg=gg, gbe=gbe, tr=tr, bn_tr=bn_tr:
+                                         hip.param_grad_finalize(147, c.N, c.N, c.dw_unp, c.colsum, c.w, c.b, c.gamma, c.mean, c.var, BN_EPS,
+                                                                 float(cfg.WEIGHT_DECAY), tr, bn_tr, gw, gb, gg, gbe, self.fin_ws)))
                 self.labels["bwd"].append("finalize:" + node.name)
             elif tr or bn_tr:
                 d = c.desc
@@ -820,11 +834,18 @@ class Engine(object):
             if isinstance(op, tuple):
                 ph, k = op
                 ids = [self.convs[nm].desc_id for nm in groups[k]]
-                if self.pbatch.plan(ph, k, ids) == 0:
+                nb_ = self.pbatch.plan(ph, k, ids)
+                if nb_ == 0:
                     continue                                   # nothing to launch (e.g. no split layer in the bucket)
-                op = (lambda ph=ph, k=k: self.pbatch.run(ph, k, dt))
+                if self.fused_sqnorm and ph in (hip.PB_FINALIZE_MAT, hip.PB_FINALIZE_VEC):
+                    s0, s1 = sq_slots[0], sq_slots[0] + nb_
+                    sq_slots[0] = s1
+                    op = (lambda ph=ph, k=k, s0=s0, s1=s1: self.pbatch.run(ph, k, dt, sqpart=self.sqpart[s0:s1]))
+                else:
+                    op = (lambda ph=ph, k=k: self.pbatch.run(ph, k, dt))
             resolved.append((tag, op)); labels.append(lab)
         self.bwd_ops, self.labels["bwd"] = resolved, labels
+        self.sqpart = torch.zeros(max(sq_slots[0], 1), dtype=torch.float32, device=dev) if self.fused_sqnorm else None
         # ---------------------------------------------------------------- optimizer
         n = self.n_flat
         self.adam = str(getattr(cfg, "OPTIMIZER", "SGD")).upper() != "SGD"          # net.py:979-983: anything else is Adam(amsgrad)
@@ -843,7 +864,10 @@ class Engine(object):
             self.hyper = torch.tensor([float(cfg.LEARNING_RATE), float(cfg.LEARNING_MOMENTUM), clip], dtype=torch.float32, device=dev)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sq_ws = torch.empty(hip.sqnorm_ws_bytes(n) // 4, dtype=torch.float32, device=dev)
-        self.opt_ops.append(lambda: hip.sqnorm(n, self.flat_g, self.sq_ws, self.normsq))
+        if self.fused_sqnorm:
+            self.opt_ops.append(lambda: hip.sqnorm_final(self.sqpart, self.normsq))
+        else:
+            self.opt_ops.append(lambda: hip.sqnorm(n, self.flat_g, self.sq_ws, self.normsq))
         if self.adam:
             self.opt_ops.append(lambda: hip.adam_amsgrad_clip(n, self.flat_w, self.flat_g, self.flat_v, self.flat_v2, self.flat_vhat,
                                                               self.hyper, self.normsq))

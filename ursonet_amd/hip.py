@@ -116,6 +116,11 @@ _SIGS = {
     "urso_param_grad_finalize": (_i, [_i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i,
                                       _fp, _fp, _fp, _fp, _fp, _sz, _vp]),
     "urso_param_grad_finalize_ws_bytes": (_sz, [_i, _i]),
+    "urso_param_grad_finalize_sq": (_i, [_i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i,
+                                         _fp, _fp, _fp, _fp, _fp, _sz, _fp, _vp]),
+    "urso_param_grad_finalize_sq_slots": (_i, [_i, _i]),
+    "urso_param_batch_run_sq": (_i, [_i, _i, _vp, _vp, _i, _fp, _vp]),
+    "urso_sqnorm_final": (_i, [_i, _fp, _fp, _vp]),
     "urso_bn_ws_bytes": (_sz, [_i, _i]),
     "urso_bn_batch_stats": (_i, [_i, _i, _i, _vp, _vp, _sz, _fp, _fp, _fp, _fp, _f, _f, _vp]),
     "urso_bn_apply": (_i, [_i, _i, _i, _vp, _fp, _fp, _fp, _fp, _f, _vp, _i, _vp, _vp]),
@@ -397,10 +402,17 @@ class ParamBatch(object):
         self.maps[(phase, key)] = (t, nb)
         return nb
 
-    def run(self, phase, key, dt, stream=None):
+    def run(self, phase, key, dt, stream=None, sqpart=None):
+        """sqpart (fp32, >= the phase's block count; FINALIZE phases): every block also leaves the sum of squares of what it stored there."""
         t, nb = self.maps[(phase, key)]
-        if nb:
+        if nb and sqpart is not None:
+            assert sqpart.dtype == torch.float32 and sqpart.numel() >= nb
+            _chk(_lib.urso_param_batch_run_sq(phase, dt, ptr(self.dev), ptr(t), nb, ptr(sqpart), stream_ptr(stream)), "urso_param_batch_run_sq")
+        elif nb:
             _chk(_lib.urso_param_batch_run(phase, dt, ptr(self.dev), ptr(t), nb, stream_ptr(stream)), "urso_param_batch_run")
+
+    def nblocks(self, phase, key):
+        return self.maps[(phase, key)][1]
 
 
 def conv_wgrad_pair_splits(g0, g1, dt):
@@ -508,6 +520,25 @@ def param_grad_finalize(K, N, ldn, dw_raw, colsum, w, b, gamma, mean, var, eps, 
                                        ptr(var), eps, wd, int(trainable), int(bn_trainable), ptr(gw), ptr(gb),
                                        ptr(ggamma), ptr(gbeta), ptr(ws), ws.numel() * ws.element_size(),
                                        stream_ptr(stream)), "urso_param_grad_finalize")
+
+
+def param_grad_finalize_sq_slots(K, N):
+    return int(_lib.urso_param_grad_finalize_sq_slots(K, N))
+
+
+def param_grad_finalize_sq(K, N, ldn, dw_raw, colsum, w, b, gamma, mean, var, eps, wd, trainable, bn_trainable,
+                           gw, gb, ggamma, gbeta, ws, sqpart, stream=None):
+    assert sqpart.dtype == torch.float32 and sqpart.numel() >= param_grad_finalize_sq_slots(K, N)
+    _chk(_lib.urso_param_grad_finalize_sq(K, N, ldn, ptr(dw_raw), ptr(colsum), ptr(w), ptr(b), ptr(gamma), ptr(mean),
+                                          ptr(var), eps, wd, int(trainable), int(bn_trainable), ptr(gw), ptr(gb),
+                                          ptr(ggamma), ptr(gbeta), ptr(ws), ws.numel() * ws.element_size(), ptr(sqpart),
+                                          stream_ptr(stream)), "urso_param_grad_finalize_sq")
+
+
+def sqnorm_final(parts, out, stream=None):
+    """urso_sqnorm_final: out[0] = sum of parts (the slots the *_sq finalisation launches wrote), in index order."""
+    assert parts.dtype == torch.float32 and out.dtype == torch.float32
+    _chk(_lib.urso_sqnorm_final(parts.numel(), ptr(parts), ptr(out), stream_ptr(stream)), "urso_sqnorm_final")
 
 
 def mold_images(B, H, W, src, mean3, dt, dst, stream=None):
