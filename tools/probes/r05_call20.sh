@@ -1,0 +1,6 @@
+mkdir -p gpurun_out
+for v in 0 1 2 4 8 15 0 1 2 4 8 15; do
+  URSO_SIDE_STREAM=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pcie-steps 0 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('side_stream=$v', d['value'], d['ms_per_step'])" | tee -a gpurun_out/r05_ab_side_stream.txt
+done
+URSO_SIDE_STREAM=15 timeout 1500 python -m pytest tests/test_model_gpu.py -x -q -k "parity_16bit or graph_replay or parity_fp32" 2>&1 | tail -4
