@@ -720,6 +720,9 @@ def test_data_parallel_engine_single_rank_rccl_matches_plain_engine(monkeypatch)
     from ursonet_amd.dp import DataParallelEngine
     from ursonet_amd import hip
     monkeypatch.setenv("URSO_DP_FORCE_COLLECTIVES", "1")
+    # the DP path takes the clip norm of the all-reduced gradient with urso_sqnorm; the plain engines it is compared with bit for bit do the same
+    # here (their default adds per-block sums of the finalisation launches: another fp32 summation order, test_gradient_norm_from_the_...)
+    monkeypatch.setenv("URSO_FUSE_SQNORM", "0")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                             device_id=torch.device("cuda", torch.cuda.current_device()))
@@ -894,7 +897,7 @@ def test_engine_refuses_to_step_under_other_planning_options():
     eng.step_eager(); torch.cuda.synchronize()
 
 
-def test_urso_comm_bucket_averaging_one_rank():
+def test_urso_comm_bucket_averaging_one_rank(monkeypatch):
     """The C-ABI exchange step (urso_comm_*: RCCL bound at run time) with one rank: the average over one rank is the identity, the
     collective runs on the communicator's own stream ordered after the producer kernel, and urso_comm_wait orders the consumer
     after it; then the same transport under DataParallelEngine reproduces the plain engine's step bit for bit."""
@@ -903,6 +906,7 @@ def test_urso_comm_bucket_averaging_one_rank():
     from ursonet_amd import hip
     from ursonet_amd.engine import Engine
     from ursonet_amd.dp import DataParallelEngine
+    monkeypatch.setenv("URSO_FUSE_SQNORM", "0")          # the plain engine takes its clip norm the way the DP path must (urso_sqnorm): bit-for-bit comparison below
     comm = hip.Comm(1, 0, hip.comm_unique_id())
     try:
         for dtype in (torch.float32, torch.bfloat16, torch.float16):
