@@ -325,6 +325,39 @@ def test_training_step_parity_bf16_full_benchmark_batch():
     _compare_step(eng, ref, newW, 2e-2, 4e-2, 1e-3, tol_l2=2.5e-2, tol_norm=1e-2)
 
 
+@pytest.mark.parametrize("case", ["cfg4_r101_n24_b16_bf16", "cfg5_r50_f16_classify_loc_b32"])
+def test_training_step_parity_full_size_cfg4_cfg5(case):
+    """ONE oracle-compared training step of BASELINE.json configs[3] and configs[4] at their real per-GPU sizes (ResNet-101 / 13,824 bins / batch
+    16 x 512 x 640 / bf16; ResNet-50 / fp16 / batch 32 x 640 x 960 / classification location head): outputs, losses, every gradient, the norm,
+    the post-step weights against the rounding-aware oracle.  2-4 minutes of oracle time each on the GPU box's host cores, so they run on request
+    only (URSO_FULL_SIZE_ORACLE=1; the numbers of this round's run are in profiles/r05_parity.txt); the default suite holds the same comparison
+    for cfg2 (test_training_step_parity_bf16_full_benchmark_batch) and these configurations' property tests."""
+    import os
+    if os.environ.get("URSO_FULL_SIZE_ORACLE", "0") != "1":
+        pytest.skip("set URSO_FULL_SIZE_ORACLE=1 (minutes of host time per case)")
+    from oracle import graph_ref as G
+    torch.set_num_threads(min(os.cpu_count() or 8, 128))
+    if case.startswith("cfg4"):
+        cfg = make_config(backbone="resnet101", h=512, w=640, batch=16, regress_ori=False, ori_bins=24, dtype="bfloat16")
+        qt, tol_out, tol_g, tol_l2, tol_norm, dtol = torch.bfloat16, 2.5e-2, 6e-2, 4e-2, 1.5e-2, 2e-2
+    else:
+        cfg = make_config(backbone="resnet50", h=640, w=960, batch=32, regress_ori=False, regress_loc=False, ori_bins=16, loc_bins=16,
+                          dtype="float16", f16=True)
+        qt, tol_out, tol_g, tol_l2, tol_norm, dtol = torch.float16, 4e-3, 1.6e-2, 1e-2, 4e-3, 4e-3
+    img, loc, ori, _ = synthetic_batch(cfg, cfg.BATCH_SIZE, seed=15)
+    eng, w0 = _run_engine(cfg, img, loc, ori)
+    q = G.StorageRounding(qt)
+    dec = ReluDecisions(eng, tol=dtol)
+    ref, newW = _oracle_step(cfg, w0, img, loc, ori, cfg.LEARNING_RATE, relu_hook=dec, q=q)
+    m = _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3, tol_l2=tol_l2, tol_norm=tol_norm, check=False)
+    log = os.environ.get("URSO_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("%s FULL size: %s; relu flips %d of %d, worst %.2e %s\n" % (case, {k: "%.2e" % v for k, v in m.items()}, dec.flips, dec.total, dec.worst, dec.histogram()))
+    assert dec.flips <= 2e-3 * dec.total, "too many ReLU decision flips: %d of %d" % (dec.flips, dec.total)
+    _compare_step(eng, ref, newW, tol_out, tol_g, 1e-3, tol_l2=tol_l2, tol_norm=tol_norm)
+
+
 @pytest.mark.parametrize("pwx", [1, 2], ids=["policy", "pwx_everywhere"])
 def test_training_step_parity_bf16_at_cfg2_width(pwx):
     """The benchmarked dtype at the real cfg2 image size (2 x 512 x 640, ori_resolution 16) against the rounding-aware oracle: the
