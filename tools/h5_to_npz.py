@@ -17,7 +17,13 @@ import numpy as np
 
 def read_keras_h5(path):
     """-> OrderedDict {layer: OrderedDict {weight: array}} in the file's own layer order."""
-    import h5py
+    try:
+        import h5py
+    except ImportError:                                                   # no h5py here: the HDF5 C library through ctypes, when this file sits in the repository
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from ursonet_amd import h5lite
+        return h5lite.read_keras_weights(path)
     out = OrderedDict()
     dec = lambda n: n.decode("utf8") if isinstance(n, bytes) else str(n)
     with h5py.File(path, mode="r") as f:

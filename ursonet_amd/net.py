@@ -8,9 +8,9 @@ is provided here with the same names, argument meaning and error behaviour; the 
 done by ursonet_amd.engine.Engine (HIP kernels through the C ABI) -- there is no Keras/TF and no
 CPU fallback: building a model without an MI355X raises.
 
-Weights files: Keras HDF5 (`.h5`, by-name, nested `model_weights` groups handled) when h5py is
-importable; always a `.npz` twin with the same layer/weight names and layouts
-("<layer>/<weight>" keys), which is what this container (no h5py) reads and writes.
+Weights files: Keras HDF5 (`.h5`, by-name, nested `model_weights` groups handled) through h5py or, where this interpreter has none,
+through the HDF5 C library itself (ursonet_amd/h5lite.py: ctypes on libhdf5.so, checked against files written by the real h5py);
+always also a `.npz` twin with the same layer/weight names and layouts ("<layer>/<weight>" keys).
 """
 import datetime
 import logging
@@ -131,7 +131,12 @@ def read_weights_file(path):
     try:
         import h5py
     except ImportError:
-        raise ImportError("`load_weights` of a Keras .h5 file requires h5py (absent here); use the .npz twin")
+        # no h5py for this interpreter: the HDF5 C library itself through ctypes (ursonet_amd/h5lite.py: same files, same library h5py binds)
+        from . import h5lite
+        if not h5lite.available():
+            raise ImportError("`load_weights` of a Keras .h5 file needs h5py or an HDF5 library (libhdf5.so; $URSO_HDF5_LIB): neither found -- "
+                              "use the .npz twin (tools/h5_to_npz.py converts on any machine that has one)")
+        return h5lite.read_keras_weights(path)
     out = OrderedDict()
     with h5py.File(path, mode='r') as f:
         if 'layer_names' not in f.attrs and 'model_weights' in f:          # net.py:831-832
@@ -155,6 +160,10 @@ def write_weights_file(path, params):
         try:
             import h5py
         except ImportError:
+            from . import h5lite
+            if h5lite.available():                      # the HDF5 library without h5py: the same Keras layout (keras save_weights_to_hdf5_group)
+                h5lite.write_keras_weights(path, params)
+                written.append(path)
             return written
         with h5py.File(path, "w") as f:
             f.attrs['layer_names'] = [ln.encode('utf8') for ln in params]
