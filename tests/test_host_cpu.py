@@ -301,6 +301,31 @@ def test_sim2real_draws_follow_the_reference_distributions():
     assert (frac == 0).mean() > 0.3 and 0.01 < frac[frac > 0].mean() < 0.06
 
 
+def test_resize_image_matches_the_reference_run_with_the_real_scikit_image():
+    """utils.resize_image (utils.py:398-511) on uint8 frames against what THE REFERENCE'S function returned with the real scikit-image 0.18.3
+    (tests/golden/resize_skimage.npz, generated by tests/golden/make_resize_golden.py under the interpreter of this image that has skimage):
+    window, scale and padding exactly; pure-padding cases bit for bit; rescaled images within ONE grey level on at most 2 % of the pixels
+    (skimage's anti-aliasing filter runs in uint8 and truncates after each axis -- reproduced; its warp estimates the affine map by least
+    squares, so a bilinear value that is an exact integer here can sit 1e-13 below it there and truncate one lower)."""
+    import os
+    from ursonet_amd import utils
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize_skimage.npz"))
+    assert str(z["skimage_version"]) == "0.18.3"
+    for case in z["cases"]:
+        name, mode = str(case).split()
+        a = z[name + "/args"]
+        out, window, scale, padding, crop = utils.resize_image(z[name + "/in"], min_dim=int(a[0]), max_dim=int(a[1]) or None, min_scale=float(a[2]) or None, mode=mode)
+        ref = z[name + "/out"]
+        assert out.shape == ref.shape and out.dtype == ref.dtype == np.uint8 and crop is None
+        assert tuple(window) == tuple(z[name + "/window"]) and float(scale) == float(z[name + "/scale"])
+        assert np.array_equal(np.asarray(padding), z[name + "/padding"])
+        d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+        if float(scale) == 1.0:
+            assert d.max() == 0, name
+        else:
+            assert d.max() <= 1 and (d > 0).mean() <= 0.02, (name, int(d.max()), float((d > 0).mean()))
+
+
 def test_resize_antialiasing_and_identity():
     """utils._bilinear_resize: identity at equal size; when shrinking, the Gaussian pre-filter (sigma = (s - 1)/2, skimage's
     anti_aliasing default) keeps a one-pixel checkerboard from aliasing into a constant pattern of the wrong mean."""
