@@ -586,9 +586,12 @@ def test_resize_equals_scipy_ndimage_the_backend_of_skimage_resize():
     assert scale == 64 / 150 and out.dtype == np.uint8 and out.shape[0] % 64 == 0 and out.shape[1] % 64 == 0
     nh, nw = round(150 * scale), round(240 * scale)
     fac = np.array([150 / nh, 240 / nw, 1.0])
-    ref = ndi.zoom(ndi.gaussian_filter(u8.astype(np.float64), np.maximum(0, (fac - 1) / 2), cval=0, mode="grid-constant"), [1 / x for x in fac], order=1,
+    # (scikit-image <= 0.18 -- the reference's era -- hands the frame to gaussian_filter in its own dtype: uint8 in, uint8 out, truncated after each
+    # axis; tests/golden/resize_skimage.npz holds the real thing's outputs)
+    ref = ndi.zoom(ndi.gaussian_filter(u8, np.maximum(0, (fac - 1) / 2), cval=0, mode="grid-constant").astype(np.float64), [1 / x for x in fac], order=1,
                    mode="grid-constant", cval=0, grid_mode=True).astype(np.uint8)
-    assert np.array_equal(out[window[0]:window[2], window[1]:window[3]], ref)
+    d = np.abs(out[window[0]:window[2], window[1]:window[3]].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3      # (the filtered frame is integer-valued: a bilinear value that is an exact integer in one arithmetic can sit 1e-13 below it in the other)
 
 
 def test_algorithmic_bytes_charge_compact_and_sampled_tensors_at_their_real_size():
