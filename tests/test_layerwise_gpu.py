@@ -290,7 +290,11 @@ def _check(dtype_name, errs):
 def test_teacher_forced_layer_parity_bf16_at_cfg2_width(plan, seed):
     """Every conv / dense layer of the cfg2 plan (ResNet-50, bottleneck 32, ori_resolution 16, 512 x 640; batch 2 shortens the tile
     streams only) on three data seeds.  'policy' = the plan the benchmark runs (fused pairs keep some gradients on chip: those tensors
-    are listed, not checked); 'apart' = pair 0, where every activation gradient reaches memory and every layer is checked."""
+    are listed, not checked); 'apart' = pair 0, where every activation gradient reaches memory and every layer is checked.
+    The default suite runs both plans on seed 1 and the benchmark's plan on seed 2 (each case is 25-45 s of host-side oracle time, and the
+    suite has to fit a GPU box's time slot); URSO_ALL_SEEDS=1 runs all six (profiles/r05_parity.txt holds them)."""
+    if (plan, seed) not in (("policy", 1), ("apart", 1), ("policy", 2)) and os.environ.get("URSO_ALL_SEEDS", "0") != "1":
+        pytest.skip("URSO_ALL_SEEDS=1 runs this seed")
     kw = dict(backbone="resnet50", h=512, w=640, batch=2, regress_ori=False, ori_bins=16)
     (errs, skipped), eng = _run("bfloat16", kw, seed, {} if plan == "policy" else {"pair": 0})
     _report("bf16 cfg2-width %s seed %d" % (plan, seed), errs, skipped)
