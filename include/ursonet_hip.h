@@ -71,9 +71,9 @@ int         urso_abi_version(void);           /* bumped on any signature or data
  *                     workgroups hold) BEFORE it plans a step, so that a CU held by RCCL never gives a statically partitioned tile
  *                     stream a second wave; split counts (urso_*_splits, urso_conv_wgrad_ws_bytes) follow it, so it must not change
  *                     between planning and launching
- *   bneck (1)         conv_bneck.hip for bottleneck_layer (3x3 / stride 2 / <= 32 filters, net.py:639-640): bit 0 its data gradient by parity
+ *   bneck (3)         conv_bneck.hip for bottleneck_layer (3x3 / stride 2 / <= 32 filters, net.py:639-640): bit 0 its data gradient by parity
  *                     class of the input pixel (only the real taps; bit-identical to the dilated general form), bit 1 its forward pass in
- *                     one launch without a split-K workspace (slower than the split-K pair at cfg2: opt-in)
+ *                     one launch without a split-K workspace (16 pixels x all filters per block, LDS-staged rows, C % 512 == 0)
  *   dense (1)         conv_dense.hip skinny GEMM (<= 32 rows) for the Dense heads and their data gradients; host plans may then put the
  *                     layers of one depth into one urso_dense_multi launch (read by ursonet_amd/engine.py)
  *   pair (1)          host plans may fuse qualifying pointwise pairs into urso_conv_pair launches (read by ursonet_amd/engine.py; the library

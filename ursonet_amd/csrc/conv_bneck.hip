@@ -2,9 +2,9 @@
 // gradient, 16-bit dtypes, gfx950.  The layer is 2 x 3 GFLOP against 42 MB of activations (cfg2: [32,16,20,2048] -> [32,8,10,32]): both
 // passes are byte-bound, and the general kernel served neither well --
 //   forward : 2,560 output pixels x 32 filters is 20 tiles of the 128-row kernel, so it ran split-K (K = 18,432) plus a finishing launch
-//             (35 us for 42 MB); here a block owns 16 output pixels x all (<= 32) filters and its 16 waves split the reduction: the input
-//             is read once from HBM (the 9/4 tap overlap hits L2), the filter (1.2 MB) comes out of L2 per block, partial accumulators
-//             are added in wave order through LDS (deterministic), one launch, no workspace;
+//             (35 us for 42 MB); here a block owns 16 output pixels x all (<= 32) filters and its 16 waves split every (tap, 512-channel)
+//             chunk of the reduction, rows staged through LDS one contiguous KiB per copy; partial accumulators are added in wave order
+//             through LDS (deterministic), one launch, no workspace;
 //   dgrad   : the gather form is a 3x3 convolution over the zero-stuffed gradient (dilation 2): three quarters of its taps multiply
 //             zeros (41 us).  Here the input pixels are grouped by parity class (y & 1, x & 1): a class has 4 / 2 / 2 / 1 real taps, each
 //             exactly one 32-deep MFMA step (N = 32 filters), and a wave keeps the flipped filter rows of its 64 channels for the class's
@@ -17,64 +17,82 @@ struct BnfArgs {
     const void* src; const void* wgt; const float* bias; void* dst;
     uint32_t src_bytes, wgt_bytes;
     int B, H, W, C, OH, OW, N, PH, PW, M, relu;
-    int cpt;                 // 64-channel slab pairs per tap (C / 64)
+    int cq;                  // 512-channel quarters per tap (C / 512)
 };
 
-// forward: grid = ceil(M / 16) blocks of NW waves
-template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64) void bneck_fwd_kernel(const BnfArgs a) {
+__device__ __forceinline__ void bn_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
+    // m0 = wave-uniform LDS destination; lane l lands at m0 + 16 l (conv_pw.hip pw_dma16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4_t bn_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void bn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// forward: grid = ceil(M / 16) blocks of 16 waves; a block = 16 output pixels x 32 filters.  The reduction (9 taps x C channels) is cut into
+// chunks of (one tap, 512 channels): per chunk 32 filter rows and 16 pixel rows of 1 KiB each arrive by LDS-DMA -- one instruction = one
+// CONTIGUOUS KiB of one row (the first form of this kernel loaded MFMA fragments straight from memory: 16 rows 36 KiB apart, 64 bytes each, per
+// instruction, and measured 54 us) -- into a ring of three 48 KiB stages, two chunks ahead; 16-byte slot s of row r holds logical slot
+// s ^ (r & 15), so the 16 rows of a fragment read hit 16 different bank groups.  Wave w multiplies the chunk's k-step w (32 channels): three
+// ds_read_b128 and two MFMAs per chunk and wave; the 16 partial accumulators are added in wave order through LDS (deterministic).
+template <typename T>
+__global__ __launch_bounds__(1024) void bneck_fwd_kernel(const BnfArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
-    __shared__ f32x4_t red[NW][2][64];
+    constexpr int STAGE = 48 * 1024, NSTG = 3;
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * STAGE];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.src, a.src_bytes), rw = make_rsrc(a.wgt, a.wgt_bytes);
-    // lane (fr, fg): output pixel m0 + fr (MFMA column), filter rows fr and 16 + fr, k chunk fg of every 32-deep slab
-    const int m = blockIdx.x * 16 + fr;
-    const bool mok = m < a.M;
+    const i32x4_t rs = bn_rsrc(a.src, a.src_bytes), rw = bn_rsrc(a.wgt, a.wgt_bytes);
+    // this wave's copy roles: filter rows `wave` and 16 + `wave`, pixel row `wave` (output pixel m0 + wave)
+    const int mw = blockIdx.x * 16 + wave;
     const int ohw = a.OH * a.OW;
-    const int b = m / ohw, r_ = m - b * ohw, oy = r_ / a.OW, ox = r_ - oy * a.OW;
-    const int iy0 = oy * 2 - a.PH, ix0 = ox * 2 - a.PW;
-    const uint32_t Krow = (uint32_t)(9 * a.C) * 2u;                     // bytes of one filter row
-    const uint32_t w0 = (fr < a.N) ? (uint32_t)fr * Krow + (uint32_t)fg * 16u : URSO_OOB_SHIFT;
-    const uint32_t w1 = (16 + fr < a.N) ? (uint32_t)(16 + fr) * Krow + (uint32_t)fg * 16u : URSO_OOB_SHIFT;
+    const int bw = mw / ohw, rw_ = mw - bw * ohw, oyw = rw_ / a.OW, oxw = rw_ - oyw * a.OW;
+    const int iy0 = oyw * 2 - a.PH, ix0 = oxw * 2 - a.PW;
+    const uint32_t Krow = (uint32_t)(9 * a.C) * 2u;
+    const uint32_t lsw = (uint32_t)((lane ^ (wave & 15)) << 4);                    // source slot of this lane for rows with (row & 15) == wave
+    const uint32_t wsrc0 = wave < a.N ? (uint32_t)wave * Krow + lsw : URSO_OOB_SHIFT;
+    const uint32_t wsrc1 = 16 + wave < a.N ? (uint32_t)(16 + wave) * Krow + lsw : URSO_OOB_SHIFT;
+    const int nch = 9 * a.cq;
+    auto issue = [&](int ch) {
+        const int tap = ch / a.cq, q = ch - tap * a.cq, ky = tap / 3, kx = tap - ky * 3;
+        const uint32_t ko = (uint32_t)(tap * a.C + q * 512) * 2u;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool pok = mw < a.M && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+        const uint32_t psrc = pok ? (uint32_t)(((bw * a.H + iy) * a.W + ix) * a.C + q * 512) * 2u + lsw : URSO_OOB_SHIFT;
+        const uint32_t st = lds0 + (uint32_t)(ch % NSTG) * STAGE;
+        bn_dma16(rw, st + (uint32_t)wave * 1024u, wsrc0 == URSO_OOB_SHIFT ? URSO_OOB_SHIFT : wsrc0 + ko);
+        bn_dma16(rw, st + (uint32_t)(16 + wave) * 1024u, wsrc1 == URSO_OOB_SHIFT ? URSO_OOB_SHIFT : wsrc1 + ko);
+        bn_dma16(rs, st + (uint32_t)(32 + wave) * 1024u, psrc);
+    };
+    // fragment read offsets inside a stage: k-step `wave` = logical slots 4 wave .. 4 wave + 3; row r's slot s sits at s ^ (r & 15)
+    const uint32_t slot = (uint32_t)(((4 * wave + fg) ^ fr) << 4);
+    const uint32_t offw0 = (uint32_t)fr * 1024u + slot, offw1 = (uint32_t)(16 + fr) * 1024u + slot, offp = (uint32_t)(32 + fr) * 1024u + slot;
     f32x4_t acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    const int npairs = 9 * a.cpt;
-    constexpr int UN = 2;                                               // slab pairs (128 B of every row) in flight per wave: 12 loads per lane
-    for (int p0 = wave; p0 < npairs; p0 += NW * UN) {
-        i32x4_t fw0[UN][2], fw1[UN][2], fa[UN][2];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int p = p0 + u * NW;
-            const bool pok = p < npairs;
-            const int tap = p / a.cpt, cp = p - tap * a.cpt, ky = tap / 3, kx = tap - ky * 3;
-            const int iy = iy0 + ky, ix = ix0 + kx;
-            const bool aok = pok && mok && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
-            const uint32_t ao = aok ? (uint32_t)(((b * a.H + iy) * a.W + ix) * a.C + cp * 64 + fg * 8) * 2u : URSO_OOB_SHIFT;
-            const uint32_t ko = (uint32_t)p * 128u;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                fa[u][h] = buf_load16(rs, ao + (uint32_t)h * 64u);       // an out-of-range base stays out of range (+ 64)
-                fw0[u][h] = buf_load16(rw, pok ? w0 + ko + (uint32_t)h * 64u : URSO_OOB_SHIFT);
-                fw1[u][h] = buf_load16(rw, pok ? w1 + ko + (uint32_t)h * 64u : URSO_OOB_SHIFT);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                Mma<T>::run(fw0[u][h], fa[u][h], acc0);                  // D rows -> filters, columns -> pixels
-                Mma<T>::run(fw1[u][h], fa[u][h], acc1);
-            }
+    issue(0);
+    if (nch > 1) issue(1);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) bn_wait_vm<3>(); else bn_wait_vm<0>();     // this wave's copies of chunk ch have landed (chunk ch + 1's may be in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... every wave's have; and every wave is done reading the stage chunk ch + 2 goes to
+        if (ch + 2 < nch) issue(ch + 2);
+        const char* sb = smem + (ch % NSTG) * STAGE;
+        const i32x4_t fw0 = *(const i32x4_t*)(sb + offw0), fw1 = *(const i32x4_t*)(sb + offw1), fp = *(const i32x4_t*)(sb + offp);
+        Mma<T>::run(fw0, fp, acc0);                                   // D rows -> filters, columns -> pixels
+        Mma<T>::run(fw1, fp, acc1);
     }
+    bn_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every stage is free: the partial sums go to stage 0
+    f32x4_t (*red)[2][64] = (f32x4_t (*)[2][64])smem;
     red[wave][0][lane] = acc0; red[wave][1][lane] = acc1;
     __syncthreads();
     if (wave >= 2) return;
     const int t = wave;                                                 // wave t finishes filter half t: filters 16 t + 4 fg .. + 3 of pixel fr
-    const int nb = 16 * t + fg * 4;
+    const int m = blockIdx.x * 16 + fr, nb = 16 * t + fg * 4;
     f32x4_t y = red[0][t][lane];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) y += red[w][t][lane];
-    if (!mok || nb >= a.N) return;                                      // N % 4 == 0
+    for (int w = 1; w < 16; ++w) y += red[w][t][lane];
+    if (m >= a.M || nb >= a.N) return;                                  // N % 4 == 0
     if (a.bias) y += *(const f32x4_t*)(a.bias + nb);
     float v[4] = {y.x, y.y, y.z, y.w};
     T o[4];
@@ -178,26 +196,24 @@ __global__ __launch_bounds__(256) void bneck_dgrad_kernel(const BndArgs a) {
 }
 
 // ---------------------------------------------------------------- host side
-// option bneck: bit 0 (default) the data gradient, bit 1 the forward kernel.  Measured at cfg2 (profiles/r05_heads.txt): the data gradient
-// 40 -> 24 us; the forward kernel 54 us against 35 us of the split-K pair it would replace -- a fragment load touches 16 filter rows
-// 36 KiB apart, 64 bytes each, and every block pulls the whole 1.2 MB filter that way -- so it stays opt-in.
-// Forward: 3x3 / stride-2 / undilated, <= 32 filters (N % 4 == 0), C % 64 == 0, no residual / mask / fp32 output.
+// option bneck: bit 0 the data gradient, bit 1 the forward kernel (default 3: both).
+// Forward: 3x3 / stride-2 / undilated, <= 32 filters (N % 4 == 0), C % 512 == 0, no residual / mask / fp32 output.
 bool urso_bneck_fwd_fits(const urso_conv_geom* g, int dt, int flags, const void* add, const void* mask) {
     if (!(g_urso_opt.bneck & 2) || dt == URSO_F32 || add || mask) return false;
     if (flags & ~URSO_EPI_RELU) return false;
     if (g->KH != 3 || g->KW != 3 || g->SH != 2 || g->SW != 2 || g->DH != 1 || g->DW != 1 || g->FH > 0) return false;
-    if (g->N > 32 || (g->N % 4) || (g->C % 64)) return false;
+    if (g->N > 32 || (g->N % 4) || (g->C % 512)) return false;
     return (long long)g->B * g->H * g->W * g->C * 2 < 0x7FFFFF00ll;
 }
 int urso_bneck_fwd_launch(const urso_conv_geom* g, int dt, int flags, const void* src, const void* wgt, const float* bias, void* dst, hipStream_t st) {
     BnfArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.dst = dst;
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.OH = g->OH; a.OW = g->OW; a.N = g->N; a.PH = g->PH; a.PW = g->PW;
-    a.M = g->B * g->OH * g->OW; a.relu = (flags & URSO_EPI_RELU) ? 1 : 0; a.cpt = g->C / 64;
+    a.M = g->B * g->OH * g->OW; a.relu = (flags & URSO_EPI_RELU) ? 1 : 0; a.cq = g->C / 512;
     a.src_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2); a.wgt_bytes = (uint32_t)((size_t)g->N * 9 * g->C * 2);
     const dim3 grid(ceil_div(a.M, 16)), blk(1024);
-    if (dt == URSO_BF16) URSO_KLAUNCH((bneck_fwd_kernel<__bf16, 16>), grid, blk, 0, st, a);
-    else URSO_KLAUNCH((bneck_fwd_kernel<_Float16, 16>), grid, blk, 0, st, a);
+    if (dt == URSO_BF16) URSO_KLAUNCH((bneck_fwd_kernel<__bf16>), grid, blk, 0, st, a);
+    else URSO_KLAUNCH((bneck_fwd_kernel<_Float16>), grid, blk, 0, st, a);
     return urso_check_launch("urso_conv_igemm(bneck fwd)");
 }
 
