@@ -43,13 +43,14 @@ def save_weights_to_hdf5_group(f, vlen_attrs):
             d[...] = a
 
 
-with h5py.File(os.path.join(HERE, "keras_weights.h5"), "w") as f:          # model.save_weights(): what the reference's ModelCheckpoint writes
-    save_weights_to_hdf5_group(f, vlen_attrs=False)
-with h5py.File(os.path.join(HERE, "keras_model.h5"), "w") as f:            # model.save(): the weights live under model_weights (net.py:830-832)
-    f.attrs["model_config"] = '{"class_name": "Model"}'
-    save_weights_to_hdf5_group(f.create_group("model_weights"), vlen_attrs=True)
-np.savez(os.path.join(HERE, "keras_weights_expected.npz"), **{"%s/%s" % (ln, wn): a for ln, ws in LAYERS for wn, a in ws})
-print("h5py", h5py.__version__, "hdf5", h5py.version.hdf5_version, "->", [p for p in sorted(os.listdir(HERE)) if p.startswith("keras_")])
+if len(sys.argv) == 1:                                                      # (no argument: regenerate the fixtures)
+    with h5py.File(os.path.join(HERE, "keras_weights.h5"), "w") as f:          # model.save_weights(): what the reference's ModelCheckpoint writes
+        save_weights_to_hdf5_group(f, vlen_attrs=False)
+    with h5py.File(os.path.join(HERE, "keras_model.h5"), "w") as f:            # model.save(): the weights live under model_weights (net.py:830-832)
+        f.attrs["model_config"] = '{"class_name": "Model"}'
+        save_weights_to_hdf5_group(f.create_group("model_weights"), vlen_attrs=True)
+    np.savez(os.path.join(HERE, "keras_weights_expected.npz"), **{"%s/%s" % (ln, wn): a for ln, ws in LAYERS for wn, a in ws})
+    print("h5py", h5py.__version__, "hdf5", h5py.version.hdf5_version, "->", [p for p in sorted(os.listdir(HERE)) if p.startswith("keras_")])
 if len(sys.argv) > 1:                                                       # `make_h5_golden.py --dump file.h5`: what the real h5py reads out of a file
     with h5py.File(sys.argv[-1], "r") as f:
         g = f["model_weights"] if "layer_names" not in f.attrs else f
