@@ -819,7 +819,7 @@ def test_adam_amsgrad_clip_against_numpy():
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("MN", [(600, 64), (130, 40), (96, 2048)])
+@pytest.mark.parametrize("MN", [(600, 64), (130, 40), (96, 2048), (20000, 256), (5000, 24), (3000, 2048)])
 def test_batch_stat_bn_kernels_against_autograd(dt, MN):
     """urso_bn_batch_stats / urso_bn_apply / urso_bn_backward (TRAIN_BN=None mode) vs torch autograd through a
     training-mode batch norm + residual + ReLU; moving statistics follow Keras' update (momentum 0.99, variance fed

@@ -13,12 +13,15 @@ ap.add_argument("--batch", type=int, default=32); ap.add_argument("--height", ty
 ap.add_argument("--width", type=int, default=640); ap.add_argument("--dtype", default="bfloat16")
 ap.add_argument("--backbone", default="resnet50"); ap.add_argument("--ori-bins", type=int, default=16)
 ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE")
+ap.add_argument("--train-bn", action="store_true", help="batch-statistics BN (TRAIN_BN=None, config.py:143-147) instead of the frozen default")
 a = ap.parse_args()
 from ursonet_amd import hip
 for kv in a.opt:
     k, _, v = kv.partition("=")
     hip.set_option(k, int(v))
 cfg = make_config(backbone=a.backbone, h=a.height, w=a.width, batch=a.batch, regress_ori=False, ori_bins=a.ori_bins, dtype=a.dtype)
+if a.train_bn:
+    cfg.TRAIN_BN = None
 eng = Engine(cfg, "training", seed=1234, randomize_bn=True)
 img, loc, ori, _ = synthetic_batch(cfg, a.batch, seed=1)
 eng.load_batch(img, loc, ori)
