@@ -315,7 +315,7 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
         // the HBM-bound c -> 4c layers stay where they are (register-filter kernel / conv_pw.hip); this kernel takes the reduction-heavy
         // ones: K >= 512 with at least 128 filters, on pixel counts where a 160-row tile grid fills the chip
         const bool s4_wide = K == 256 && N >= 1024 && !(g_urso_opt.pair_single & 1);      // (A/B: the stage-4 c -> 4c layers when conv_pair.hip is told to leave them)
-        if ((K < 512 && !s4_wide) || N < 128 || M < 160 * 64) return 0;
+        if ((K < 512 && !s4_wide) || N < 128 || M < 160 * 32) return 0;      // (half a chip of 160 x 128 tiles still beats conv_pw.hip's 1.25 rounds: cfg4 stage 5, 34.8 -> 31.8 us)
     }
     PxArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst; a.bits_out = bits_out;
