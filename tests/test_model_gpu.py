@@ -475,6 +475,41 @@ def test_graph_replay_equals_eager_and_is_deterministic():
     assert torch.equal(e1.flat_w, e2.flat_w)
 
 
+@pytest.mark.parametrize("name,kw", [("r50", dict(backbone="resnet50", batch=4, h=256, w=320, regress_ori=False, ori_bins=16, dtype="bfloat16")),
+                                     ("r101_f16", dict(backbone="resnet101", batch=2, h=192, w=256, regress_ori=False, ori_bins=8, f16=True))])
+def test_weight_gradients_beside_the_chain_change_no_bit(name, kw, monkeypatch):
+    """The complementary fork (Engine._fork_weight_gradients, URSO_WGRAD_STREAM=2, the default): the arithmetic-heavy weight gradients of stages
+    4-5 deferred to the point where the data gradients reach stage 3 and run on a second branch of the captured graph.  Same kernels, same
+    operands: weights and gradients after three replayed steps equal the single chain's bit for bit (a captured graph that ran a chain node
+    early showed only from the second replay on: the first one reads what the eager warm-up step left)."""
+    from ursonet_amd.engine import Engine
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("URSO_WGRAD_STREAM", mode)
+        cfg = make_config(**kw)
+        eng = Engine(cfg, "training", seed=11, randomize_bn=True)
+        img, loc, ori, _ = synthetic_batch(cfg, kw["batch"], seed=4)
+        eng.load_batch(img, loc, ori)
+        for _ in range(3):
+            eng.step()
+        torch.cuda.synchronize()
+        out[mode] = (eng.flat_w.clone(), eng.flat_g.clone(), eng.flat_v.clone())
+        labs = [l for l in eng.labels["bwd"] if l is not None]
+        at = next(i for i, l in enumerate(labs) if l.startswith(("dgrad:res3", "dgrad:res2")))
+        if mode == "0":
+            assert eng.wgrad_stream is None
+            n_before = sum(1 for l in labs[:at] if l.startswith("wgrad:res"))
+        else:
+            assert eng.wgrad_stream is not None
+            moved = [l for l in labs[:at] if l.startswith("wgrad:res")]
+            tail = []
+            while at - 1 - len(tail) >= 0 and labs[at - 1 - len(tail)].startswith("wgrad"):
+                tail.append(labs[at - 1 - len(tail)])
+            assert len(tail) >= 3 and len(moved) == n_before, (tail, len(moved), n_before)      # deferred launches stand right in front of the point
+    for a, b in zip(out["0"], out["2"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype,tol_out,cos_min", [("bfloat16", 5e-2, 0.95), ("float16", 1e-2, 0.99)])
 def test_training_step_parity_16bit(dtype, tol_out, cos_min):
     """bf16 (cfg2) and fp16 (cfg5, F16) storage with fp32 accumulation against the fp32 oracle: outputs within the format's

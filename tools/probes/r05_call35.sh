@@ -1,0 +1,10 @@
+#!/bin/bash
+python tools/probes/fork2_check.py 2>&1 | grep -v amdgpu
+for i in 1 2 3; do for v in 0 2; do
+  URSO_WGRAD_STREAM=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pcie-steps 0 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('URSO_WGRAD_STREAM=$v  %.3f ms  %.1f img/s' % (d['ms_per_step'], d['value']))"
+done; done
+for i in 1 2; do for v in 0 2; do echo mode $v; URSO_WGRAD_STREAM=$v python tools/config_sweep.py cfg4_r101_n24_bf16 cfg5_r50_f16_classify_loc 2>&1 | grep cfg; done; done

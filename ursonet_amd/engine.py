@@ -68,6 +68,18 @@ class _Conv(object):
     pass
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One second stream per device for the process, shared by every Engine: engines come and go (tests build dozens), and a replay of a forked
+    graph segfaulted inside hipGraphLaunch (ROCm 7.2) in a process where earlier engines' side streams had been destroyed with them."""
+    key = torch.device(device).index or 0
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _no_gc(object):
     """Collect garbage now and keep the cyclic collector off inside the block.  An Engine is full of reference cycles (its op lists are
     closures over itself), so an engine that went out of scope dies whenever the collector happens to run -- and if that is in the
@@ -878,24 +890,87 @@ class Engine(object):
         self._fork_weight_gradients()
 
     def _fork_weight_gradients(self):
-        """Weight-gradient launches are leaves of the backward pass: nothing reads their partials before the bucket's reduction.  On one
-        chain each of them is a full-chip persistent grid with a cold prologue and a synchronised store tail, and the data-gradient launch
-        behind it waits for its last block.  Here they go to a second stream instead (captured into the same hipGraph as a fork off the
-        chain): fork = the point of the chain where the launch stood (its dz is final there, every tensor has a gradient buffer of its own
-        and nothing later overwrites what it reads), join = the next reduction / finalisation / unpack launch (and the optimizer).  The
-        blocks of the two launches share the chip: a data-gradient grid fills the CUs the weight-gradient launch's tail has left and vice
-        versa.  Every kernel keeps its fixed-order arithmetic, so the step stays bit-identical to the single chain.  The wrapped closures
-        are what ursonet_amd/dp.py cuts into segments: every segment ends behind a finalisation, i.e. joined.
-        MEASURED (round 5, cfg2, alternating in one gpurun call): 7.07 / 7.06 ms on the single chain, 7.24 / 7.23 ms forked -- it LOSES 2.4 %.
-        Every grid here is a static partition of its tile stream over all 256 CUs; a block that finds its CU held by the other launch
-        runs as a second wave behind it, which costs more than the idle tails it fills (the same arithmetic as CUs held by a collective,
-        profiles/r02_dp_cu_contention.json).  So the fork is OFF by default (URSO_WGRAD_STREAM=1 switches it on); what the tails want is
-        both gradients of a layer inside ONE grid that partitions the CUs itself (conv_dwg.hip)."""
+        """Weight-gradient launches are leaves of the backward pass: nothing reads their partials before the bucket's reduction, every tensor
+        has a gradient buffer of its own and nothing later overwrites what they read.  So they may run LATER than where they stand in the
+        chain, and beside it: on a second stream, captured into the same hipGraph as a branch.
+        What pays (tools/probes/overlap_probe.py, profiles/r05_overlap_probe.txt): an HBM-bound chain and an MFMA-bound chain side by side
+        finish 9-12 % sooner than one after the other; two chains of the same kind only get in each other's way (every grid is a static
+        partition of its tiles over all 256 CUs, and a block that finds its CU held by the other launch runs behind it).  Hence the
+        COMPLEMENTARY fork (URSO_WGRAD_STREAM=2, the default): only the arithmetic-heavy weight gradients (>= 150 FLOP per byte: stages 4-5,
+        the 3x3 layers of stage 3, bottleneck_layer, the heads) leave the chain, and those whose dz is final before the data gradients reach
+        stage 3 are DEFERRED to that point, where the chain turns HBM-bound (stage-3 / stage-2 data gradients and weight gradients).  Join =
+        the bucket's reduction.  cfg2, alternating in one gpurun call: 7.13 -> 6.97 ms (-2.1 %), bit-identical to the single chain (same
+        kernels, same operands; tests/test_model_gpu.py).  URSO_WGRAD_STREAM=1 is the plain fork of round 5's first experiment (every weight
+        gradient, where it stands: +2.4 %), 0 the single chain.  Plans whose buckets are finalised inside the backward pass (data-parallel
+        runs: ursonet_amd/dp.py) keep the single chain -- a deferred launch would land behind its bucket's finalisation.
+        One edge per fork: the side stream waits for the chain only when the chain has moved since the last side launch.  A captured graph in
+        which twenty side nodes each carried their own (redundant) edge from the same chain node ran the chain node BEHIND that fan before
+        its predecessors (stale operands from the previous replay; ROCm 7.2, profiles/r05_fork.txt) -- eager streams did not."""
         self.wgrad_stream = None
-        if os.environ.get("URSO_WGRAD_STREAM", "0") != "1" or self.mode != "training":
+        mode = int(os.environ.get("URSO_WGRAD_STREAM", "2"))
+        if mode not in (1, 2) or self.mode != "training":
             return
-        self.wgrad_stream = torch.cuda.Stream(device=self.device)
+        import re
+        labs = self.labels["bwd"]
+        assert len(labs) == len(self.bwd_ops)
+        fin = ("reduce", "finalize_mat", "finalize_vec", "finalize", "unpack")
+        side = lambda lab: lab is not None and lab.startswith(("wgrad:", "wgrad_heads:"))
+        if mode == 2:
+            es = 4 if self.dt == hip.F32 else 2
+
+            def work(name, back=False):          # (FLOP, bytes) of a layer's weight gradient (back: of its data gradient): operands once, result once
+                c = self.convs.get(name)
+                g = getattr(c, "gf", None) if c is not None else None
+                if g is None:
+                    return 0.0, 0.0              # heads: small, latency-bound
+                m_out, m_in, k = g.B * g.OH * g.OW, g.B * g.H * g.W, g.KH * g.KW * g.C
+                return 2.0 * m_out * k * g.N, (m_in * g.C + m_out * g.N) * es + (es if back else 4.0) * k * g.N
+
+            def names(lab):
+                return [n for part in lab.split("+wgrad:")[0:1] + lab.split("+wgrad:")[1:] for n in part.split(":", 1)[-1].split("+") if n != "maxpool_bwd"]
+
+            def est_ms(lab):                     # what the launch takes at the rates launches of its kind reach here (1.0 PFLOP/s, 4.5 TB/s)
+                fl = by = 0.0
+                for n in names(lab):
+                    f, b = work(n, lab.startswith("dgrad"))
+                    fl += f; by += b
+                return max(fl / 1.0e12, by / 4.5e9)
+
+            def intensity(lab):
+                fl = by = 0.0
+                for n in names(lab):
+                    f, b = work(n)
+                    fl += f; by += b
+                return fl / by if by else 1e9
+
+            def wg(lab):
+                return lab is not None and lab.startswith(("wgrad:", "wgrad_heads:")) and "dgrad" not in lab
+            at = next((i for i, l in enumerate(labs) if l is not None and re.match(r"dgrad:res[23]", l)), None)
+            if at is None:
+                return
+            # the HBM-bound stretch of the chain behind the deferral point, and as much arithmetic-heavy weight-gradient work as fits beside it:
+            # the LAST such launches in front of the point (the others stay where they are, on the chain)
+            room = 0.8 * sum(est_ms(l) for l in labs[at:] if l is not None and l.startswith(("dgrad:", "wgrad:")) and not (wg(l) and intensity(l) >= 400.0))
+            early = []
+            for i in range(at - 1, -1, -1):
+                if wg(labs[i]) and (labs[i].startswith("wgrad_heads:") or intensity(labs[i]) >= 150.0):
+                    room -= est_ms(labs[i])
+                    if room < 0:
+                        break
+                    early.append(i)
+            early.reverse()
+            if not early or any(labs[i] is not None and labs[i].split(":")[0] in fin for i in range(early[0], at)):
+                return                           # nothing to defer, or a bucket is finalised inside the region: the chain stays as it is
+            moved = set(early)
+            late = set(i for i in range(at, len(labs)) if wg(labs[i]) and intensity(labs[i]) >= 400.0)      # 3x3 layers of >= 128 channels behind the point
+            side_ids = set(id(self.bwd_ops[i]) for i in moved | late)
+            order = [i for i in range(at) if i not in moved] + early + list(range(at, len(labs)))
+            self.bwd_ops = [self.bwd_ops[i] for i in order]
+            self.labels["bwd"] = [labs[i] for i in order]
+            side = None
+        self.wgrad_stream = _side_stream(self.device)
         self._side_open = False
+        self._main_moved = True
         self._single_chain = False
 
         def on_side(op):
@@ -903,7 +978,9 @@ class Engine(object):
                 if self._single_chain:
                     return op()
                 main = torch.cuda.current_stream(self.device)
-                self.wgrad_stream.wait_stream(main)
+                if self._main_moved or not self._side_open:         # one edge per fork (see above)
+                    self.wgrad_stream.wait_stream(main)
+                    self._main_moved = False
                 with torch.cuda.stream(self.wgrad_stream):
                     op()
                 self._side_open = True
@@ -912,14 +989,24 @@ class Engine(object):
         def joined(op):
             def run():
                 self._join_weight_gradients()
+                self._main_moved = True
+                return op()
+            return run
+
+        def on_main(op):
+            def run():
+                self._main_moved = True
                 return op()
             return run
         ops = []
-        for (tag, op), lab in zip(self.bwd_ops, self.labels["bwd"]):
-            if lab.startswith(("wgrad:", "wgrad_heads:")):
+        for item, lab in zip(self.bwd_ops, self.labels["bwd"]):
+            tag, op = item
+            if (id(item) in side_ids) if side is None else side(lab):
                 op = on_side(op)
-            elif lab.split(":")[0] in ("reduce", "finalize_mat", "finalize_vec", "finalize", "unpack"):
+            elif lab is not None and lab.split(":")[0] in fin:
                 op = joined(op)
+            elif callable(op):
+                op = on_main(op)
             ops.append((tag, op))
         self.bwd_ops = ops
         self.opt_ops[0] = joined(self.opt_ops[0])
