@@ -948,9 +948,10 @@ class Engine(object):
             at = next((i for i, l in enumerate(labs) if l is not None and re.match(r"dgrad:res[23]", l)), None)
             if at is None:
                 return
-            # the HBM-bound stretch of the chain behind the deferral point, and as much arithmetic-heavy weight-gradient work as fits beside it:
+            # the HBM-bound stretch of the chain behind the deferral point, and as much arithmetic-heavy weight-gradient work as fits beside it (1.2 x
+            # its estimate: cfg4, ResNet-101 at batch 16, has more such work than stretch -- 0.4 / 0.8 / 1.2 / 2.0: 8.48 / 8.37 / 8.33 / 8.33 ms, chain 8.49):
             # the LAST such launches in front of the point (the others stay where they are, on the chain)
-            room = 0.8 * sum(est_ms(l) for l in labs[at:] if l is not None and l.startswith(("dgrad:", "wgrad:")) and not (wg(l) and intensity(l) >= 400.0))
+            room = 1.2 * sum(est_ms(l) for l in labs[at:] if l is not None and l.startswith(("dgrad:", "wgrad:")) and not (wg(l) and intensity(l) >= 400.0))
             early = []
             for i in range(at - 1, -1, -1):
                 if wg(labs[i]) and (labs[i].startswith("wgrad_heads:") or intensity(labs[i]) >= 150.0):
