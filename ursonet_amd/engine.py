@@ -948,13 +948,14 @@ class Engine(object):
             at = next((i for i, l in enumerate(labs) if l is not None and re.match(r"dgrad:res[23]", l)), None)
             if at is None:
                 return
+            EARLY, LATE = 150.0, 400.0           # FLOP per byte (swept 50 ... 300 / 250 ... none: 6.93 ... 6.98 ms, nothing to choose between them)
             # the HBM-bound stretch of the chain behind the deferral point, and as much arithmetic-heavy weight-gradient work as fits beside it (1.2 x
             # its estimate: cfg4, ResNet-101 at batch 16, has more such work than stretch -- 0.4 / 0.8 / 1.2 / 2.0: 8.48 / 8.37 / 8.33 / 8.33 ms, chain 8.49):
             # the LAST such launches in front of the point (the others stay where they are, on the chain)
-            room = 1.2 * sum(est_ms(l) for l in labs[at:] if l is not None and l.startswith(("dgrad:", "wgrad:")) and not (wg(l) and intensity(l) >= 400.0))
+            room = 1.2 * sum(est_ms(l) for l in labs[at:] if l is not None and l.startswith(("dgrad:", "wgrad:")) and not (wg(l) and intensity(l) >= LATE))
             early = []
             for i in range(at - 1, -1, -1):
-                if wg(labs[i]) and (labs[i].startswith("wgrad_heads:") or intensity(labs[i]) >= 150.0):
+                if wg(labs[i]) and (labs[i].startswith("wgrad_heads:") or intensity(labs[i]) >= EARLY):
                     room -= est_ms(labs[i])
                     if room < 0:
                         break
@@ -963,7 +964,7 @@ class Engine(object):
             if not early or any(labs[i] is not None and labs[i].split(":")[0] in fin for i in range(early[0], at)):
                 return                           # nothing to defer, or a bucket is finalised inside the region: the chain stays as it is
             moved = set(early)
-            late = set(i for i in range(at, len(labs)) if wg(labs[i]) and intensity(labs[i]) >= 400.0)      # 3x3 layers of >= 128 channels behind the point
+            late = set(i for i in range(at, len(labs)) if wg(labs[i]) and intensity(labs[i]) >= LATE)      # 3x3 layers of >= 128 channels behind the point
             side_ids = set(id(self.bwd_ops[i]) for i in moved | late)
             order = [i for i in range(at) if i not in moved] + early + list(range(at, len(labs)))
             self.bwd_ops = [self.bwd_ops[i] for i in order]
