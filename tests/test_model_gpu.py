@@ -484,12 +484,14 @@ def test_weight_gradients_beside_the_chain_change_no_bit(name, kw, monkeypatch):
     early showed only from the second replay on: the first one reads what the eager warm-up step left)."""
     from ursonet_amd.engine import Engine
     out = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("URSO_WGRAD_STREAM", mode)
+    for mode in ("0", "2", "2 rejected"):
+        monkeypatch.setenv("URSO_WGRAD_STREAM", mode[0])
         cfg = make_config(**kw)
         eng = Engine(cfg, "training", seed=11, randomize_bn=True)
         img, loc, ori, _ = synthetic_batch(cfg, kw["batch"], seed=4)
         eng.load_batch(img, loc, ori)
+        if mode == "2 rejected":             # what Engine._verify_forked_graph does when the captured graph fails its check: the same launch list on one chain
+            eng._single_chain_always = True
         for _ in range(3):
             eng.step()
         torch.cuda.synchronize()
@@ -500,14 +502,15 @@ def test_weight_gradients_beside_the_chain_change_no_bit(name, kw, monkeypatch):
             assert eng.wgrad_stream is None
             n_before = sum(1 for l in labs[:at] if l.startswith("wgrad:res"))
         else:
-            assert eng.wgrad_stream is not None
+            assert eng.wgrad_stream is not None and eng.forked == (mode == "2")
             moved = [l for l in labs[:at] if l.startswith("wgrad:res")]
             tail = []
             while at - 1 - len(tail) >= 0 and labs[at - 1 - len(tail)].startswith("wgrad"):
                 tail.append(labs[at - 1 - len(tail)])
             assert len(tail) >= 3 and len(moved) == n_before, (tail, len(moved), n_before)      # deferred launches stand right in front of the point
-    for a, b in zip(out["0"], out["2"]):
-        assert torch.equal(a, b)
+    for other in ("2", "2 rejected"):
+        for a, b in zip(out["0"], out[other]):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dtype,tol_out,cos_min", [("bfloat16", 5e-2, 0.95), ("float16", 1e-2, 0.99)])
@@ -1053,6 +1056,7 @@ def test_bench_under_torchrun_with_forced_collectives_one_rank():
     common = ["bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--pcie-steps", "0", "--profile-steps", "1"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("URSO_DP_FORCE_COLLECTIVES", None)
+    env["URSO_WGRAD_STREAM"] = "0"        # like with like: data-parallel plans keep the single chain (Engine._fork_weight_gradients)
     plain = subprocess.run([sys.executable] + common, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert plain.returncode == 0, plain.stderr.decode()[-2000:]
     p = json.loads(plain.stdout.decode().strip().splitlines()[-1])

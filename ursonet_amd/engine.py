@@ -907,6 +907,7 @@ class Engine(object):
         which twenty side nodes each carried their own (redundant) edge from the same chain node ran the chain node BEHIND that fan before
         its predecessors (stale operands from the previous replay; ROCm 7.2, profiles/r05_fork.txt) -- eager streams did not."""
         self.wgrad_stream = None
+        self._single_chain_always = False
         mode = int(os.environ.get("URSO_WGRAD_STREAM", "2"))
         if mode not in (1, 2) or self.mode != "training":
             return
@@ -979,7 +980,7 @@ class Engine(object):
 
         def on_side(op):
             def run():
-                if self._single_chain:
+                if self._single_chain or self._single_chain_always:
                     return op()
                 main = torch.cuda.current_stream(self.device)
                 if self._main_moved or not self._side_open:         # one edge per fork (see above)
@@ -1458,7 +1459,39 @@ class Engine(object):
                 else:
                     self.run_prep(); self.run_forward()
         self._graphs = gr
-        return gr
+        if self.mode == "training" and getattr(self, "wgrad_stream", None) is not None and not self._single_chain_always:
+            self._verify_forked_graph(gr)
+        return self._graphs
+
+    def _verify_forked_graph(self, gr):
+        """The captured graph with its second branch against the same launches issued eagerly on one chain: two steps each from the same state,
+        weights and gradients bit for bit (the second replay is the one that shows a node run early: the first reads what the warm-up step
+        left).  A graph executor that fails this (see _fork_weight_gradients) costs the engine its side branch, not its results."""
+        saved = self.save_train_state()
+        gr.replay(); gr.replay()
+        torch.cuda.synchronize(self.device)
+        got = (self.flat_w.clone(), self.flat_g.clone())
+        self.restore_train_state(saved)
+        self._single_chain = True
+        try:
+            self.step_eager(); self.step_eager()
+        finally:
+            self._single_chain = False
+        torch.cuda.synchronize(self.device)
+        ok = torch.equal(got[0], self.flat_w) and torch.equal(got[1], self.flat_g)
+        self.restore_train_state(saved)
+        if not ok:
+            import warnings
+            warnings.warn("ursonet_amd: the captured training graph with the weight gradients on a second branch does not reproduce the single chain "
+                          "on this device / runtime -- captured again on one chain")
+            self._single_chain_always = True
+            self._graphs = None
+            self.capture()
+
+    @property
+    def forked(self):
+        """True when the captured step runs weight gradients on a second graph branch (_fork_weight_gradients) and that graph has been verified."""
+        return getattr(self, "wgrad_stream", None) is not None and not getattr(self, "_single_chain_always", False)
 
     def step(self):
         """Replay the captured training step (captures on first use)."""
