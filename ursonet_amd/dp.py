@@ -232,6 +232,11 @@ class DataParallelEngine(object):
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
         if tail_bytes is None:
             tail_bytes = DEFAULT_TAIL_BYTES if self.world > 1 else eng.grad_tail_bytes
+        if getattr(eng, "wgrad_stream", None) is not None or not getattr(eng, "no_wgrad_fork", False):
+            # the step runs as graph segments between collectives here, not through Engine.capture (which checks a forked graph against the chain):
+            # the backward pass stays one chain
+            replan = replan or getattr(eng, "wgrad_stream", None) is not None
+            eng.no_wgrad_fork = True
         if getattr(eng, "fused_sqnorm", False) or not getattr(eng, "no_fused_sqnorm", False):
             eng.no_fused_sqnorm = True                  # the clip norm is that of the AVERAGED gradient: taken after the all-reduces, by urso_sqnorm
             replan = replan or bool(getattr(eng, "fused_sqnorm", False))

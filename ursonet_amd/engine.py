@@ -909,7 +909,7 @@ class Engine(object):
         self.wgrad_stream = None
         self._single_chain_always = False
         mode = int(os.environ.get("URSO_WGRAD_STREAM", "2"))
-        if mode not in (1, 2) or self.mode != "training":
+        if mode not in (1, 2) or self.mode != "training" or getattr(self, "no_wgrad_fork", False):       # (no_wgrad_fork: set by ursonet_amd/dp.py)
             return
         import re
         labs = self.labels["bwd"]
