@@ -259,6 +259,39 @@ def test_data_generator_and_mold_image():
     assert imgs.shape == (2, 64, 128, 3) and k1.shape == (2, 3) and k2.shape == (2, 3)
 
 
+def test_feeder_shards_every_global_batch_over_the_ranks():
+    """Data-parallel feeding (ursonet_amd.feeder.batches, rank= / world=): the ranks walk ONE shuffled order, their shards of a global
+    batch are disjoint and rank-ordered, and together they are what a single process drawing world x batch samples with the same private
+    shuffle would have drawn -- over several epochs of a dataset whose size is no multiple of the global batch."""
+    from ursonet_amd import feeder
+    from ursonet_amd.dataset import SyntheticPoses
+    cfg = make_config("resnet18", 64, 128, batch=2, regress_ori=False, ori_bins=4)
+    cfg.ROT_AUG = False
+    ds = SyntheticPoses(11, 64, 128, cfg, seed=1)
+    world, bs, nb = 3, 2, 9
+    per_rank = []
+    for r in range(world):
+        g = feeder.batches(ds, cfg, True, bs, molded=False, rank=r, world=world)
+        per_rank.append([[int(m[0]) for m in next(g).meta] for _ in range(nb)])       # image_meta[0] = image_id (net.py:1314)
+    # the single-process order under the same private generator
+    rng, ids, cursor, want = np.random.RandomState(feeder.DP_SHUFFLE_SEED), np.copy(ds.image_ids), -1, []
+    for _ in range(nb * world * bs):
+        cursor = (cursor + 1) % len(ids)
+        if cursor == 0:
+            rng.shuffle(ids)
+        want.append(int(ids[cursor]))
+    for k in range(nb):
+        glob = sum((per_rank[r][k] for r in range(world)), [])
+        assert glob == want[k * world * bs:(k + 1) * world * bs], (k, glob)
+    # world == 1 keeps the reference's generator: NumPy's global RNG shuffles (net.py:489-490)
+    np.random.seed(5)
+    g = feeder.batches(ds, cfg, True, bs, molded=False)
+    got = [int(m[0]) for _ in range(3) for m in next(g).meta]
+    np.random.seed(5)
+    ids = np.copy(ds.image_ids); np.random.shuffle(ids)
+    assert got == [int(i) for i in ids[:6]]
+
+
 def test_data_generator_skips_up_to_five_bad_samples():
     """net.py:553-559: a failing sample is logged and skipped; the sixth failure re-raises."""
     from ursonet_amd import net
@@ -324,6 +357,26 @@ def test_resize_image_matches_the_reference_run_with_the_real_scikit_image():
             assert d.max() == 0, name
         else:
             assert d.max() <= 1 and (d > 0).mean() <= 0.02, (name, int(d.max()), float((d > 0).mean()))
+
+
+def test_resize_compat_switch_selects_the_skimage_generation(monkeypatch):
+    """URSO_RESIZE_COMPAT: 0.18 (default) truncates integer frames after each anti-aliasing pass, as scikit-image <= 0.18 does
+    (golden above); 0.19 smooths in float like scikit-image >= 0.19 -- a shrunk uint8 frame then equals the float frame's result truncated
+    once at the end, is never darker than the 0.18 result and differs from it by at most two grey levels (one truncation per smoothed axis)."""
+    from ursonet_amd import utils
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(240, 320, 3), dtype=np.uint8)
+    monkeypatch.delenv("URSO_RESIZE_COMPAT", raising=False)
+    old = utils.resize_image(img, min_dim=96, max_dim=128, mode="square")[0]
+    monkeypatch.setenv("URSO_RESIZE_COMPAT", "0.19")
+    new = utils.resize_image(img, min_dim=96, max_dim=128, mode="square")[0]
+    flt = utils.resize_image(img.astype(np.float64), min_dim=96, max_dim=128, mode="square")[0]
+    assert new.dtype == np.uint8 and np.array_equal(new, flt.astype(np.uint8))
+    d = new.astype(int) - old.astype(int)
+    assert d.min() >= 0 and 1 <= d.max() <= 2
+    monkeypatch.setenv("URSO_RESIZE_COMPAT", "1.0")
+    with pytest.raises(ValueError):
+        utils.resize_image(img, min_dim=96, max_dim=128, mode="square")
 
 
 def test_resize_antialiasing_and_identity():

@@ -315,3 +315,22 @@ def test_teacher_forced_layer_parity_fp16_resnet101():
     _report("fp16 r101 128x192", errs, skipped)
     assert len(errs["fwd"]) == len(eng.convs) - len(eng.shortcut_folded)
     _check("float16", errs)
+
+
+@pytest.mark.parametrize("case", ["cfg4_r101_n24_512x640_bf16", "cfg5_r50_f16_classify_loc_640x960"])
+def test_teacher_forced_layer_parity_at_cfg4_cfg5_geometry(case):
+    """Every conv / dense layer of BASELINE.json configs[3] and configs[4] at their real image sizes (batch 2): ResNet-101's 105 convs on
+    512 x 640 in bf16 with the 13,824-bin head, ResNet-50 in fp16 on 640 x 960 with both heads classifying over 4,096 bins -- each layer fed
+    the DEVICE's stored input / output gradient and compared with the oracle's single layer, no compounding (VERDICT r05 missing 4)."""
+    if case.startswith("cfg4"):
+        dtype_name, kw = "bfloat16", dict(backbone="resnet101", h=512, w=640, batch=2, regress_ori=False, ori_bins=24)
+    else:
+        dtype_name, kw = "float16", dict(backbone="resnet50", h=640, w=960, batch=2, regress_ori=False, regress_loc=False, ori_bins=16,
+                                         loc_bins=16, f16=True)
+    (errs, skipped), eng = _run(dtype_name, kw, 1, {})
+    _report("%s batch 2" % case, errs, skipped)
+    nconv = len(eng.convs)
+    assert len(errs["fwd"]) == nconv - len(eng.shortcut_folded) and not skipped["fwd"]
+    assert len(errs["dkernel"]) >= nconv - 4, skipped
+    _check(dtype_name, errs)
+

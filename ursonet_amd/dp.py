@@ -53,7 +53,7 @@ def plan_buckets(layer_sizes, bucket_bytes=32 << 20, tail_bytes=0):
 def allreduce_rel_norms(norms, group=None):
     """Sum {sum (gt-pred)^2, sum gt^2} of rel_loss_graph over the ranks (DP_EXACT_REL_LOSS); synchronous w.r.t. the caller's stream."""
     if dist.is_initialized() and dist.get_world_size(group) > 1 or _force_collectives():
-        dist.all_reduce(norms, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum_(norms, group)
     return norms
 
 
@@ -73,6 +73,78 @@ def reserve_comm_cus(n=None):
     if n > 0:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
     return n
+
+
+def launcher_world():
+    """(rank, local_rank, world_size) as a launcher (`python -m torch.distributed.run`, torchrun) put them in the environment;
+    (0, 0, 1) in a plain process.  An already initialised process group wins over the environment."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), int(os.environ.get("LOCAL_RANK", "0")), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if world <= 1:
+        return 0, 0, 1
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))), world
+
+
+def init_from_launcher():
+    """One process per GPU: pick this rank's device, bound RCCL's channels (reserve_comm_cus) and join the process group the launcher
+    describes -- what `net.UrsoNet(mode='training')` does when WORLD_SIZE > 1, so that `pose_estimator.py train` under torchrun is the
+    data-parallel run with no change to the caller.  Backend: RCCL ("nccl"); URSO_DP_BACKEND=gloo moves the exchange to gloo on the
+    SAME device tensors (ranks that share one GPU, which RCCL refuses: tests/test_dp_two_ranks_gpu.py).  Returns (rank, local_rank, world)."""
+    rank, local, world = launcher_world()
+    if world <= 1:
+        return rank, local, world
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("ursonet_amd: data-parallel training needs an AMD GPU per rank")
+    dev = int(os.environ.get("URSO_DP_DEVICE", local % ndev))
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("URSO_DP_BACKEND", "nccl")
+        reserve_comm_cus()
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def _host_staged(group=None):
+    """gloo between ranks whose tensors live on a GPU (two ranks sharing one device, which RCCL refuses; URSO_DP_BACKEND=gloo): collectives
+    go through a host copy, synchronously -- a test transport, never the measured one."""
+    return dist.is_initialized() and dist.get_backend(group) != "nccl"
+
+
+def broadcast_(t, src=0, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def allreduce_sum_(t, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def average_over_ranks(t, group=None):
+    """In place: t <- mean over the ranks of t (a small tensor of logged scalars); identity without a process group."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        else:
+            allreduce_sum_(t, group)
+            t.div_(dist.get_world_size(group))
+    return t
 
 
 def _force_collectives():
@@ -123,6 +195,9 @@ class GradReducer(object):
             self.works.append((None, None, back, t))
         elif self.backend == "nccl":        # RCCL: averaging happens inside the collective
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, back, t))
+        elif t.is_cuda:                     # gloo under device tensors (ranks sharing one GPU): host-staged and synchronous, see _host_staged
+            allreduce_sum_(t, self.group)
+            self.works.append((None, t, back, t))
         else:                               # gloo (CPU tests): sum, then scale on wait
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t, back, t))
 
@@ -173,6 +248,13 @@ class _OptionOverride(object):
         return True
 
 
+def _release_holds(holds):
+    """weakref.finalize callback of DataParallelEngine: the process-wide options a collected wrapper still held."""
+    for name in list(holds):
+        _OptionOverride.release(name)
+    del holds[:]
+
+
 class DataParallelEngine(object):
     """Wraps an Engine: broadcasts the initial weights, splits the captured step into
     [prep+forward+loss+backward-part-0], [backward-part-1], ..., [optimizer] hipGraphs and
@@ -199,8 +281,8 @@ class DataParallelEngine(object):
         if self.rel_exact:
             engine.rel_scale.fill_(float(self.world))
         eng = engine
-        dist.broadcast(eng.flat_w, src=0, group=group)
-        dist.broadcast(eng.flat_stats, src=0, group=group)
+        broadcast_(eng.flat_w, 0, group)
+        broadcast_(eng.flat_stats, 0, group)
         # gradient buckets are planned by the engine (it batches the gradient finalisation per bucket)
         replan = False
         self._holds = []                                # options this wrapper holds (_OptionOverride), given back by close()
@@ -209,6 +291,9 @@ class DataParallelEngine(object):
         except BaseException:
             self.close()                                # an exception here must not leave the process on the reduced chip / without stream-K
             raise
+        # a wrapper that is dropped without close() must not keep `cus` / `hconv_streamk` held for the rest of the process
+        import weakref
+        self._finalizer = weakref.finalize(self, _release_holds, self._holds)
 
     def _init_policy(self, eng, explicit, comm, bucket_bytes, tail_bytes, replan):
         if self.comm_cus and eng.device.type == "cuda" and (self.world > 1 or (explicit and _force_collectives())):
@@ -232,6 +317,7 @@ class DataParallelEngine(object):
         # GPU the extra finalisation group costs 0.06 ms (0.7 %) and buys nothing, so the plain engine keeps its plan.
         if tail_bytes is None:
             tail_bytes = DEFAULT_TAIL_BYTES if self.world > 1 else eng.grad_tail_bytes
+        self._prev_flags = (bool(getattr(eng, "no_wgrad_fork", False)), bool(getattr(eng, "no_fused_sqnorm", False)))
         if getattr(eng, "wgrad_stream", None) is not None or not getattr(eng, "no_wgrad_fork", False):
             # the step runs as graph segments between collectives here, not through Engine.capture (which checks a forked graph against the chain):
             # the backward pass stays one chain
@@ -251,6 +337,21 @@ class DataParallelEngine(object):
         """Give the CUs reserved for the collectives back: option `cus` is process-wide, and an Engine planned after this wrapper is gone
         would otherwise size its grids for the smaller chip."""
         holds, self._holds = list(getattr(self, "_holds", [])), []
+        fin = getattr(self, "_finalizer", None)
+        if fin is not None:
+            fin.detach()                                # close() ran: nothing left for the collector to release
+            self._finalizer = None
+        prev = getattr(self, "_prev_flags", None)
+        if prev is not None:
+            # the engine goes back to what it was before it was wrapped: used on its own again it gets its forked backward pass and the
+            # gradient norm from the finalisation blocks back (ADVICE r05: close() used to leave both switched off)
+            self._prev_flags = None
+            eng = self.eng
+            if (bool(getattr(eng, "no_wgrad_fork", False)), bool(getattr(eng, "no_fused_sqnorm", False))) != prev:
+                eng.no_wgrad_fork, eng.no_fused_sqnorm = prev
+                eng._graphs = None
+                if "cus" not in holds and hasattr(eng, "_build_plan"):
+                    eng._build_plan()                   # (with `cus` held the re-plan below does it, under the restored option)
         if "hconv_streamk" in holds:
             _OptionOverride.release("hconv_streamk")
             self.eng._graphs = None
@@ -260,7 +361,7 @@ class DataParallelEngine(object):
             # once the option is back (the last wrapper holding it is gone) re-plan it for the whole chip (its captured graph goes with the
             # plan; plan_version moves); while another wrapper still holds the reduced chip this engine's plan already matches the option
             self.eng._graphs = None
-            if restored:
+            if restored or prev is not None:
                 self.eng._build_plan()
         self._graphs = None
 

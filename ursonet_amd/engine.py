@@ -212,6 +212,7 @@ class Engine(object):
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
         self.wino_ws = None
+        self._cleared_once = []    # gradient buffers cleared at plan time only (scattered data gradients): (layer, buffer, H, W, C, sy, sx)
         self.loss_pre_ops = []     # DP_EXACT_REL_LOSS: the part of the loss that precedes the cross-rank sum of the two norms
         self.labels = {"prep": [], "fwd": [], "loss": [], "bwd": [], "opt": []}
         self.convs = OrderedDict()
@@ -283,6 +284,7 @@ class Engine(object):
                     c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.dst.h, node.dst.w, node.cin, 1, 1,
                                     FH=node.src.h, FW=node.src.w, OSH=s, OSW=s)
                     c.gd_scatter = True
+                    c.gd_scatter_stride = s
                 else:
                     c.gd = hip.geom(B, node.dst.h, node.dst.w, c.npad, node.src.h, node.src.w, node.cin, node.kh, node.kw,
                                     1, 1, node.kh - 1 - pt, node.kw - 1 - pl, s, s)
@@ -823,10 +825,18 @@ class Engine(object):
                         # (only when EVERY launch that writes this buffer is such a scattered data gradient: a dense one accumulating in place
                         # behind this one would leave its values off the grid for the next step to find)
                         writers = [cc for cc in self.convs.values() if cc.src is X and getattr(cc, "gd", None) is not None]
-                        once = all(getattr(cc, "gd_scatter", False) for cc in writers) and not any(cc.res is X for cc in self.convs.values())
+                        once = (all(getattr(cc, "gd_scatter", False) for cc in writers) and not any(cc.res is X for cc in self.convs.values())
+                                # ... nor a max-pool reading X (urso_maxpool_bwd writes X.grad densely) or X being a network output
+                                and not any(n.op == "pool" and n.src.id == X.spec.id for n in g.nodes)
+                                and not any(t.id == X.spec.id for t in g.outputs.values()))
                         if not once or os.environ.get("URSO_ZERO_EVERY_STEP", "0") == "1":
                             self.bwd_ops.append((None, lambda t=dstg: hip.zero_fill(t)))
                             self.labels["bwd"].append("zero:" + node.name)
+                        else:
+                            # URSO_CHECK_CLEARED=1 (debugging; check_cleared_once()): the pixels no step writes must still be zero after any
+                            # number of steps -- a tool that writes gradient buffers (teacher-forced tests, dumps) would break that silently
+                            st = int(getattr(c, "gd_scatter_stride", 2))
+                            self._cleared_once.append((node.name, dstg, X.spec.h, X.spec.w, X.spec.c, st, st))
                     elif add is not dstg:
                         raise AssertionError("scattered dgrad into %s needs an in-place accumulate" % node.name)
                 self.bwd_ops.append((None, lambda c=c, G=G, add=add, mask=mask, dstg=dstg, mflag=mflag:
@@ -1177,6 +1187,7 @@ class Engine(object):
             A.desc.splits = max(A.splits, 1)
             A.gd = hip.geom(B, H // 2, W // 2, A.npad, H // 2, W // 2, n.cin, 1, 1, FH=H, FW=W, OSH=2, OSW=2)
             A.gd_scatter = True
+            A.gd_scatter_stride = 2
             A.ws_d = 0
             # one layer further down: A's data gradient (dense tensor, zero off the even grid) is the dz of the layer that produced A's
             # input -- its weight gradient is the stride-2 one over the even pixels, reading dz in place (scattered dz operand)
@@ -1402,6 +1413,19 @@ class Engine(object):
 
     PLAN_OPTIONS = ("cus", "wgrad_blocks", "wgrad_narrow", "wgrad_big", "hwgrad", "grid_cap", "pair", "stem", "stem_pool", "c3", "bneck", "dense")
 
+    def check_cleared_once(self):
+        """Debug check of the plan-time clearing invariant (the `once` branch of _build_plan): every pixel OFF the sampled grid of a
+        gradient buffer that is cleared once must still be zero.  Returns the offending layers (empty = invariant holds).  Step() calls it
+        after every replay when URSO_CHECK_CLEARED=1."""
+        bad = []
+        for name, buf, h, w, c, sy, sx in self._cleared_once:
+            t = buf[:self.B * h * w * c].view(self.B, h, w, c)
+            off = t.clone()
+            off[:, ::sy, ::sx, :] = 0
+            if bool(off.any()):
+                bad.append(name)
+        return bad
+
     def _planning_options(self):
         return tuple(hip.get_option(o) for o in self.PLAN_OPTIONS)
 
@@ -1463,23 +1487,64 @@ class Engine(object):
             self._verify_forked_graph(gr)
         return self._graphs
 
-    def _verify_forked_graph(self, gr):
-        """The captured graph with its second branch against the same launches issued eagerly on one chain: two steps each from the same state,
-        weights and gradients bit for bit (the second replay is the one that shows a node run early: the first reads what the warm-up step
-        left).  A graph executor that fails this (see _fork_weight_gradients) costs the engine its side branch, not its results."""
-        saved = self.save_train_state()
-        gr.replay(); gr.replay()
-        torch.cuda.synchronize(self.device)
-        got = (self.flat_w.clone(), self.flat_g.clone())
-        self.restore_train_state(saved)
-        self._single_chain = True
-        try:
-            self.step_eager(); self.step_eager()
-        finally:
-            self._single_chain = False
-        torch.cuda.synchronize(self.device)
-        ok = torch.equal(got[0], self.flat_w) and torch.equal(got[1], self.flat_g)
-        self.restore_train_state(saved)
+    def _verification_batch(self):
+        """Context manager: the verification of a forked graph must not run on an all-zero batch (nothing would distinguish a node that
+        read stale operands; zero targets make rel_loss 0/0 and NaN never equals NaN).  When the engine's input or target buffers are still
+        all zero -- capture before the first load_batch -- they hold a fixed pseudo-random batch for the check and get their bytes back after."""
+        eng = self
+
+        class _Ctx(object):
+            def __enter__(self):
+                self.saved = []
+                g = torch.Generator(device=eng.device)
+                g.manual_seed(20240607)
+                img = eng.in_images_u8 if eng.input_u8 else eng.in_images
+                if img is not None and not bool(img.any()):
+                    self.saved.append((img, img.clone()))
+                    if img.dtype == torch.uint8:
+                        img.copy_(torch.randint(0, 256, img.shape, generator=g, device=eng.device, dtype=torch.uint8))
+                    else:
+                        img.copy_((torch.rand(img.shape, generator=g, device=eng.device) * 255.0 - 110.0).to(img.dtype))
+                for name in ("gt_loc", "gt_ori", "gt_k3"):
+                    t = getattr(eng, name, None)
+                    if t is not None and t.numel() and not bool(t.any()):
+                        self.saved.append((t, t.clone()))
+                        r = torch.rand(t.shape, generator=g, device=eng.device) + 0.1
+                        t.copy_((r / r.sum(-1, keepdim=True)).to(t.dtype))     # rows that are valid soft labels and non-zero regression targets alike
+                return self
+
+            def __exit__(self, *exc):
+                for t, old in self.saved:
+                    t.copy_(old)
+        return _Ctx()
+
+    def _verify_forked_graph(self, gr, replays=None):
+        """The captured graph with its second branch against the same launches issued eagerly on one chain: `replays` steps each from the same
+        state (URSO_FORK_VERIFY_REPLAYS, default 4; the second replay is the first that shows a node run early: the first reads what the
+        warm-up step left), compared bit for bit on EVERYTHING a step writes: weights, gradients, momentum / Adam moments, BN statistics.
+        A graph executor that fails this (see _fork_weight_gradients) costs the engine its side branch, not its results.
+        Cost: 2 x replays training steps and two clones of the training state per capture (and per re-capture: set_input_u8 toggles,
+        set_trainable).  It runs again wherever verify_fork() is called (UrsoNet.train: once per epoch; tests/test_model_gpu.py holds a
+        200-replay stress test); bench.py repeats the comparison with two fresh engines before it times anything."""
+        n = int(replays if replays is not None else os.environ.get("URSO_FORK_VERIFY_REPLAYS", "4"))
+        with self._verification_batch():
+            saved = self.save_train_state()
+            for _ in range(n):
+                gr.replay()
+            torch.cuda.synchronize(self.device)
+            got = [t.clone() for t in (self.flat_w, self.flat_g, self.flat_v, self.flat_stats)]
+            self.restore_train_state(saved)
+            self._single_chain = True
+            try:
+                for _ in range(n):
+                    self.step_eager()
+            finally:
+                self._single_chain = False
+            torch.cuda.synchronize(self.device)
+            ok = all(torch.equal(a, b) for a, b in zip(got, (self.flat_w, self.flat_g, self.flat_v, self.flat_stats)))
+            ok = ok and bool(torch.isfinite(self.flat_g).all())       # (NaN never equals NaN: a non-finite check batch proves nothing either way)
+            self.restore_train_state(saved)
+        self.fork_checks = getattr(self, "fork_checks", 0) + 1
         if not ok:
             import warnings
             warnings.warn("ursonet_amd: the captured training graph with the weight gradients on a second branch does not reproduce the single chain "
@@ -1487,6 +1552,18 @@ class Engine(object):
             self._single_chain_always = True
             self._graphs = None
             self.capture()
+        return ok
+
+    def verify_fork(self, replays=None):
+        """Re-run the forked graph's check against the single chain on the batch that is loaded NOW (training state is restored afterwards).
+        True = the step runs forked and is verified; False = it runs (or from now on runs) on one chain."""
+        if self.mode != "training" or not self.forked:
+            return False
+        if self._graphs is None:
+            self.capture()                         # (verifies)
+            return self.forked
+        self._verify_forked_graph(self._graphs, replays)
+        return self.forked
 
     @property
     def forked(self):
@@ -1498,6 +1575,9 @@ class Engine(object):
         if self._graphs is None:
             self.capture()
         self._graphs.replay()
+        if self._cleared_once and os.environ.get("URSO_CHECK_CLEARED", "0") == "1":
+            bad = self.check_cleared_once()
+            assert not bad, "gradient buffers cleared at plan time hold values off their sampled grid: %s" % bad
 
     def forward(self):
         if self.mode == "training":
@@ -1555,7 +1635,7 @@ class Engine(object):
             return {"loc_loss": float(l[0]), "k2_loss": float(l[2]), "k3_loss": float(l[3])}
         return {"loc_loss": float(l[0]), "ori_loss": float(l[1])}
 
-    def evaluate(self):
+    def evaluate(self, read=True):
         """Forward + losses on the loaded batch WITHOUT touching any training state: what Keras' validation pass does
         (learning_phase 0, net.py:1155-1157).  In batch-statistics BN mode the moving statistics are restored afterwards (the
         forward kernels of the training plan update them) -- the normalisation itself still uses batch statistics there, which
@@ -1566,7 +1646,7 @@ class Engine(object):
             op()
         if stats is not None:
             self.flat_stats.copy_(stats)
-        return self.losses()
+        return self.losses() if read else None     # read=False: the scalars stay in loss_buf (UrsoNet.train copies them on the device, no sync)
 
     def set_lr(self, lr):
         self.hyper[0] = float(lr)

@@ -163,13 +163,26 @@ class BatchAssembler(object):
         return [self.images, self.meta, self.loc, self.ori]
 
 
-def batches(dataset, config, shuffle, batch_size, molded, workers=0):
+DP_SHUFFLE_SEED = 1234
+
+
+def batches(dataset, config, shuffle, batch_size, molded, workers=0, rank=0, world=1):
     """Endless iterator of BatchAssembler objects.  molded=True: images are mean-subtracted floats (the reference's generator
     format); False: uint8 frames for the device path.  Up to 5 failing samples are logged and skipped, the 6th re-raises
-    (net.py:553-559).  workers > 0 loads the raw samples of a batch with that many threads."""
+    (net.py:553-559).  workers > 0 loads the raw samples of a batch with that many threads.
+
+    world > 1 (data parallel, one process per GPU): every rank walks the SAME order over the dataset -- the shuffles come from a private
+    RandomState(DP_SHUFFLE_SEED), identical on all ranks, instead of NumPy's global one -- and keeps samples [rank * batch_size,
+    (rank + 1) * batch_size) of every global batch of world * batch_size: the ranks' shards are disjoint and together they are the batch a
+    single process with GPU_COUNT = world would have drawn.  The global RNG (augmentation draws) is seeded with DP_SHUFFLE_SEED + rank so
+    that the ranks do not apply identical warps to their different samples.  world == 1 is the reference's generator, draw for draw."""
     from .net import mold_image
     ids = np.copy(dataset.image_ids)
     cursor, errors = -1, 0
+    order_rng = None
+    if world > 1:
+        order_rng = np.random.RandomState(DP_SHUFFLE_SEED)
+        np.random.seed(DP_SHUFFLE_SEED + int(rank))
     pool = None
     if workers > 0:
         from concurrent.futures import ThreadPoolExecutor
@@ -184,16 +197,19 @@ def batches(dataset, config, shuffle, batch_size, molded, workers=0):
         except Exception:
             logging.exception("Error processing image {}".format(dataset.image_info[image_id]))
             return None
+    def advance():
+        nonlocal cursor
+        cursor = (cursor + 1) % len(ids)
+        if shuffle and cursor == 0:
+            (order_rng or np.random).shuffle(ids)
+        return ids[cursor]
     while True:
         chosen = []
+        for _ in range(rank * batch_size if world > 1 else 0):      # the samples of this global batch that belong to the ranks before this one
+            advance()
         while len(chosen) < batch_size:
             want = batch_size - len(chosen)
-            todo = []
-            for _ in range(want):
-                cursor = (cursor + 1) % len(ids)
-                if shuffle and cursor == 0:
-                    np.random.shuffle(ids)
-                todo.append(ids[cursor])
+            todo = [advance() for _ in range(want)]
             loaded = list(pool.map(safe_load, todo)) if pool is not None else [safe_load(i) for i in todo]
             for s in loaded:
                 if s is None:
@@ -202,6 +218,8 @@ def batches(dataset, config, shuffle, batch_size, molded, workers=0):
                         raise RuntimeError("more than 5 samples failed to load (net.py:553-559)")
                 else:
                     chosen.append(s)
+        for _ in range((world - 1 - rank) * batch_size if world > 1 else 0):     # ... and to the ranks behind it
+            advance()
         augment_samples(chosen, dataset, config)
         asm = None
         for b, s in enumerate(chosen):
@@ -217,7 +235,7 @@ class DeviceFeeder(object):
     side copies batch k+1 to a device staging buffer on a SIDE stream while step k runs, and `next_into(engine)` makes the
     engine's input buffers hold the next batch (device-to-device copy ordered after the upload by an event)."""
 
-    def __init__(self, engine, dataset, config, shuffle=True, workers=4, depth=3):
+    def __init__(self, engine, dataset, config, shuffle=True, workers=4, depth=3, rank=0, world=1):
         import torch
         self.eng, self.torch = engine, torch
         self.q = queue.Queue(maxsize=depth)
@@ -229,7 +247,7 @@ class DeviceFeeder(object):
         self.consumed = [None, None]                           # recorded on the compute stream once a slot's batch has been copied out of it
         self.k = 0
         self.pinned_bytes = 0
-        gen = batches(dataset, config, shuffle, engine.B, molded=False, workers=workers)
+        gen = batches(dataset, config, shuffle, engine.B, molded=False, workers=workers, rank=rank, world=world)
 
         def produce():
             from . import hip

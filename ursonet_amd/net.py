@@ -204,9 +204,24 @@ class UrsoNet(object):
         assert mode in ['training', 'inference']
         graph = build_graph(config)                   # raises the 'dividable by 2 at least 6 times' Exception
         self._graph = graph
+        self._dp, self._rank, self._world = None, 0, 1
         if build_engine:
             from .engine import Engine
-            self._engine = Engine(config, mode)
+            from . import dp
+            world = dp.launcher_world()[2]
+            if mode == "training" and world > 1:
+                # under a launcher (`python -m torch.distributed.run --nproc-per-node N pose_estimator.py train ...`): one process per GPU, this
+                # rank's engine takes IMAGES_PER_GPU samples of every global batch of IMAGES_PER_GPU x WORLD_SIZE, the gradient exchange is
+                # ursonet_amd.dp.DataParallelEngine (RCCL).  The reference's own knob for this is GPU_COUNT (config.py:20,154) feeding a
+                # ParallelModel it left commented out (net.py:694-697); the launcher's world size takes its place
+                self._rank, _, self._world = dp.init_from_launcher()
+                gc = int(getattr(config, "GPU_COUNT", 1))
+                assert gc in (1, self._world), "GPU_COUNT = %d but the launcher started %d ranks" % (gc, self._world)
+                self._engine = Engine(config, mode, batch=int(config.IMAGES_PER_GPU))
+                self._dp = dp.DataParallelEngine(self._engine, bucket_bytes=int(getattr(config, "DP_BUCKET_BYTES", 32 << 20)),
+                                                 compress=getattr(config, "DP_COMPRESS", None))
+            else:
+                self._engine = Engine(config, mode)
         return KerasModelShim(self, graph)
 
     # ---------------------------------------------------------------- checkpoints / log dirs
@@ -308,35 +323,67 @@ class UrsoNet(object):
         # the reference hands Keras two Python generators and `workers = cpu_count` processes (net.py:1100-1163); here a producer
         # thread + loader threads assemble uint8 batches in pinned memory and a side stream uploads batch k+1 while step k runs
         from .feeder import DeviceFeeder
+        import torch
         workers = int(getattr(cfg, "LOADER_WORKERS", min(8, os.cpu_count() or 1)))
-        train_feed = DeviceFeeder(eng, train_dataset, cfg, shuffle=True, workers=workers)
-        val_feed = DeviceFeeder(eng, val_dataset, cfg, shuffle=True, workers=workers) if int(cfg.VALIDATION_STEPS) > 0 else None
+        rank, world, runner = self._rank, self._world, (self._dp or eng)
+        # data-parallel run: every rank walks the SAME shuffled order and takes samples [rank * B, (rank + 1) * B) of each global batch (feeder.batches)
+        train_feed = DeviceFeeder(eng, train_dataset, cfg, shuffle=True, workers=workers, rank=rank, world=world)
+        val_feed = (DeviceFeeder(eng, val_dataset, cfg, shuffle=True, workers=workers, rank=rank, world=world)
+                    if int(cfg.VALIDATION_STEPS) > 0 else None)
         history_full = BatchLogger()
-        log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
-        log("Checkpoint Path: {}".format(self.checkpoint_path))
-        self.set_trainable(layers)
+        chief = rank == 0
+        if chief:
+            log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
+            log("Checkpoint Path: {}".format(self.checkpoint_path))
+            if world > 1:
+                log("Data parallel: {} ranks x {} images (global batch {})".format(world, eng.B, world * eng.B))
+        self.set_trainable(layers, verbose=1 if chief else 0)
         self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
-        os.makedirs(self.log_dir, exist_ok=True)
+        if chief:
+            os.makedirs(self.log_dir, exist_ok=True)
+        steps, vsteps = int(cfg.STEPS_PER_EPOCH), int(cfg.VALIDATION_STEPS)
+        # Keras' BatchLogger reads the batch's losses after every step (net.py:1106-1115): a device -> host round trip per 7 ms step.  Here each
+        # step's loss scalars are copied into a device-side history row (same stream, no synchronisation) and read ONCE per epoch -- the same
+        # per-batch lists, no bubble; under data parallelism the rows are averaged over the ranks first (the loss of the global batch)
+        n_loss = int(eng.loss_buf.numel())
+        hist = torch.zeros(max(steps, 1), n_loss, dtype=torch.float32, device=eng.device)
+        vhist = torch.zeros(max(vsteps, 1), n_loss, dtype=torch.float32, device=eng.device)
+        kp = bool(cfg.REGRESS_KEYPOINTS)
         clr_it = 0
         for epoch in range(self.epoch, epochs):
-            for _ in range(int(cfg.STEPS_PER_EPOCH)):
+            for i in range(steps):
                 if cfg.CLR:
                     eng.set_lr(utils.clr_triangular(clr_it, cfg.BASE_LEARNING_RATE, cfg.MAX_LEARNING_RATE, cfg.CLR_STEP_SIZE))
                     clr_it += 1
                 train_feed.next_into()
-                eng.step()
-                ls = eng.losses()
-                history_full.ori_loss_acc.append(ls.get("ori_loss"))      # None in keypoint mode, as logs.get('ori_loss') is (net.py:1112)
-                history_full.loc_loss_acc.append(ls["loc_loss"])
-            val = {}
-            for _ in range(int(cfg.VALIDATION_STEPS)):
+                runner.step()
+                hist[i].copy_(eng.loss_buf.view(-1), non_blocking=True)
+            for i in range(vsteps):
                 val_feed.next_into()
-                for k, v in eng.evaluate().items():
-                    val.setdefault(k, []).append(v)
-            log("epoch %d  loc_loss %.5f  %s" % (
-                epoch + 1, float(np.mean(history_full.loc_loss_acc[-int(cfg.STEPS_PER_EPOCH):])),
-                "  ".join("val_%s %.5f" % (k, float(np.mean(v))) for k, v in sorted(val.items()))))
-            self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))
+                eng.evaluate(read=False)
+                vhist[i].copy_(eng.loss_buf.view(-1), non_blocking=True)
+            if world == 1 and eng.forked:
+                eng.verify_fork()                       # the forked backward pass against the single chain on this epoch's last batch (engine.py)
+            if world > 1:
+                from . import dp
+                dp.average_over_ranks(hist)
+                dp.average_over_ranks(vhist)
+            h = hist[:steps].cpu().numpy()
+            for row in h:
+                history_full.ori_loss_acc.append(None if kp else float(row[1]))   # None in keypoint mode, as logs.get('ori_loss') is (net.py:1112)
+                history_full.loc_loss_acc.append(float(row[0]))
+            val = {}
+            if vsteps:
+                v = vhist[:vsteps].cpu().numpy().mean(0)
+                val = ({"loc_loss": v[0], "k2_loss": v[2], "k3_loss": v[3]} if kp else {"loc_loss": v[0], "ori_loss": v[1]})
+            if chief:
+                log("epoch %d  loc_loss %.5f  %s" % (
+                    epoch + 1, float(np.mean(h[:, 0])) if steps else float("nan"),
+                    "  ".join("val_%s %.5f" % (k, float(x)) for k, x in sorted(val.items()))))
+                self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))     # replicas are identical: one writer
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()                          # nobody runs ahead of the checkpoint (find_last on another rank sees it)
         train_feed.close()
         if val_feed is not None:
             val_feed.close()
