@@ -76,10 +76,15 @@ class SyntheticPoses(Dataset):
             codec = utils.OrientationCodec(config.ORI_BINS_PER_DIM, config.BETA)
             enc = codec.encode(q)
             self.ori_histogram_map, self.ori_output_mask = codec.H_quat, codec.redundant
+        loc_enc = None
+        if not config.REGRESS_LOC:
+            # classification location head: soft labels over the (x/z, y/z, z) grid, as urso.py:85-93 builds them with utils.encode_loc
+            xyz = np.stack([t[:, 0] / t[:, 2], t[:, 1] / t[:, 2], t[:, 2]], axis=1)
+            loc_enc, self.loc_histogram_map = utils.encode_loc(xyz, config.LOC_BINS_PER_DIM, config.BETA, xyz.max(0), xyz.min(0))
         for i in range(n):
             self.add_image("SYN", image_id=i, path="synthetic://%d" % i, location=t[i], quaternion=q[i],
                            pyr=np.zeros(3, dtype=np.float32), angleaxis=np.zeros(3, dtype=np.float32),
-                           keypoints=[np.zeros(3), np.zeros(3)], location_map=[],
+                           keypoints=[np.zeros(3), np.zeros(3)], location_map=[] if loc_enc is None else loc_enc[i],
                            ori_map=[] if config.REGRESS_ORI else enc[i])
         self._image_ids = np.arange(n)
 
