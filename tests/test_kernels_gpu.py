@@ -388,6 +388,28 @@ def test_mold_images_float_source(dt, shape):
         assert torch.equal(out[..., :3].float(), ref.to(hip.TORCH_DT[dt]).float()) and float(out[..., 3].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 6, 12), (3, 5, 7)], ids=["octets", "octets_small", "ragged"])
+def test_mold_images_uint8_source_eight_pixels_per_thread(dt, shape):
+    """urso_mold_images on uint8 frames (Engine.load_batch_u8; net.py:1346 mold_image): the 8-pixels-per-thread form (round 6) against the
+    one-pixel form (option mold_scalar) and against torch, bit for bit; pixel counts that are no multiple of 8 keep the scalar form."""
+    hip = _hip()
+    B, H, W = shape
+    torch.manual_seed(6)
+    src = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8).cuda()
+    mean = torch.tensor([123.7, 116.8, 103.9]).cuda()
+    outs = []
+    for scalar in (0, 1):
+        with hip.options(mold_scalar=scalar):
+            out = torch.full((B, H, W, 4), 7.0, dtype=hip.TORCH_DT[dt], device="cuda")
+            hip.mold_images(B, H, W, src, mean, dt, out)
+            torch.cuda.synchronize()
+            outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = (src.float() - mean).to(hip.TORCH_DT[dt])
+    assert torch.equal(outs[0][..., :3], ref) and float(outs[0][..., 3].float().abs().max()) == 0.0
+
+
 def _stem_case(hip, dt, B, H, W, N):
     torch.manual_seed(7)
     img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)

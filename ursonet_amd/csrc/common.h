@@ -45,6 +45,7 @@ struct UrsoOptions {
     int pwx = 1;             // conv_pwx.hip (8-wave 160-row-tile pointwise GEMM): 0 off, 1 the reduction-heavy layers (K >= 512), 2 every supported layer
     int pwx_dbg = 0;         // kernel-development switches of conv_pwx.hip (0 in production): 1 no copies after the prologue, 2 no MFMAs, 4 no epilogue
     int pwx_bn = 0;          // 128 / 256: force its tile width (tests); 0 = by tile-count rounding
+    int mold_scalar = 0;     // 1: urso_mold_images keeps the one-pixel-per-thread form for uint8 frames (A/B, tests; default: 8 pixels per thread, round 6)
     int bneck = 3;           // conv_bneck.hip, bottleneck_layer (3x3 / stride 2, <= 32 filters): bit 0 its data gradient by parity class (no zero taps), bit 1 its forward pass in one launch (LDS-staged, no split-K workspace)
 };
 extern UrsoOptions g_urso_opt;

@@ -450,10 +450,20 @@ __global__ __launch_bounds__(512, 2) void c3w_kernel(const C3Args a) {
 //   * a fragment (halo row hr, column shift kx, 32-channel step j) is read once and multiplied with the taps ky = 0..2 it serves (output rows
 //     hr - ky): 120 ds_read_b128 per 288 MFMAs and wave; every wave reads the whole patch (960 KiB of LDS reads per tile: 42 % of the port at the
 //     matrix pipe's pace);
-//   * pixel rows are 256 B = 16 slots, slot ^ (halo column & 15): conflict-free for kx = 0 and 2, two 2-way conflicts per instruction for kx = 1
-//     (ds_read_b128 serves lanes {0-3, 12-15, 20-27} together: the k groups' pixel sets shift with kx);
+//   * pixel rows are 256 B = 16 slots, slot ^ c3v_swz(halo column): conflict-free for every kx (round 6; (halo column & 15) had two 2-way conflicts
+//     per instruction for kx = 1: ds_read_b128 serves lanes {0-3, 12-15, 20-27} together, the k groups' pixel sets shift with kx);
 //   * the accumulators (lane: one pixel, 4 consecutive filters) go through a 32 KiB output tile (8-byte stores, slot ^ (pixel & 15)) to
 //     row-contiguous 16-byte stores; that tile is separate from the patch buffers, so the next tile's MFMAs wait for nothing but their patch.
+// Round 6: slot ^ c3v_swz(halo column) with a 16-entry table instead of (halo column & 15).  ds_read_b128 serves the lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} (+32): pixel columns fr + kx for fr in {0-3, 12-15} with channel group fg and fr in {4-11} with fg ^ 1.  With the identity
+// table the shifted window kx = 1 puts two pairs of lanes on one slot (two 2-way conflicts per instruction, SQ_LDS_BANK_CONFLICT 0.265 of the kernel's
+// LDS cycles in profiles/r05_mfma_util.json); the table below makes i -> T[(kx + i) & 15] ^ [4 <= i < 12] a bijection for kx = 0, 1 and 2 (found by
+// search, checked against the lane groups of MI355X_MICROARCH.md's LDS table): no conflict for any (kx, j).  Placement only: results are bit-identical.
+#ifdef C3V_OLD_SWZ                 // (A/B through URSO_VARIANT_FLAGS: the identity table of rounds 5)
+__device__ __forceinline__ uint32_t c3v_swz(int col) { return (uint32_t)(col & 15); }
+#else
+__device__ __forceinline__ uint32_t c3v_swz(int col) { return (uint32_t)(0xfe64dcba98643210ull >> (4 * (col & 15))) & 15u; }
+#endif
 constexpr int C3V_HW = 18, C3V_HPIX = 10 * C3V_HW, C3V_PATCH = C3V_HPIX * 256;       // 180 halo pixels, 45 KiB
 constexpr int C3V_NA = 6;                                                             // DMA instructions per lane: 8 waves x 6 >= 45 (4 pixels each)
 #ifndef C3V_PF
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void c3v_kernel(const C3Args a) {
             const int hy = (hp * 3641) >> 16, hx = hp - hy * C3V_HW;      // hp / 18 for hp < 256
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool ok = ii < 45 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + (((lane_d & 15) ^ (hx & 15)) << 4));
+            const uint32_t off = (uint32_t)(base + (hy * a.W + hx) * 256 + (((uint32_t)(lane_d & 15) ^ c3v_swz(hx)) << 4));
             if (ii < 45) c3_dma16(rs, lds0 + buf * C3V_PATCH + ii * 1024, ok ? off : URSO_OOB_SHIFT);
         }
     };
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void c3v_kernel(const C3Args a) {
     // fragment read addresses: pixel (hr, fr + kx) of the patch, slot (4 j + fg) ^ ((fr + kx) & 15) -- the lane part per kx, hr and j added at use
     uint32_t ea[3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) ea[kx] = (uint32_t)((fr + kx) * 256 + ((fg ^ ((fr + kx) & 15)) << 4));
+    for (int kx = 0; kx < 3; ++kx) ea[kx] = (uint32_t)((fr + kx) * 256) + (((uint32_t)fg ^ c3v_swz(fr + kx)) << 4);
     constexpr int NST = 4;                                     // 128 pixels x 16 slots = 2048 vectors / 512 threads
     // The output tile is double-buffered and its way to memory is deferred by one tile: a tile's epilogue only writes the accumulators into
     // its LDS tile (and requests the mask vectors); the row-contiguous reads of that tile and the global stores run at the top of the NEXT

@@ -28,7 +28,7 @@ static int* opt_slot(const char* name) {
     if (!name) return nullptr;
 #define URSO_OPT(n) if (!strcmp(name, #n)) return &g_urso_opt.n;
     URSO_OPT(pw_kernel) URSO_OPT(pw_small) URSO_OPT(igemm_shortk) URSO_OPT(wgrad_narrow) URSO_OPT(wgrad_blocks) URSO_OPT(wgrad_pipe) URSO_OPT(wgrad_ring) URSO_OPT(wgrad_big)
-    URSO_OPT(grid_cap) URSO_OPT(hconv) URSO_OPT(hconv_dbg) URSO_OPT(hconv2) URSO_OPT(hconv2_shape) URSO_OPT(hconv_streamk) URSO_OPT(pair) URSO_OPT(pair_single) URSO_OPT(c3) URSO_OPT(c3v) URSO_OPT(stem) URSO_OPT(stem_pool) URSO_OPT(cus) URSO_OPT(hwgrad) URSO_OPT(dense) URSO_OPT(pwx) URSO_OPT(pwx_bn) URSO_OPT(pwx_dbg) URSO_OPT(bneck)
+    URSO_OPT(grid_cap) URSO_OPT(hconv) URSO_OPT(hconv_dbg) URSO_OPT(hconv2) URSO_OPT(hconv2_shape) URSO_OPT(hconv_streamk) URSO_OPT(pair) URSO_OPT(pair_single) URSO_OPT(c3) URSO_OPT(c3v) URSO_OPT(stem) URSO_OPT(stem_pool) URSO_OPT(cus) URSO_OPT(hwgrad) URSO_OPT(dense) URSO_OPT(pwx) URSO_OPT(pwx_bn) URSO_OPT(pwx_dbg) URSO_OPT(bneck) URSO_OPT(mold_scalar)
 #undef URSO_OPT
     return nullptr;
 }
