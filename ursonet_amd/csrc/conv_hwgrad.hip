@@ -105,6 +105,13 @@ __device__ __forceinline__ void hwgrad_body(const HwgArgs& a, const int bid, con
     static_assert(sizeof(T) == 2, "16-bit element types only");
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "Two waves per SIMD" item 4: the younger wave of a
+    // SIMD loses every issue arbitration against its older partner; one s_setprio for the whole kernel, no per-segment flips).  Round 6, same
+    // box, single-chain layer profile: hwgrad2 98.0 / 97.6 / 93.8 / 94.0 / 93.2 -> 94.4 / 93.2 / 90.9 / 91.6 / 89.5 us (-3 ... -4.5 %); the same line
+    // in hconv2, pwx, c3v and the 256 x 256 grouped weight gradient changed nothing (profiles/r06_ab_prio.txt).  URSO_NO_PRIO_YOUNG: A/B.
+#ifndef URSO_NO_PRIO_YOUNG
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int ct = wave & 1, nt = (wave >> 1) & 1, tg = wave >> 2;
     const int l31 = lane & 31, h = lane >> 5, l15 = lane & 15, g = lane >> 4;
 
