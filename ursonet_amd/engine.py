@@ -531,6 +531,7 @@ class Engine(object):
             if self.layer_trainable[node.name] or (folded_bn and self.layer_trainable[node.bn]):
                 groups.setdefault(bucket_of[node.name], []).append(node.name)
         last_of_group = {names[-1]: k for k, names in groups.items()}
+        self._bucket_groups = groups                # (param_pass_bytes: what the batched parameter-sized launches of a bucket move)
         # which activation gradients are needed at all: a tensor's gradient only if a trainable parameter lies at or upstream of its
         # producer.  With layers='heads' / '4+' / '5+' (net.py:1086-1095) the data-gradient chain stops at the earliest trainable
         # layer instead of running through the frozen backbone (TF prunes those gradients too)
@@ -1441,6 +1442,33 @@ class Engine(object):
         self._check_plan_options()
         self.run_prep(); self.run_forward(); self.run_backward(); self.run_optimizer()
 
+    def param_pass_bytes(self, label):
+        """Algorithmic bytes of a batched parameter-sized launch, from the descriptor table (the library's launch profiler reports none for
+        them: a launch covers many layers).  prep: fp32 filter in, compute-type forward + flipped layouts out; reduce: the split partials of
+        the layers with more than FUSE_MAX partials in, their fp32 sum out; finalize_mat: fp32 filter + the partials the launch sums itself
+        (2 ... FUSE_MAX) or the reduced sum in, fp32 gradient out.  None for other labels."""
+        FUSE_MAX = int(os.environ.get("URSO_FUSE_REDUCE_MAX", "16"))
+        es = 4 if self.dt == hip.F32 else 2
+        kind = label.split(":")[0]
+        if kind == "prep" and "batched" in label:
+            ds = list(self._descs)
+        elif kind in ("reduce", "finalize_mat") and "bucket" in label:
+            k = int(label.split("bucket")[1])
+            ds = [self.convs[nm].desc for nm in self._bucket_groups[k]]
+        else:
+            return None
+        total = 0.0
+        for d in ds:
+            K, N, npad, sp = int(d.K), int(d.N), int(d.npad), max(int(d.splits), 1)
+            if kind == "prep":
+                total += K * N * 4 + K * npad * es * (2 if d.wd else 1)
+            elif kind == "reduce":
+                if sp > FUSE_MAX:
+                    total += (sp + 1) * K * npad * 4
+            else:
+                total += 2 * K * N * 4 + (sp if 1 < sp <= FUSE_MAX else 1) * K * npad * 4
+        return total
+
     def profile_step(self):
         """One eager training step with the library's HIP-event launch profiler on.
         Returns [(label, kernel_id, ms, flops, bytes, n_kernels, device_symbol)] in launch order."""
@@ -1458,7 +1486,14 @@ class Engine(object):
             self._single_chain = False
             hip.prof_enable(False)
         assert len(recs) == len(labels), (len(recs), len(labels))
-        return [(l,) + r for l, r in zip(labels, recs)]
+        out = []
+        for l, r in zip(labels, recs):
+            if not r[3]:                            # no bytes from the library: the batched parameter-sized passes are priced from the descriptor table
+                by = self.param_pass_bytes(l)
+                if by:
+                    r = r[:3] + (by,) + r[4:]
+            out.append((l,) + r)
+        return out
 
     def capture(self):
         """Capture the step (training) or prep+forward (inference) into a hipGraph."""
