@@ -221,6 +221,10 @@ class UrsoNet(object):
                 self._dp = dp.DataParallelEngine(self._engine, bucket_bytes=int(getattr(config, "DP_BUCKET_BYTES", 32 << 20)),
                                                  compress=getattr(config, "DP_COMPRESS", None))
             else:
+                if world > 1:                           # inference under a launcher: N independent replicas, each on its own GPU, no exchange
+                    import torch
+                    self._rank, local, self._world = dp.launcher_world()
+                    torch.cuda.set_device(int(os.environ.get("URSO_DP_DEVICE", local % max(torch.cuda.device_count(), 1))))
                 self._engine = Engine(config, mode)
         return KerasModelShim(self, graph)
 
