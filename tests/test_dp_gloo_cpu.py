@@ -306,3 +306,37 @@ def test_error_feedback_remainder_of_frozen_layers_is_dropped_on_replan():
     r = out.get(timeout=120)
     p.join(60)
     assert np.all(r[100:400] == 0.25) and np.all(r[:100] == 0.0) and np.all(r[400:] == 0.0)
+
+
+def _worker_helpers(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ursonet_amd import dp
+    assert dp.launcher_world() == (rank, rank, world)                 # from the launcher's environment, before a group exists
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dp.launcher_world() == (rank, rank, world)                 # ... and from the group once it does
+    t = torch.full((3, 4), float(rank + 1))
+    dp.average_over_ranks(t)
+    w = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    dp.broadcast_(w, 0)
+    s = torch.tensor([1.0 + rank, 10.0])
+    dp.allreduce_sum_(s)
+    out[rank] = (t.tolist(), w.tolist(), s.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_launcher_helpers_of_the_drop_in_boundary(monkeypatch):
+    """What net.UrsoNet / UrsoNet.train use under a launcher (ursonet_amd/dp.py): rank / world from the environment, the rank-averaged loss
+    history, the weight broadcast and the two-scalar sum of exact rel_loss -- two gloo ranks on CPU tensors.  A plain process is (0, 0, 1)."""
+    from ursonet_amd import dp
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert dp.launcher_world() == (0, 0, 1)
+    t = torch.ones(2)
+    assert dp.average_over_ranks(t) is t and t.tolist() == [1.0, 1.0]          # no process group: identity
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_helpers, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        t, w, s = out[rank]
+        assert t == [[1.5] * 4] * 3 and w == [0.0, 1.0, 2.0, 3.0, 4.0] and s == [3.0, 20.0]

@@ -294,6 +294,7 @@ class DataParallelEngine(object):
         # a wrapper that is dropped without close() must not keep `cus` / `hconv_streamk` held for the rest of the process
         import weakref
         self._finalizer = weakref.finalize(self, _release_holds, self._holds)
+        self._finalizer.atexit = False                  # (nothing to give back at interpreter exit)
 
     def _init_policy(self, eng, explicit, comm, bucket_bytes, tail_bytes, replan):
         if self.comm_cus and eng.device.type == "cuda" and (self.world > 1 or (explicit and _force_collectives())):
