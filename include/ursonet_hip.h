@@ -219,6 +219,20 @@ int urso_conv_pointwise_sampled_ok(const urso_conv_geom* g, int dt, int flags, i
 int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, const void* src_d, const void* wgt_d, const float* bias_d,
                                 const void* add_d, void* dst_d, void* bits_out_d, void* dst_sampled_d, void* stream);
 
+/* TWO pointwise convolutions over the same pixels, summed, in one launch (conv_pwx.hip, two reduction segments):
+ *   dst[M][N] = epilogue(src0[M][C0] . wgt0[N][C0]^T + src1[M][C1] . wgt1[N][C1]^T),  M = B * OH * OW dense pixels.
+ * The case it exists for: the data gradients that meet in the input X of a stage's first block -- Conv2DBackpropInput of the projection
+ * shortcut 'res{3,4,5}a_branch1' (net.py:148-157) and of 'res{3,4,5}a_branch2a' (net.py:138), both 1x1 / stride 2 on X -- on the compact
+ * (sampled) gradient grid: dL/dX is written once, rounded once, instead of written by one launch, read back and rewritten by the other.
+ * 16-bit dtypes, C0 % 64 == C1 % 64 == 0, N % 8 == 0; wgt* in the [N][K] data-gradient layout of urso_conv_weight_prep; flags:
+ * URSO_EPI_RELU, URSO_EPI_MASK_BITS with mask_d = the ReLU bit mask of dst (1 byte per 8 elements; N % 32 == 0 then).  urso_conv_pointwise2_ok() tells
+ * whether the big-tile kernel takes the pair (else the caller launches the two layers one after the other); same k order per segment as
+ * the single-layer kernel, segment 0 first. */
+int urso_conv_pointwise2_ok(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags);
+int urso_conv_pointwise2(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags,
+                         const void* src0_d, const void* wgt0_d, const void* src1_d, const void* wgt1_d,
+                         const float* bias_d, const void* mask_d, void* dst_d, void* stream);
+
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel).  Given a workspace of
  * urso_conv_igemm_halo_ws_bytes() through ws_d, that kernel balances the chip where whole tiles do not (e.g. 340 tiles on 256 CUs):

@@ -438,7 +438,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "symbol %s declared in include/ursonet_hip.h is not exported" % s
     assert set(syms) == set(hip.EXPORTED_SYMBOLS), set(syms) ^ set(hip.EXPORTED_SYMBOLS)
-    assert hip._lib.urso_abi_version() == 8
+    assert hip._lib.urso_abi_version() == 9
 
 
 def test_policy_options_are_explicit_and_never_read_the_environment():

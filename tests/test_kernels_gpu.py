@@ -887,6 +887,59 @@ def test_batch_stat_bn_kernels_against_autograd(dt, MN):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("masked", [True, False], ids=["relu_bits", "plain"])
+@pytest.mark.parametrize("shape", [(2, 32, 40, 1024, 256, 512, 0), (4, 16, 20, 2048, 512, 1024, 0), (2, 64, 80, 512, 128, 256, 0), (3, 20, 24, 256, 320, 128, 16),
+                                   (1, 16, 20, 64, 512, 136, 0), (1, 16, 20, 64, 512, 160, 8)],
+                         ids=["stage4_entry", "stage5_entry", "stage3_entry", "ragged_capped", "short_first_segment", "short_first_segment_n160"])
+def test_pointwise2_two_reduction_segments(dt, masked, shape):
+    """urso_conv_pointwise2 (conv_pwx.hip, SEG2): dst = mask(src0 . W0^T + src1 . W1^T) -- the data gradients of a stage's projection shortcut and
+    branch2a into the stage's input as ONE launch (net.py:121-126, 138, 148-157) -- against a CPU fp32 reference rounded once, and against the
+    two urso_conv_igemm_ex launches it replaces (those round the first product to 16 bits before the second is added: one more rounding
+    step).  Shapes: the three entry blocks of ResNet-50 at reduced pixel counts, a ragged one with a capped grid (every block walks several
+    tiles across the segment switch), and a first segment of ONE K-tile."""
+    hip = _hip()
+    B, OH, OW, C0, C1, N, cap = shape
+    M = B * OH * OW
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + C0 + dt)
+    flags = hip.EPI_MASK_BITS if masked else 0
+    with hip.options(pwx=2, grid_cap=cap):
+        if masked and N % 32:                               # the bit mask is read a dword (32 channels) at a time
+            assert not hip.conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags)
+            return
+        assert hip.conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags)
+        assert not hip.conv_pointwise2_ok(B, OH, OW, C0 + 8, C1, N, dt, flags) and not hip.conv_pointwise2_ok(B, OH, OW, C0, C1, N, 0, flags)
+        x0, x1 = dev(torch.randn(M, C0), dt), dev(torch.randn(M, C1), dt)
+        w0, w1 = dev(torch.randn(N, C0) / C0 ** 0.5, dt), dev(torch.randn(N, C1) / C1 ** 0.5, dt)
+        keep = torch.rand(M, N, device="cuda") > 0.4
+        bits = (keep.reshape(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8) if masked else None
+        dst = torch.full((M, N), 9.0, device="cuda").to(tdt)
+        hip.conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, x0, w0, x1, w1, None, bits, dst)
+        torch.cuda.synchronize()
+        f = lambda t: t.float().cpu()
+        ref = f(x0) @ f(w0).T + f(x1) @ f(w1).T
+        if masked:
+            ref = ref * keep.cpu()
+        ref = ref.to(tdt).float()
+        tol = 8e-3 if dt == 1 else 1e-3                     # one rounding step of values of a few units
+        assert float((f(dst) - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+        if masked:
+            assert float(f(dst)[~keep.cpu()].abs().max()) == 0.0
+        # the two launches it replaces: first product stored (rounded), then added to the second
+        g0, g1 = hip.geom(B, OH, OW, C0, OH, OW, N, 1, 1), hip.geom(B, OH, OW, C1, OH, OW, N, 1, 1)
+        two = torch.empty_like(dst)
+        hip.conv_igemm_ex(g0, dt, flags, x0, w0, None, None, bits, two, None)
+        hip.conv_igemm_ex(g1, dt, flags, x1, w1, None, two, bits, two, None)
+        torch.cuda.synchronize()
+        assert float((dst.float() - two.float()).abs().max()) <= 2 * tol * max(1.0, float(two.float().abs().max()))
+        # deterministic: a second launch writes the same bits
+        again = torch.empty_like(dst)
+        hip.conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, x0, w0, x1, w1, None, bits, again)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, again)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
 @pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0), (32, 32, 40, 0)],
                          ids=["one_tile", "small", "capped", "multi_tile", "chip"])

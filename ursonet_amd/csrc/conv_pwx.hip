@@ -21,6 +21,7 @@
 // semantics (bias, residual, ReLU, mask tensor / ReLU bit mask, emitted bit mask, scatter destination) as conv_pw.hip; results are
 // bit-identical to it (same MFMA, same k order inside a 64-wide K-tile, same fp32 epilogue).
 #include "common.h"
+#include <string.h>
 
 struct PxArgs {
     const void* src; const void* wgt; const float* bias; const void* add; const void* mask; void* dst; void* bits_out;
@@ -30,6 +31,11 @@ struct PxArgs {
     float rcp_ohw, rcp_ow;
     int relu;
     int dbg;                           // urso_set_option("pwx_dbg"): 1 no copies after the prologue, 2 no MFMAs, 4 no epilogue (timing experiments)
+    // SEG2 (round 6): a second reduction segment -- dst = epilogue(src . wgt^T + src1 . wgt1^T) over the same pixels and filters: K-tiles
+    // 0 .. nkt0 - 1 come from (src, wgt: C channels), nkt0 .. nkt - 1 from (src1, wgt1: C1 channels).  The two data gradients that meet in a
+    // stage's input (the projection shortcut's and branch2a's, net.py:121-126, 148-157) as ONE launch: the gradient tensor is written once
+    // instead of written, read back and written again, and rounded once.
+    const void* src1; const void* wgt1; uint32_t src1_bytes, wgt1_bytes; int C1, Kc1, nkt0;
 };
 
 __device__ __forceinline__ void px_dma16(const i32x4_t& rsrc, uint32_t lds_byte, uint32_t voff) {
@@ -43,7 +49,7 @@ __device__ __forceinline__ i32x4_t px_rsrc(const void* p, uint32_t bytes) {
 template <int N> __device__ __forceinline__ void px_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // MASKK: 0 none, 1 mask tensor like dst (keep where > 0), 2 ReLU BIT mask (1 byte per 16-byte vector of dst); EMIT: write such a bit mask
-template <typename T, int TMW, int BN, int NST, bool HAS_ADD, int MASKK, bool EMIT>
+template <typename T, int TMW, int BN, int NST, bool HAS_ADD, int MASKK, bool EMIT, bool SEG2 = false>
 __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
     static_assert(sizeof(T) == 2, "16-bit element types only");
     constexpr bool HAS_MASK = MASKK == 1;
@@ -95,14 +101,30 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
         const int nrow = w * WN + (j / JPV) * 4 * VE + qq * VE + (j % JPV) * 4 + t;
         bsrc[q] = (uint32_t)nrow * (uint32_t)a.Kc * 16u + (uint32_t)((c8 ^ lds_swz(R)) << 4);
     }
+    uint32_t asrc1[SEG2 ? RA : 1], bsrc1[SEG2 ? RB : 1];                       // the same rows of segment 1's tensors (row strides C1 / Kc1)
+    if constexpr (SEG2) {
+#pragma unroll
+        for (int q = 0; q < RA; ++q) { const int R = 8 * ga[q] + r8; asrc1[q] = (uint32_t)R * (uint32_t)a.C1 * 2u + (uint32_t)((c8 ^ lds_swz(R)) << 4); }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int R = 8 * (wave + 8 * q) + r8;
+            const int w = R / WN, rr = R % WN, j = rr >> 4, qq = (rr & 15) >> 2, t = rr & 3;
+            const int nrow = w * WN + (j / JPV) * 4 * VE + qq * VE + (j % JPV) * 4 + t;
+            bsrc1[q] = (uint32_t)nrow * (uint32_t)a.Kc1 * 16u + (uint32_t)((c8 ^ lds_swz(R)) << 4);
+        }
+    }
     // DMA pointer: the next K-step to copy (tile dtile, K-tile dkt, dcnt = tiles completed by the pointer)
     int dtile = tile0, dkt = 0, dcnt = 0;
-    uint32_t d_a = 0, d_b = 0;
+    uint32_t d_a = 0, d_b = 0, d_a1 = 0, d_b1 = 0;
     auto dma_tile_base = [&]() {
         const bool ok = dtile < t_end;
         const int m0 = (dtile / a.tilesN) * BM, n0 = (dtile % a.tilesN) * BN;
         d_a = ok ? (uint32_t)m0 * (uint32_t)a.C * 2u : URSO_OOB_SHIFT;           // OOB_SHIFT + anything below 2 GiB stays out of range: zeros, no traffic
         d_b = ok ? (uint32_t)n0 * (uint32_t)a.Kc * 16u : URSO_OOB_SHIFT;
+        if constexpr (SEG2) {
+            d_a1 = ok ? (uint32_t)m0 * (uint32_t)a.C1 * 2u : URSO_OOB_SHIFT;
+            d_b1 = ok ? (uint32_t)n0 * (uint32_t)a.Kc1 * 16u : URSO_OOB_SHIFT;
+        }
     };
     dma_tile_base();
     auto dma_issue = [&](int stg) {
@@ -111,10 +133,21 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
             const int n0 = (dtile % a.tilesN) * BN;
             px_dma16(rbi, lds0 + BIAS_OFF + (uint32_t)(dcnt & 3) * 1024u, (dtile < t_end && lane * 4 < BN) ? (uint32_t)(n0 + lane * 4) * 4u : URSO_OOB_SHIFT);
         }
+        if (SEG2 && dkt == a.nkt0) { d_a = d_a1; d_b = d_b1; }      // (wave-uniform) entering the second segment: re-base the running offsets
+        if (SEG2 && dkt >= a.nkt0) {                       // ... and copy from the other pair of tensors
+            // (descriptors formed here from the kernel arguments, and ONE pair of running offsets for both segments: with a second pair
+            // incremented in this branch hipcc merged the two `+= 128` into a store through a selected address and kept all four in scratch)
+            const i32x4_t rs1 = px_rsrc(a.src1, a.src1_bytes), rw1 = px_rsrc(a.wgt1, a.wgt1_bytes);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) px_dma16(rw1, la + BM * 128 + (uint32_t)(wave + 8 * q) * 1024u, d_b + bsrc1[q]);
+#pragma unroll
+            for (int q = 0; q < RA; ++q) px_dma16(rs1, la + (uint32_t)ga[q] * 1024u, d_a + asrc1[q]);
+        } else {
 #pragma unroll
         for (int q = 0; q < RB; ++q) px_dma16(rw, la + BM * 128 + (uint32_t)(wave + 8 * q) * 1024u, d_b + bsrc[q]);
 #pragma unroll
         for (int q = 0; q < RA; ++q) px_dma16(rs, la + (uint32_t)ga[q] * 1024u, d_a + asrc[q]);
+        }
         d_a += 128u; d_b += 128u;                         // an OOB base stays out of range: nkt * 128 < 2 GiB
         if (++dkt == a.nkt) { dkt = 0; dtile += bpx; ++dcnt; dma_tile_base(); }
     };
@@ -298,29 +331,50 @@ __global__ __launch_bounds__(512, 2) void pwx_kernel(const PxArgs a) {
 // Returns 1 after launching, 0 when the layer does not take this kernel (conv_pw.hip then serves it), < 0 on a launch error.
 // Policy (option `pwx`: 0 off, 1 default, 2 every supported layer): pointwise 16-bit layers with whole 64-channel K-tiles whose
 // epilogue form is instantiated below, K >= 256 and enough work per CU that the matrix pipe, not the stream, is the bound.
+static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                        const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
+                        const void* src1, const void* wgt1, int C1, uint32_t src1_bytes, uint32_t wgt1_bytes, bool dry, hipStream_t st);
 int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
                  const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
                  hipStream_t st) {
+    return pwx_try_impl(g, dt, relu, src, wgt, bias, add, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, bits_out, nullptr, nullptr, 0, 0, 0, false, st);
+}
+// Two reduction segments (PxArgs::src1 ...): g describes segment 0 (C = its channels), C1 the channels of segment 1; `dry` only answers
+// whether the pair qualifies.  Forms: no residual, no emitted mask; mask = none or a ReLU bit mask.
+int urso_pwx_try2(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const void* src1, const void* wgt1, int C1,
+                  const float* bias, const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t src1_bytes, uint32_t wgt1_bytes,
+                  uint32_t dst_bytes, int mask_bits, bool dry, hipStream_t st) {
+    if (C1 <= 0 || (C1 % 64) || (mask && !mask_bits)) return 0;
+    return pwx_try_impl(g, dt, relu, src, wgt, bias, nullptr, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, nullptr, src1, wgt1, C1, src1_bytes, wgt1_bytes, dry, st);
+}
+static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
+                        const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
+                        const void* src1, const void* wgt1, int C1, uint32_t src1_bytes, uint32_t wgt1_bytes, bool dry, hipStream_t st) {
     const int mode = g_urso_opt.pwx;
     if (!mode) return 0;
+    const bool seg2 = C1 > 0;
     const int maskk = mask ? (mask_bits ? 2 : 1) : 0;
     const bool emit = bits_out != nullptr;
     // instantiated epilogue forms: (add, maskk, emit)
     const int form = (!add && !maskk && !emit) ? 0 : (add && !maskk && emit) ? 1 : (!add && maskk == 1 && !emit) ? 2 :
                      (add && maskk == 2 && !emit) ? 3 : (!add && maskk == 2 && !emit) ? 4 : (add && !maskk && !emit) ? 5 : -1;
     if (form < 0 || (g->C % 64) || (g->N % 8)) return 0;
+    if (seg2 && form != 0 && form != 4) return 0;
     const long long M = (long long)g->B * g->OH * g->OW;
-    const int K = g->C, N = g->N;
+    const int K = g->C + (seg2 ? C1 : 0), N = g->N;
     if (mode == 1) {
         // the HBM-bound c -> 4c layers stay where they are (register-filter kernel / conv_pw.hip); this kernel takes the reduction-heavy
         // ones: K >= 512 with at least 128 filters, on pixel counts where a 160-row tile grid fills the chip
         const bool s4_wide = K == 256 && N >= 1024 && !(g_urso_opt.pair_single & 1);      // (A/B: the stage-4 c -> 4c layers when conv_pair.hip is told to leave them)
         if ((K < 512 && !s4_wide) || N < 128 || M < 160 * 32) return 0;      // (half a chip of 160 x 128 tiles still beats conv_pw.hip's 1.25 rounds: cfg4 stage 5, 34.8 -> 31.8 us)
     }
+    if (dry) return 1;
     PxArgs a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.add = add; a.mask = mask; a.dst = dst; a.bits_out = bits_out;
     a.src_bytes = src_bytes; a.wgt_bytes = wgt_bytes; a.dst_bytes = dst_bytes;
     a.M = (int)M; a.C = g->C; a.N = N; a.Kc = g->C / 8; a.nkt = a.Kc / 8;
+    a.src1 = src1; a.wgt1 = wgt1; a.src1_bytes = src1_bytes; a.wgt1_bytes = wgt1_bytes; a.C1 = C1; a.Kc1 = C1 / 8; a.nkt0 = a.nkt;
+    if (seg2) a.nkt += a.Kc1 / 8;
     a.OH = g->OH; a.OW = g->OW; a.FH = g->FH > 0 ? g->FH : 0; a.FW = g->FW; a.OSH = g->OSH; a.OSW = g->OSW;
     a.rcp_ohw = 1.0f / (float)(g->OH * g->OW); a.rcp_ow = 1.0f / (float)g->OW; a.relu = relu; a.dbg = g_urso_opt.pwx_dbg;
     const int cus = urso_usable_cus();
@@ -339,10 +393,62 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
 #define URSO_PXF(TT, BN_, NST_) switch (form) { case 0: URSO_PX(TT, BN_, NST_, false, 0, false); break; case 1: URSO_PX(TT, BN_, NST_, true, 0, true); break; \
                                                 case 2: URSO_PX(TT, BN_, NST_, false, 1, false); break; case 3: URSO_PX(TT, BN_, NST_, true, 2, false); break; \
                                                 case 4: URSO_PX(TT, BN_, NST_, false, 2, false); break; default: URSO_PX(TT, BN_, NST_, true, 0, false); }
-    if (dt == URSO_BF16) { if (bn == 256) { URSO_PXF(__bf16, 256, 3) } else { URSO_PXF(__bf16, 128, 4) } }
+#define URSO_PX2(TT, BN_, NST_) do { if (form == 4) URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, false, 2, false, true>), grid, blk, 0, st, a); \
+                                     else URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, false, 0, false, true>), grid, blk, 0, st, a); } while (0)
+    if (seg2) {
+        if (dt == URSO_BF16) { if (bn == 256) URSO_PX2(__bf16, 256, 3); else URSO_PX2(__bf16, 128, 4); }
+        else { if (bn == 256) URSO_PX2(_Float16, 256, 3); else URSO_PX2(_Float16, 128, 4); }
+    }
+    else if (dt == URSO_BF16) { if (bn == 256) { URSO_PXF(__bf16, 256, 3) } else { URSO_PXF(__bf16, 128, 4) } }
     else { if (bn == 256) { URSO_PXF(_Float16, 256, 3) } else { URSO_PXF(_Float16, 128, 4) } }
+#undef URSO_PX2
 #undef URSO_PXF
 #undef URSO_PX
     const int rc = urso_check_launch("urso_conv_igemm(pwx)");
     return rc == URSO_OK ? 1 : rc;
+}
+
+// ---------------------------------------------------------------- C ABI: two pointwise convolutions over the same pixels, summed
+// dst[M][N] = epilogue(src0[M][C0] . wgt0[N][C0]^T + src1[M][C1] . wgt1[N][C1]^T): the two data gradients that meet in the input of a
+// stage's first block -- the projection shortcut's (net.py:148-157, res{3,4,5}a_branch1) and branch2a's (net.py:138) -- as one launch.
+// M = B * OH * OW dense pixels (the compact gradient grid), flags: URSO_EPI_RELU, URSO_EPI_MASK_BITS (mask_d = ReLU bit mask of dst).
+static int pw2_check(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags, const void* mask_d) {
+    if (B <= 0 || OH <= 0 || OW <= 0 || C0 <= 0 || C1 <= 0 || N <= 0) return URSO_EINVAL;
+    if ((dt != URSO_BF16 && dt != URSO_F16) || (C0 % 64) || (C1 % 64) || (N % 8)) return URSO_EINVAL;
+    if (flags & ~(URSO_EPI_RELU | URSO_EPI_MASK_BITS)) return URSO_EINVAL;
+    if (mask_d && !(flags & URSO_EPI_MASK_BITS)) return URSO_EINVAL;
+    if ((flags & URSO_EPI_MASK_BITS) && (N % 32)) return URSO_EINVAL;       // a lane picks its mask byte out of the dword of its pixel's 32 channels
+    const size_t M = (size_t)B * OH * OW;
+    if (M * (size_t)(C0 > C1 ? C0 : C1) * 2 >= 0x7FFFFF00ull || M * (size_t)N * 2 >= 0x7FFFFF00ull) return URSO_EINVAL;
+    return URSO_OK;
+}
+static urso_conv_geom pw2_geom(int B, int OH, int OW, int C0, int N) {
+    urso_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.H = OH; g.W = OW; g.C = C0; g.OH = OH; g.OW = OW; g.N = N; g.KH = g.KW = 1; g.SH = g.SW = 1; g.DH = g.DW = 1;
+    return g;
+}
+extern "C" int urso_conv_pointwise2_ok(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags) {
+    if (pw2_check(B, OH, OW, C0, C1, N, dt, flags, (flags & URSO_EPI_MASK_BITS) ? (const void*)1 : nullptr) != URSO_OK) return 0;
+    const urso_conv_geom g = pw2_geom(B, OH, OW, C0, N);
+    return urso_pwx_try2(&g, dt, 0, nullptr, nullptr, nullptr, nullptr, C1, nullptr, (flags & URSO_EPI_MASK_BITS) ? (const void*)1 : nullptr, nullptr,
+                         0, 0, 0, 0, 0, (flags & URSO_EPI_MASK_BITS) ? 1 : 0, true, nullptr) == 1;
+}
+extern "C" int urso_conv_pointwise2(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags,
+                                    const void* src0_d, const void* wgt0_d, const void* src1_d, const void* wgt1_d,
+                                    const float* bias_d, const void* mask_d, void* dst_d, void* stream) {
+    if (!src0_d || !wgt0_d || !src1_d || !wgt1_d || !dst_d) { urso_set_error("urso_conv_pointwise2: null argument"); return URSO_EINVAL; }
+    const int rc0 = pw2_check(B, OH, OW, C0, C1, N, dt, flags, mask_d);
+    if (rc0 != URSO_OK) { urso_set_error("urso_conv_pointwise2: unsupported arguments (16-bit, C0 %% 64 == C1 %% 64 == 0, N %% 8 == 0, flags RELU | MASK_BITS)"); return rc0; }
+    hipStream_t st = (hipStream_t)stream;
+    const urso_conv_geom g = pw2_geom(B, OH, OW, C0, N);
+    const size_t M = (size_t)B * OH * OW;
+    const double es = 2.0;
+    ProfScope ps(st, URSO_K_IGEMM, 2.0 * (double)M * N * (C0 + C1),
+                 (double)M * (C0 + C1) * es + (double)N * (C0 + C1) * es + (double)M * N * es + (mask_d ? (double)M * N / 8 : 0.0));
+    const int rc = urso_pwx_try2(&g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src0_d, wgt0_d, src1_d, wgt1_d, C1, bias_d, mask_d, dst_d,
+                                 (uint32_t)(M * C0 * 2), (uint32_t)((size_t)N * C0 * 2), (uint32_t)(M * C1 * 2), (uint32_t)((size_t)N * C1 * 2),
+                                 (uint32_t)(M * N * 2), mask_d ? 1 : 0, false, st);
+    if (rc == 0) { urso_set_error("urso_conv_pointwise2: the pair does not qualify for the two-segment kernel (urso_conv_pointwise2_ok)"); return URSO_EINVAL; }
+    return rc > 0 ? URSO_OK : rc;
 }

@@ -19,7 +19,7 @@ int urso_check_launch(const char* what) {
 }
 
 extern "C" const char* urso_last_error(void) { return g_err; }
-extern "C" int urso_abi_version(void) { return 8; }
+extern "C" int urso_abi_version(void) { return 9; }
 
 // ---------------------------------------------------------------- explicit policy options
 UrsoOptions g_urso_opt;

@@ -212,6 +212,7 @@ class Engine(object):
         self.acts = {}
         self.prep_ops, self.fwd_ops, self.loss_ops, self.bwd_ops, self.opt_ops = [], [], [], [], []
         self.wino_ws = None
+        self.n_entry_dgrad2 = 0
         self._cleared_once = []    # gradient buffers cleared at plan time only (scattered data gradients): (layer, buffer, H, W, C, sy, sx)
         self.loss_pre_ops = []     # DP_EXACT_REL_LOSS: the part of the loss that precedes the cross-rank sum of the two norms
         self.labels = {"prep": [], "fwd": [], "loss": [], "bwd": [], "opt": []}
@@ -746,6 +747,29 @@ class Engine(object):
                     if not X.grad_written and not getattr(X, "fwd_sampled", False):       # (a sampled block output wrote the compact mask in its forward pass)
                         self.bwd_ops.append((None, lambda X=X: hip.rows_subsample2(B, X.compact[0], X.compact[1], X.spec.c // 8, X.bits, X.bits_compact)))
                         self.labels["bwd"].append("bits_subsample")
+                    gq = c.gd_compact
+                    first = getattr(X, "_compact_first", None)
+                    if (first is not None and X.grad_written and os.environ.get("URSO_ENTRY_DGRAD2", "1") != "0" and
+                            hip.conv_pointwise2_ok(B, gq.OH, gq.OW, first[1].npad, c.npad, node.cin, dt, hip.EPI_MASK_BITS)):
+                        # the SECOND stride-2 consumer of X (a stage's first block: the projection shortcut and branch2a, net.py:121-126, 148-157):
+                        # both data gradients in ONE launch with two reduction segments (urso_conv_pointwise2) -- dL/dX is written once and
+                        # rounded once instead of written by the first launch, read back and rewritten by this one.  The first launch becomes
+                        # a no-op where it stood (its operands -- the block output's gradient, its filter -- outlive it: every tensor has its
+                        # own gradient buffer); the sum runs in the same order (shortcut first).  URSO_ENTRY_DGRAD2=0: the two launches (A/B).
+                        i0, c0, G0 = first
+                        self.bwd_ops[i0] = (None, lambda: None)
+                        self.labels["bwd"][i0] = None
+                        self.bwd_ops.append((None, lambda c=c, c0=c0, G0=G0, G=G, X=X, gq=gq, N=node.cin:
+                                             hip.conv_pointwise2(B, gq.OH, gq.OW, c0.npad, c.npad, N, dt, hip.EPI_MASK_BITS, G0, c0.wd, G, c.wd, None,
+                                                                 X.bits_compact, X.grad)))
+                        self.labels["bwd"].append("dgrad:%s+%s" % (c0.name, node.name))
+                        X._compact_first = None
+                        self.n_entry_dgrad2 = getattr(self, "n_entry_dgrad2", 0) + 1
+                        continue
+                    if not X.grad_written:
+                        X._compact_first = (len(self.bwd_ops), c, G)
+                    else:
+                        X._compact_first = None            # a third writer: no merge
                     self.bwd_ops.append((None, lambda c=c, G=G, X=X, add=(X.grad if X.grad_written else None):
                                          hip.conv_igemm_ex(c.gd_compact, dt, hip.EPI_MASK_BITS, G, c.wd, None, add, X.bits_compact, X.grad, None, None)))
                     self.labels["bwd"].append("dgrad:" + node.name)

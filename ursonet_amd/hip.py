@@ -176,6 +176,8 @@ _SIGS = {
     "urso_prof_enable": (_i, [_i]),
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
     "urso_prof_collect_ex": (_i, [C.POINTER(ProfRecordEx), _i]),
+    "urso_conv_pointwise2_ok": (_i, [_i] * 8),
+    "urso_conv_pointwise2": (_i, [_i] * 8 + [_vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 for _name, (_res, _args) in _SIGS.items():
@@ -357,6 +359,16 @@ def conv_igemm_halo2_shape(g, dt, flags, has_add=False, has_ws=False):
 def conv_igemm_ex(g, dt, flags, src, wgt, bias, add, mask, dst, bits_out=None, ws=None, stream=None):
     _chk(_lib.urso_conv_igemm_ex(C.byref(g), dt, flags, ptr(src), ptr(wgt), ptr(bias), ptr(add), ptr(mask), ptr(dst), ptr(bits_out),
                                  ptr(ws), (ws.numel() * ws.element_size()) if ws is not None else 0, stream_ptr(stream)), "urso_conv_igemm_ex")
+
+
+def conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags):
+    return bool(_lib.urso_conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags))
+
+
+def conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, src0, wgt0, src1, wgt1, bias, mask, dst, stream=None):
+    """dst = epilogue(src0 . wgt0^T + src1 . wgt1^T): two pointwise layers over the same pixels in one launch (include/ursonet_hip.h)."""
+    _chk(_lib.urso_conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, ptr(src0), ptr(wgt0), ptr(src1), ptr(wgt1), ptr(bias), ptr(mask), ptr(dst),
+                                   stream_ptr(stream)), "urso_conv_pointwise2")
 
 
 def conv_wgrad_ws_bytes(g, dt):
