@@ -220,18 +220,23 @@ int urso_conv_pointwise_sampled(const urso_conv_geom* g, int dt, int flags, cons
                                 const void* add_d, void* dst_d, void* bits_out_d, void* dst_sampled_d, void* stream);
 
 /* TWO pointwise convolutions over the same pixels, summed, in one launch (conv_pwx.hip, two reduction segments):
- *   dst[M][N] = epilogue(src0[M][C0] . wgt0[N][C0]^T + src1[M][C1] . wgt1[N][C1]^T),  M = B * OH * OW dense pixels.
- * The case it exists for: the data gradients that meet in the input X of a stage's first block -- Conv2DBackpropInput of the projection
- * shortcut 'res{3,4,5}a_branch1' (net.py:148-157) and of 'res{3,4,5}a_branch2a' (net.py:138), both 1x1 / stride 2 on X -- on the compact
- * (sampled) gradient grid: dL/dX is written once, rounded once, instead of written by one launch, read back and rewritten by the other.
- * 16-bit dtypes, C0 % 64 == C1 % 64 == 0, N % 8 == 0; wgt* in the [N][K] data-gradient layout of urso_conv_weight_prep; flags:
- * URSO_EPI_RELU, URSO_EPI_MASK_BITS with mask_d = the ReLU bit mask of dst (1 byte per 8 elements; N % 32 == 0 then).  urso_conv_pointwise2_ok() tells
- * whether the big-tile kernel takes the pair (else the caller launches the two layers one after the other); same k order per segment as
- * the single-layer kernel, segment 0 first. */
+ *   dst[M][N] = epilogue(src0[M][C0] . wgt0[N][C0]^T + src1[M][C1] . wgt1[N][C1]^T + bias),  M = B * OH * OW dense pixels.
+ * The cases it exists for, both in a stage's first block (conv_block, net.py:120-158):
+ *   - backward: the data gradients that meet in the block's input X -- Conv2DBackpropInput of the projection shortcut 'res{3,4,5}a_branch1'
+ *     (net.py:148-157) and of 'res{3,4,5}a_branch2a' (net.py:138), both 1x1 / stride 2 on X -- on the compact (sampled) gradient grid: dL/dX
+ *     is written once, rounded once, instead of written by one launch, read back and rewritten by the other (flags URSO_EPI_MASK_BITS,
+ *     mask_d = the ReLU bit mask of dst);
+ *   - forward: 'res{4,5}a_branch2c' + BatchNorm and the projection shortcut 'res{4,5}a_branch1' + BatchNorm + Add + ReLU (net.py:148-157) -- the
+ *     shortcut is 1 more reduction segment of branch2c's GEMM, its output tensor is never written or read back, its launch disappears
+ *     (flags URSO_EPI_RELU | URSO_EPI_EMIT_BITS, bits_out_d as in urso_conv_igemm_ex; bias_d = the SUM of the two folded biases:
+ *     urso_param_desc::bias_from).
+ * 16-bit dtypes, C0 % 64 == C1 % 64 == 0, N % 8 == 0 (N % 32 == 0 with a bit mask); wgt* in the [N][K] layouts of urso_conv_weight_prep.
+ * urso_conv_pointwise2_ok() tells whether the big-tile kernel takes the pair (else the caller launches the two layers one after the
+ * other); same k order per segment as the single-layer kernel, segment 0 first. */
 int urso_conv_pointwise2_ok(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags);
 int urso_conv_pointwise2(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags,
                          const void* src0_d, const void* wgt0_d, const void* src1_d, const void* wgt1_d,
-                         const float* bias_d, const void* mask_d, void* dst_d, void* stream);
+                         const float* bias_d, const void* mask_d, void* dst_d, void* bits_out_d, void* stream);
 
 /* 3x3 / stride-1 layers with >= 128 channels and filters run in the halo-tile kernel (conv_halo.hip) when urso_conv_igemm_halo_ok()
  * says so (policy option "hconv"; has_add: a residual operand keeps the layer on the DMA kernel).  Given a workspace of
@@ -374,6 +379,8 @@ typedef struct urso_param_desc {
     int32_t KH, KW, C, N, npad, K;        /* K = KH*KW*C; dw rows and wd rows have stride npad, w and gw rows stride N */
     int32_t splits, ks, kb;               /* wgrad partial count; finalisation k-slabs */
     int32_t trainable, bn_trainable;
+    int32_t bias_from;                    /* PREP: 1 + index (in the same descriptor array) of a layer whose folded bias is ADDED to this layer's biasf,
+                                           * 0 = none: the projection shortcut computed inside this layer's launch (urso_conv_pointwise2, forward form) */
     float eps, regc, regb;
     const float *w, *b, *gamma, *beta, *mean, *var;     /* fp32 parameters (b / BN tensors may be NULL) */
     void *wf, *wd;                                       /* compute-dtype layouts written by PREP (wd may be NULL) */

@@ -226,8 +226,11 @@ class StorageRounding(object):
     gradient).  In exact arithmetic this is the plain oracle; it exists so that the 16-bit device path can be
     compared at 1e-2 per tensor instead of by cosine similarity.  Frozen BN only (TRAIN_BN False)."""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, unstored=()):
         self.dtype = dtype
+        # projection shortcuts the device computes INSIDE the launch of the layer that adds them (Engine.shortcut_folded: stage 2's fused pair,
+        # stages 4-5's two-segment branch2c): their output never reaches a 16-bit tensor, so it is not rounded here either
+        self.unstored = set(unstored)
 
     def weight(self, w):
         return w + (w.detach().to(self.dtype).to(w.dtype) - w.detach())
@@ -280,7 +283,9 @@ def conv_block(x, P, stage, block, stride, train_bn, hook=None, q=None):
     y = _st(relu(conv_bn(x, P[cb + "2a"], P[bb + "2a"], train_bn, stride=stride, q=q), cb + "2a", hook), q)
     y = _st(relu(conv_bn(y, P[cb + "2b"], P[bb + "2b"], train_bn, padding="same", q=q), cb + "2b", hook), q)
     y = conv_bn(y, P[cb + "2c"], P[bb + "2c"], train_bn, q=q)
-    sc = _st(conv_bn(x, P[cb + "1"], P[bb + "1"], train_bn, stride=stride, q=q), q)
+    sc = conv_bn(x, P[cb + "1"], P[bb + "1"], train_bn, stride=stride, q=q)
+    if q is None or (cb + "1") not in q.unstored:
+        sc = _st(sc, q)
     return _st(relu(y + sc, cb + "2c", hook), q)
 
 

@@ -940,6 +940,45 @@ def test_pointwise2_two_reduction_segments(dt, masked, shape):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("emit", [True, False], ids=["emit_bits", "no_bits"])
+@pytest.mark.parametrize("shape", [(2, 32, 40, 256, 512, 1024, 0), (4, 16, 20, 512, 1024, 2048, 0), (3, 20, 24, 128, 256, 512, 16)],
+                         ids=["stage4_entry", "stage5_entry", "ragged_capped"])
+def test_pointwise2_forward_form_shortcut_inside(dt, emit, shape):
+    """urso_conv_pointwise2, forward form: out = ReLU(b . W2c^T + x . Wbr1^T + bias) with the emitted ReLU bit mask -- branch2c of a stage's
+    first block with the projection shortcut as a second reduction segment (net.py:148-157) -- against a CPU fp32 reference rounded once, and
+    against the two urso_conv_igemm_ex launches it replaces (shortcut stored in 16 bits, then added: one more rounding step)."""
+    hip = _hip()
+    B, OH, OW, C0, C1, N, cap = shape
+    M = B * OH * OW
+    tdt = hip.TORCH_DT[dt]
+    torch.manual_seed(M + C0 + dt)
+    flags = hip.EPI_RELU | (hip.EPI_EMIT_BITS if emit else 0)
+    with hip.options(pwx=2, grid_cap=cap):
+        assert hip.conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags)
+        x0, x1 = dev(torch.randn(M, C0), dt), dev(torch.randn(M, C1), dt)
+        w0, w1 = dev(torch.randn(N, C0) / C0 ** 0.5, dt), dev(torch.randn(N, C1) / C1 ** 0.5, dt)
+        b0, b1 = torch.randn(N, device="cuda") * 0.3, torch.randn(N, device="cuda") * 0.3
+        dst = torch.full((M, N), 9.0, device="cuda").to(tdt)
+        bits = torch.full((M, N // 8), 0xAA, dtype=torch.uint8, device="cuda") if emit else None
+        hip.conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, x0, w0, x1, w1, b0 + b1, None, dst, bits)
+        torch.cuda.synchronize()
+        f = lambda t: t.float().cpu()
+        ref = torch.relu(f(x0) @ f(w0).T + f(x1) @ f(w1).T + (b0 + b1).cpu()).to(tdt).float()
+        tol = 8e-3 if dt == 1 else 1e-3
+        assert float((f(dst) - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+        if emit:
+            pos = (dst.float() > 0).reshape(-1, 8).to(torch.int32)
+            exp = (pos << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+            assert torch.equal(bits.reshape(-1), exp) and 0.2 < float(pos.float().mean()) < 0.8
+        g0, g1 = hip.geom(B, OH, OW, C0, OH, OW, N, 1, 1), hip.geom(B, OH, OW, C1, OH, OW, N, 1, 1)
+        sc, two = torch.empty_like(dst), torch.empty_like(dst)
+        hip.conv_igemm_ex(g1, dt, 0, x1, w1, b1, None, None, sc, None)                       # the shortcut, stored
+        hip.conv_igemm_ex(g0, dt, hip.EPI_RELU, x0, w0, b0, sc, None, two, None)              # branch2c + shortcut + ReLU
+        torch.cuda.synchronize()
+        assert float((dst.float() - two.float()).abs().max()) <= 2 * tol * max(1.0, float(two.float().abs().max()))
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("c", [64, 128], ids=["stage2", "stage3"])
 @pytest.mark.parametrize("shape", [(1, 8, 8, 0), (3, 24, 40, 0), (2, 64, 80, 8), (4, 128, 160, 0), (32, 32, 40, 0)],
                          ids=["one_tile", "small", "capped", "multi_tile", "chip"])

@@ -103,7 +103,7 @@ def layerwise_errors(eng, w0, img, cfg, dtype):
     """One pass over the plan of an engine that has just run ONE training step from weights w0 on the loaded batch.
     Returns {check name: {layer or tensor: (max-norm error, Euclidean error)}} and the lists of what could not be read."""
     from oracle import graph_ref as G
-    q = G.StorageRounding(dtype)
+    q = G.StorageRounding(dtype, unstored=getattr(eng, "shortcut_folded", ()))
     rnd = lambda t: t.to(dtype).float()
     dev = DeviceTensors(eng)
     P = G.to_torch(w0)

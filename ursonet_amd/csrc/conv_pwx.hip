@@ -340,12 +340,12 @@ int urso_pwx_try(const urso_conv_geom* g, int dt, int relu, const void* src, con
     return pwx_try_impl(g, dt, relu, src, wgt, bias, add, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, bits_out, nullptr, nullptr, 0, 0, 0, false, st);
 }
 // Two reduction segments (PxArgs::src1 ...): g describes segment 0 (C = its channels), C1 the channels of segment 1; `dry` only answers
-// whether the pair qualifies.  Forms: no residual, no emitted mask; mask = none or a ReLU bit mask.
+// whether the pair qualifies.  Forms: no residual; mask = none or a ReLU bit mask (data gradients), or no mask and an EMITTED bit mask (forward).
 int urso_pwx_try2(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const void* src1, const void* wgt1, int C1,
                   const float* bias, const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t src1_bytes, uint32_t wgt1_bytes,
-                  uint32_t dst_bytes, int mask_bits, bool dry, hipStream_t st) {
-    if (C1 <= 0 || (C1 % 64) || (mask && !mask_bits)) return 0;
-    return pwx_try_impl(g, dt, relu, src, wgt, bias, nullptr, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, nullptr, src1, wgt1, C1, src1_bytes, wgt1_bytes, dry, st);
+                  uint32_t dst_bytes, int mask_bits, void* bits_out, bool dry, hipStream_t st) {
+    if (C1 <= 0 || (C1 % 64) || (mask && !mask_bits) || (mask && bits_out)) return 0;
+    return pwx_try_impl(g, dt, relu, src, wgt, bias, nullptr, mask, dst, src_bytes, wgt_bytes, dst_bytes, mask_bits, bits_out, src1, wgt1, C1, src1_bytes, wgt1_bytes, dry, st);
 }
 static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* src, const void* wgt, const float* bias, const void* add,
                         const void* mask, void* dst, uint32_t src_bytes, uint32_t wgt_bytes, uint32_t dst_bytes, int mask_bits, void* bits_out,
@@ -357,9 +357,11 @@ static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* s
     const bool emit = bits_out != nullptr;
     // instantiated epilogue forms: (add, maskk, emit)
     const int form = (!add && !maskk && !emit) ? 0 : (add && !maskk && emit) ? 1 : (!add && maskk == 1 && !emit) ? 2 :
-                     (add && maskk == 2 && !emit) ? 3 : (!add && maskk == 2 && !emit) ? 4 : (add && !maskk && !emit) ? 5 : -1;
+                     (add && maskk == 2 && !emit) ? 3 : (!add && maskk == 2 && !emit) ? 4 : (add && !maskk && !emit) ? 5 :
+                     (seg2 && !add && !maskk && emit) ? 6 : -1;
     if (form < 0 || (g->C % 64) || (g->N % 8)) return 0;
-    if (seg2 && form != 0 && form != 4) return 0;
+    if (seg2 && form != 0 && form != 4 && form != 6) return 0;
+    if (emit && (g->N % 32)) return 0;
     const long long M = (long long)g->B * g->OH * g->OW;
     const int K = g->C + (seg2 ? C1 : 0), N = g->N;
     if (mode == 1) {
@@ -394,6 +396,7 @@ static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* s
                                                 case 2: URSO_PX(TT, BN_, NST_, false, 1, false); break; case 3: URSO_PX(TT, BN_, NST_, true, 2, false); break; \
                                                 case 4: URSO_PX(TT, BN_, NST_, false, 2, false); break; default: URSO_PX(TT, BN_, NST_, true, 0, false); }
 #define URSO_PX2(TT, BN_, NST_) do { if (form == 4) URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, false, 2, false, true>), grid, blk, 0, st, a); \
+                                     else if (form == 6) URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, false, 0, true, true>), grid, blk, 0, st, a); \
                                      else URSO_KLAUNCH((pwx_kernel<TT, 5, BN_, NST_, false, 0, false, true>), grid, blk, 0, st, a); } while (0)
     if (seg2) {
         if (dt == URSO_BF16) { if (bn == 256) URSO_PX2(__bf16, 256, 3); else URSO_PX2(__bf16, 128, 4); }
@@ -412,12 +415,13 @@ static int pwx_try_impl(const urso_conv_geom* g, int dt, int relu, const void* s
 // dst[M][N] = epilogue(src0[M][C0] . wgt0[N][C0]^T + src1[M][C1] . wgt1[N][C1]^T): the two data gradients that meet in the input of a
 // stage's first block -- the projection shortcut's (net.py:148-157, res{3,4,5}a_branch1) and branch2a's (net.py:138) -- as one launch.
 // M = B * OH * OW dense pixels (the compact gradient grid), flags: URSO_EPI_RELU, URSO_EPI_MASK_BITS (mask_d = ReLU bit mask of dst).
-static int pw2_check(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags, const void* mask_d) {
+static int pw2_check(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags, const void* mask_d, const void* bits_out_d) {
     if (B <= 0 || OH <= 0 || OW <= 0 || C0 <= 0 || C1 <= 0 || N <= 0) return URSO_EINVAL;
     if ((dt != URSO_BF16 && dt != URSO_F16) || (C0 % 64) || (C1 % 64) || (N % 8)) return URSO_EINVAL;
-    if (flags & ~(URSO_EPI_RELU | URSO_EPI_MASK_BITS)) return URSO_EINVAL;
-    if (mask_d && !(flags & URSO_EPI_MASK_BITS)) return URSO_EINVAL;
-    if ((flags & URSO_EPI_MASK_BITS) && (N % 32)) return URSO_EINVAL;       // a lane picks its mask byte out of the dword of its pixel's 32 channels
+    if (flags & ~(URSO_EPI_RELU | URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) return URSO_EINVAL;
+    if ((flags & URSO_EPI_MASK_BITS) && (flags & URSO_EPI_EMIT_BITS)) return URSO_EINVAL;
+    if ((mask_d != nullptr) != ((flags & URSO_EPI_MASK_BITS) != 0) || (bits_out_d != nullptr) != ((flags & URSO_EPI_EMIT_BITS) != 0)) return URSO_EINVAL;
+    if ((flags & (URSO_EPI_MASK_BITS | URSO_EPI_EMIT_BITS)) && (N % 32)) return URSO_EINVAL;       // a lane handles the mask byte of its pixel's 32 channels as part of one dword
     const size_t M = (size_t)B * OH * OW;
     if (M * (size_t)(C0 > C1 ? C0 : C1) * 2 >= 0x7FFFFF00ull || M * (size_t)N * 2 >= 0x7FFFFF00ull) return URSO_EINVAL;
     return URSO_OK;
@@ -429,26 +433,27 @@ static urso_conv_geom pw2_geom(int B, int OH, int OW, int C0, int N) {
     return g;
 }
 extern "C" int urso_conv_pointwise2_ok(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags) {
-    if (pw2_check(B, OH, OW, C0, C1, N, dt, flags, (flags & URSO_EPI_MASK_BITS) ? (const void*)1 : nullptr) != URSO_OK) return 0;
+    const void* one = (const void*)1;
+    if (pw2_check(B, OH, OW, C0, C1, N, dt, flags, (flags & URSO_EPI_MASK_BITS) ? one : nullptr, (flags & URSO_EPI_EMIT_BITS) ? one : nullptr) != URSO_OK) return 0;
     const urso_conv_geom g = pw2_geom(B, OH, OW, C0, N);
-    return urso_pwx_try2(&g, dt, 0, nullptr, nullptr, nullptr, nullptr, C1, nullptr, (flags & URSO_EPI_MASK_BITS) ? (const void*)1 : nullptr, nullptr,
-                         0, 0, 0, 0, 0, (flags & URSO_EPI_MASK_BITS) ? 1 : 0, true, nullptr) == 1;
+    return urso_pwx_try2(&g, dt, 0, nullptr, nullptr, nullptr, nullptr, C1, nullptr, (flags & URSO_EPI_MASK_BITS) ? one : nullptr, nullptr,
+                         0, 0, 0, 0, 0, (flags & URSO_EPI_MASK_BITS) ? 1 : 0, (flags & URSO_EPI_EMIT_BITS) ? (void*)1 : nullptr, true, nullptr) == 1;
 }
 extern "C" int urso_conv_pointwise2(int B, int OH, int OW, int C0, int C1, int N, int dt, int flags,
                                     const void* src0_d, const void* wgt0_d, const void* src1_d, const void* wgt1_d,
-                                    const float* bias_d, const void* mask_d, void* dst_d, void* stream) {
+                                    const float* bias_d, const void* mask_d, void* dst_d, void* bits_out_d, void* stream) {
     if (!src0_d || !wgt0_d || !src1_d || !wgt1_d || !dst_d) { urso_set_error("urso_conv_pointwise2: null argument"); return URSO_EINVAL; }
-    const int rc0 = pw2_check(B, OH, OW, C0, C1, N, dt, flags, mask_d);
-    if (rc0 != URSO_OK) { urso_set_error("urso_conv_pointwise2: unsupported arguments (16-bit, C0 %% 64 == C1 %% 64 == 0, N %% 8 == 0, flags RELU | MASK_BITS)"); return rc0; }
+    const int rc0 = pw2_check(B, OH, OW, C0, C1, N, dt, flags, mask_d, bits_out_d);
+    if (rc0 != URSO_OK) { urso_set_error("urso_conv_pointwise2: unsupported arguments (16-bit, C0 %% 64 == C1 %% 64 == 0, N %% 8 == 0 (32 with a bit mask), flags RELU | MASK_BITS | EMIT_BITS)"); return rc0; }
     hipStream_t st = (hipStream_t)stream;
     const urso_conv_geom g = pw2_geom(B, OH, OW, C0, N);
     const size_t M = (size_t)B * OH * OW;
     const double es = 2.0;
     ProfScope ps(st, URSO_K_IGEMM, 2.0 * (double)M * N * (C0 + C1),
-                 (double)M * (C0 + C1) * es + (double)N * (C0 + C1) * es + (double)M * N * es + (mask_d ? (double)M * N / 8 : 0.0));
+                 (double)M * (C0 + C1) * es + (double)N * (C0 + C1) * es + (double)M * N * es + ((mask_d || bits_out_d) ? (double)M * N / 8 : 0.0));
     const int rc = urso_pwx_try2(&g, dt, (flags & URSO_EPI_RELU) ? 1 : 0, src0_d, wgt0_d, src1_d, wgt1_d, C1, bias_d, mask_d, dst_d,
                                  (uint32_t)(M * C0 * 2), (uint32_t)((size_t)N * C0 * 2), (uint32_t)(M * C1 * 2), (uint32_t)((size_t)N * C1 * 2),
-                                 (uint32_t)(M * N * 2), mask_d ? 1 : 0, false, st);
+                                 (uint32_t)(M * N * 2), mask_d ? 1 : 0, bits_out_d, false, st);
     if (rc == 0) { urso_set_error("urso_conv_pointwise2: the pair does not qualify for the two-segment kernel (urso_conv_pointwise2_ok)"); return URSO_EINVAL; }
     return rc > 0 ? URSO_OK : rc;
 }

@@ -11,12 +11,21 @@ __device__ __forceinline__ float bn_scale(const float* gamma, const float* var, 
 
 // One block = one (tap, 32-channel, 32-filter) tile: reads W[tap][c][n] coalesced along n, writes
 // wd[c][ftap][n] coalesced along n and wf[n][tap][c] coalesced along c through an LDS transpose.
+// the folded bias of ANOTHER layer (urso_param_desc::bias_from): b * s + beta - mean * s with s = gamma / sqrt(var + eps), 0 outside its filters
+__device__ __forceinline__ float folded_bias(const urso_param_desc& o, int n) {
+    if (n >= o.N) return 0.f;
+    const float s = bn_scale(o.gamma, o.var, o.eps, n);
+    float bf = o.b ? o.b[n] * s : 0.f;
+    if (o.gamma) bf += o.beta[n] - o.mean[n] * s;
+    return bf;
+}
+
 template <typename T>
 __device__ __forceinline__ void weight_prep_body(int bx, int by, int tap, int KH, int KW, int C, int N, int npad,
                                    const float* __restrict__ w, const float* __restrict__ b,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                   void* wf, void* wd, float* biasf, float* scale) {
+                                   void* wf, void* wd, float* biasf, float* scale, const urso_param_desc* extra = nullptr) {
     __shared__ float tile[32][33];
     const int c0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads: 32 x 8
@@ -42,6 +51,7 @@ __device__ __forceinline__ void weight_prep_body(int bx, int by, int tap, int KH
             sc = s;
             bf = (b ? b[n] * s : 0.f);
             if (gamma) bf += beta[n] - mean[n] * s;
+            if (extra) bf += folded_bias(*extra, n);
         }
         biasf[n] = bf; scale[n] = sc;
     }
@@ -54,7 +64,7 @@ __device__ __forceinline__ void weight_prep_body64(int bx, int by, int tap, int 
                                    const float* __restrict__ w, const float* __restrict__ b,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                   void* wf, void* wd, float* biasf, float* scale) {
+                                   void* wf, void* wd, float* biasf, float* scale, const urso_param_desc* extra = nullptr) {
     __shared__ float tile[64][65];
     const int c0 = bx * 64, n0 = by * 64;
     const int tq = threadIdx.x & 15, tr = threadIdx.x >> 4;        // 16 quads x 16 rows
@@ -88,7 +98,7 @@ __device__ __forceinline__ void weight_prep_body64(int bx, int by, int tap, int 
             const int nq = n + q;
             if (nq < npad) {
                 float bf = 0.f, sc = 1.f;
-                if (nq < N) { sc = s[q]; bf = (b ? b[nq] * s[q] : 0.f); if (gamma) bf += beta[nq] - mean[nq] * s[q]; }
+                if (nq < N) { sc = s[q]; bf = (b ? b[nq] * s[q] : 0.f); if (gamma) bf += beta[nq] - mean[nq] * s[q]; if (extra) bf += folded_bias(*extra, nq); }
                 biasf[nq] = bf; scale[nq] = sc;
             }
         }
@@ -109,17 +119,18 @@ template <typename T>
 __global__ void weight_prep_batch_kernel(const urso_param_desc* __restrict__ descs, const int32_t* __restrict__ blockmap) {
     const urso_param_desc& d = descs[blockmap[2 * blockIdx.x]];
     const int local = blockmap[2 * blockIdx.x + 1];
+    const urso_param_desc* extra = d.bias_from > 0 ? &descs[d.bias_from - 1] : nullptr;
     if (((d.C | d.N | d.npad) & 3) == 0) {                          // aligned layers: 64 x 64 vector form
         const int gx = ceil_div(d.C, 64), gy = ceil_div(d.npad, 64);
         const int bx = local % gx, by = (local / gx) % gy, tap = local / (gx * gy);
         weight_prep_body64<T>(bx, by, tap, d.KH, d.KW, d.C, d.N, d.npad, d.w, d.b, d.gamma, d.beta, d.mean, d.var, d.eps,
-                              d.wf, d.wd, d.biasf, d.scale);
+                              d.wf, d.wd, d.biasf, d.scale, extra);
         return;
     }
     const int gx = ceil_div(d.C, 32), gy = ceil_div(d.npad, 32);
     const int bx = local % gx, by = (local / gx) % gy, tap = local / (gx * gy);
     weight_prep_body<T>(bx, by, tap, d.KH, d.KW, d.C, d.N, d.npad, d.w, d.b, d.gamma, d.beta, d.mean, d.var, d.eps,
-                        d.wf, d.wd, d.biasf, d.scale);
+                        d.wf, d.wd, d.biasf, d.scale, extra);
 }
 
 extern "C" int urso_conv_weight_prep(int KH, int KW, int C, int N, int npad, int dt,

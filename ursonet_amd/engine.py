@@ -418,6 +418,7 @@ class Engine(object):
                 max_ws = max(max_ws, hip.conv_wgrad_ws_bytes(c.gf, dt))
                 max_fin_ws = max(max_fin_ws, hip.param_grad_finalize_ws_bytes(147, c.N))
         self._fuse_pointwise_pairs()
+        self._fuse_entry_shortcuts()
         self._fuse_dense_heads()
         self.igemm_ws = torch.empty(max_igemm_ws // 4 + 16, dtype=torch.float32, device=dev)
         self.bn_ws = torch.empty(max_bn_ws // 8 + 32, dtype=torch.float64, device=dev) if max_bn_ws else None
@@ -931,7 +932,7 @@ class Engine(object):
         What pays (tools/probes/overlap_probe.py, profiles/r05_overlap_probe.txt): an HBM-bound chain and an MFMA-bound chain side by side
         finish 9-12 % sooner than one after the other; two chains of the same kind only get in each other's way (every grid is a static
         partition of its tiles over all 256 CUs, and a block that finds its CU held by the other launch runs behind it).  Hence the
-        COMPLEMENTARY fork (URSO_WGRAD_STREAM=2, the default): only the arithmetic-heavy weight gradients (>= 150 FLOP per byte: stages 4-5,
+        COMPLEMENTARY fork (URSO_WGRAD_STREAM=2; the default until round 5, opt-in since): only the arithmetic-heavy weight gradients (>= 150 FLOP per byte: stages 4-5,
         the 3x3 layers of stage 3, bottleneck_layer, the heads) leave the chain, and those whose dz is final before the data gradients reach
         stage 3 are DEFERRED to that point, where the chain turns HBM-bound (stage-3 / stage-2 data gradients and weight gradients).  Join =
         the bucket's reduction.  cfg2, alternating in one gpurun call: 7.13 -> 6.97 ms (-2.1 %), bit-identical to the single chain (same
@@ -943,7 +944,13 @@ class Engine(object):
         its predecessors (stale operands from the previous replay; ROCm 7.2, profiles/r05_fork.txt) -- eager streams did not."""
         self.wgrad_stream = None
         self._single_chain_always = False
-        mode = int(os.environ.get("URSO_WGRAD_STREAM", "2"))
+        self._graph_events = []
+        # OPT-IN since round 6 (ADVICE r05): hipGraphLaunch of a forked graph segfaulted inside the ROCm 7.2 runtime in a long-lived process (a pytest
+        # run, after ~22 engines of various sizes had come and gone; reproducible for that sequence, gone with URSO_WGRAD_STREAM=0, not cured by
+        # keeping the capture's events alive) -- a failure no verification can turn into a fallback.  bench.py opts in (a fresh process: the
+        # same path has run hundreds of times there without incident, and it checks the fork against the chain first); the tests of the fork
+        # run in processes of their own (tests/workers/fork_worker.py).
+        mode = int(os.environ.get("URSO_WGRAD_STREAM", "0"))
         if mode not in (1, 2) or self.mode != "training" or getattr(self, "no_wgrad_fork", False):       # (no_wgrad_fork: set by ursonet_amd/dp.py)
             return
         import re
@@ -1019,7 +1026,7 @@ class Engine(object):
                     return op()
                 main = torch.cuda.current_stream(self.device)
                 if self._main_moved or not self._side_open:         # one edge per fork (see above)
-                    self.wgrad_stream.wait_stream(main)
+                    self._stream_edge(main, self.wgrad_stream)
                     self._main_moved = False
                 with torch.cuda.stream(self.wgrad_stream):
                     op()
@@ -1051,9 +1058,20 @@ class Engine(object):
         self.bwd_ops = ops
         self.opt_ops[0] = joined(self.opt_ops[0])
 
+    def _stream_edge(self, src, dst):
+        """dst waits for what src holds now.  Stream.wait_stream() records a temporary event and lets Python destroy it right away; while a
+        stream is capturing, that event becomes part of the graph being built, and a hipGraph replay long after its events were destroyed is
+        the one place this code base has seen hipGraphLaunch segfault (round 5: after ~20 dropped engines; round 6: after 22 tests of one
+        process).  Events recorded during a capture therefore live as long as the engine that owns the graph."""
+        ev = torch.cuda.Event()
+        ev.record(src)
+        dst.wait_event(ev)
+        if torch.cuda.is_current_stream_capturing():
+            self._graph_events.append(ev)
+
     def _join_weight_gradients(self):
         if self.wgrad_stream is not None and self._side_open:
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            self._stream_edge(self.wgrad_stream, torch.cuda.current_stream(self.device))
             self._side_open = False
 
     def _plan_relu_bitmasks(self):
@@ -1417,6 +1435,58 @@ class Engine(object):
             del self.fwd_ops[i]
             del self.labels["fwd"][i]
 
+    def _fuse_entry_shortcuts(self):
+        """Forward plan rewrite (round 6): the block-closing pointwise layer of a stage's FIRST block (`res{4,5}a_branch2c` + BatchNorm, then
+        Add with the projection shortcut and ReLU, net.py:148-157) and the shortcut itself (`res{4,5}a_branch1` + BatchNorm: a pointwise layer
+        on the same pixels, no activation) become ONE launch with two reduction segments (urso_conv_pointwise2): out = ReLU(b . W2c^T +
+        x . Wbr1^T + (bias2c + biasbr1)).  The shortcut's launch, its output tensor (84 MB at cfg2's stage 4: written, then read back as the
+        residual) and one rounding step disappear; the weight preparation adds the shortcut's folded bias to branch2c's (urso_param_desc::
+        bias_from).  Stages whose branch2c already sits in a fused pair (2-3) keep that form.  Nothing in the backward plan reads the
+        shortcut's output (its gradient is the block output's).  URSO_ENTRY_FWD2=0 keeps the two launches (A/B)."""
+        g, dt, B = self.graph, self.dt, self.B
+        self.n_entry_fwd2 = 0
+        if dt == hip.F32 or os.environ.get("URSO_ENTRY_FWD2", "1") == "0":
+            return
+        convs = [n for n in g.nodes if n.op != "pool"]
+        lab = self.labels["fwd"]
+        drop = []
+        outs = set(t.id for t in g.outputs.values()) | ({g.feat.id} if getattr(g, "feat", None) is not None and hasattr(g.feat, "id") else set())
+        for a_node in convs:
+            A = self.convs[a_node.name]
+            if (a_node.stem or a_node.dense or a_node.kh != 1 or a_node.kw != 1 or a_node.stride != 1 or not a_node.relu or a_node.out_f32 or
+                    a_node.residual is None or A.batch_bn or A.npad != A.N or ("fwd:" + A.name) not in lab or getattr(A.dst, "fwd_sampled", False)):
+                continue
+            S = [self.convs[n.name] for n in convs if n.dst.id == a_node.residual.id]
+            if len(S) != 1:
+                continue
+            Sc, sn = S[0], S[0].node
+            readers = [n for n in g.nodes if (n.op == "pool" and n.src.id == a_node.residual.id) or
+                       (n.op != "pool" and (n.src.id == a_node.residual.id or (n.residual is not None and n.residual.id == a_node.residual.id)))]
+            M = B * a_node.dst.h * a_node.dst.w
+            if (len(readers) != 1 or a_node.residual.id in outs or sn.stem or sn.dense or sn.kh != 1 or sn.kw != 1 or sn.relu or sn.out_f32 or
+                    sn.residual is not None or Sc.batch_bn or Sc.npad != Sc.N or Sc.N != A.N or ("fwd:" + Sc.name) not in lab or
+                    sn.dst.h != a_node.dst.h or sn.dst.w != a_node.dst.w or
+                    Sc.xin.numel() != M * sn.cin or A.xin.numel() != M * a_node.cin):       # both read dense [M][C] tensors (a strided shortcut reads the compact input)
+                continue
+            fl = hip.EPI_RELU
+            if not (hip.conv_pointwise2_ok(B, a_node.dst.h, a_node.dst.w, a_node.cin, sn.cin, A.N, dt, fl) and
+                    (A.N % 32 == 0 and hip.conv_pointwise2_ok(B, a_node.dst.h, a_node.dst.w, a_node.cin, sn.cin, A.N, dt, fl | hip.EPI_EMIT_BITS))):
+                continue
+            iA = lab.index("fwd:" + A.name)
+            self.fwd_ops[iA] = (lambda A=A, Sc=Sc, oh=a_node.dst.h, ow=a_node.dst.w, c0=a_node.cin, c1=sn.cin: hip.conv_pointwise2(
+                B, oh, ow, c0, c1, A.N, dt, hip.EPI_RELU | (hip.EPI_EMIT_BITS if A.dst.bits is not None else 0),
+                A.xin, A.wf, Sc.xin, Sc.wf, A.biasf, None, A.dst.data, A.dst.bits))
+            lab[iA] = "fwd:%s+%s" % (A.name, Sc.name)
+            A.desc.bias_from = Sc.desc_id + 1
+            A.shortcut_inside = Sc
+            drop.append(lab.index("fwd:" + Sc.name))
+            self.shortcut_folded.append(Sc.name)
+            Sc.dst.data = torch.empty(0, dtype=self.tdt, device=self.device)      # never written any more: a read fails instead of finding stale bytes
+            self.n_entry_fwd2 += 1
+        for i in sorted(drop, reverse=True):
+            del self.fwd_ops[i]
+            del lab[i]
+
     # ------------------------------------------------------------------ execution
     def run_prep(self):
         for op in self.prep_ops:
@@ -1521,6 +1591,11 @@ class Engine(object):
 
     def capture(self):
         """Capture the step (training) or prep+forward (inference) into a hipGraph."""
+        if os.environ.get("URSO_EMPTY_CACHE_BEFORE_CAPTURE", "0") == "1":      # (experiment: graph-executor crash hunting)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()
         torch.cuda.synchronize(self.device)
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))

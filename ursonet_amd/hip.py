@@ -63,7 +63,7 @@ _gp = C.POINTER(ConvGeom)
 
 class ParamDesc(C.Structure):
     """urso_param_desc (include/ursonet_hip.h): one weight layer's parameter-side tensors for the batched phases."""
-    _fields_ = ([(n, C.c_int32) for n in ("KH", "KW", "C", "N", "npad", "K", "splits", "ks", "kb", "trainable", "bn_trainable")] +
+    _fields_ = ([(n, C.c_int32) for n in ("KH", "KW", "C", "N", "npad", "K", "splits", "ks", "kb", "trainable", "bn_trainable", "bias_from")] +
                 [(n, C.c_float) for n in ("eps", "regc", "regb")] +
                 [(n, C.c_void_p) for n in ("w", "b", "gamma", "beta", "mean", "var", "wf", "wd", "biasf", "scale", "part", "colpart",
                                            "dw_raw", "colsum", "dotpart", "gw", "gb", "ggamma", "gbeta")])
@@ -177,7 +177,7 @@ _SIGS = {
     "urso_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
     "urso_prof_collect_ex": (_i, [C.POINTER(ProfRecordEx), _i]),
     "urso_conv_pointwise2_ok": (_i, [_i] * 8),
-    "urso_conv_pointwise2": (_i, [_i] * 8 + [_vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp]),
+    "urso_conv_pointwise2": (_i, [_i] * 8 + [_vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 for _name, (_res, _args) in _SIGS.items():
@@ -365,10 +365,10 @@ def conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags):
     return bool(_lib.urso_conv_pointwise2_ok(B, OH, OW, C0, C1, N, dt, flags))
 
 
-def conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, src0, wgt0, src1, wgt1, bias, mask, dst, stream=None):
-    """dst = epilogue(src0 . wgt0^T + src1 . wgt1^T): two pointwise layers over the same pixels in one launch (include/ursonet_hip.h)."""
+def conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, src0, wgt0, src1, wgt1, bias, mask, dst, bits_out=None, stream=None):
+    """dst = epilogue(src0 . wgt0^T + src1 . wgt1^T + bias): two pointwise layers over the same pixels in one launch (include/ursonet_hip.h)."""
     _chk(_lib.urso_conv_pointwise2(B, OH, OW, C0, C1, N, dt, flags, ptr(src0), ptr(wgt0), ptr(src1), ptr(wgt1), ptr(bias), ptr(mask), ptr(dst),
-                                   stream_ptr(stream)), "urso_conv_pointwise2")
+                                   ptr(bits_out), stream_ptr(stream)), "urso_conv_pointwise2")
 
 
 def conv_wgrad_ws_bytes(g, dt):
