@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Run one hipGraph-replayed training step timing for the other BASELINE.json configs (sanity + numbers)."""
-import os
+import os, sys, time
 os.environ.setdefault("URSO_WGRAD_STREAM", "2")      # as bench.py: the forked backward pass is opt-in in the library
-, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
