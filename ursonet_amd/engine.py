@@ -1591,11 +1591,6 @@ class Engine(object):
 
     def capture(self):
         """Capture the step (training) or prep+forward (inference) into a hipGraph."""
-        if os.environ.get("URSO_EMPTY_CACHE_BEFORE_CAPTURE", "0") == "1":      # (experiment: graph-executor crash hunting)
-            import gc
-            gc.collect()
-            torch.cuda.synchronize(self.device)
-            torch.cuda.empty_cache()
         torch.cuda.synchronize(self.device)
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
